@@ -1,0 +1,691 @@
+// HIP kernels of the per-generation hot path (gfx950 / MI355X).
+//
+// One *chain subgroup* of LPC lanes (1..64, power of two) updates one chain; a
+// lane owns DPL/2 coordinate PAIRS (2*pi, 2*pi+1), pi = q + u*LPC, so every row
+// access is one 16-byte load per lane, contiguous across the subgroup.  d = 100
+// -> LPC = 64 (one wavefront per chain, 50 lanes hold data); d = 8 -> LPC = 4
+// (16 chains per wavefront); d = 2 -> LPC = 1 (64 chains per wavefront).
+// Workgroup = one wavefront (64 threads): no workgroup barrier is ever needed
+// and the grid is n_items / (64/LPC) workgroups (>> 256 at the benchmark sizes).
+//
+// What one launch does = one half generation of demc.py:103-109 / 126-132: every
+// chain of group `upd` is updated against the frozen complementary pool:
+//   DREAM  dream.py:32-107  CR index, subspace mask, P distinct pairs, gamma (+jump
+//          every 5th generation), uniform + normal jitter, CR statistic, Metropolis,
+//          append to history, Welford moments of the chain's own history;
+//   DE-MC  demc.py:153-196  one pair, gamma (+jump every 10th), normal jitter,
+//          optional snooker update (extension), Metropolis, append.
+// ln_like of the shipped analytic targets is evaluated in registers (TARGET).
+// For an arbitrary host ln_like_fn the same code is split into a propose and a
+// commit kernel (STAGE).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.h"
+
+namespace bpm {
+
+constexpr int ALGO_DEMC = 0, ALGO_DREAM = 1;
+constexpr int TARGET_HOST = 0, TARGET_GAUSS = 1, TARGET_MIXTURE = 2, TARGET_BANANA = 3;
+constexpr int STAGE_FUSED = 0, STAGE_PROPOSE = 1, STAGE_COMMIT = 2;
+constexpr int WAVE = 64;
+constexpr int MAX_CR = 8;
+constexpr int TRACE_I32 = 32;   // ints per chain in the debug trace
+constexpr int TRACE_F64 = 4;
+constexpr int MAX_PARTNERS = 2 * MAX_PAIRS + 3;
+
+// Exchange buffer: world blocks of [X_local (n_local x ld) | delta (n_local) | cr_idx (n_local)],
+// rank r's block at G + r*blk.  An in-place all-gather of `blk` doubles per rank replaces the
+// MPI_Allgather of demc.py:93-94,116-117; with world == 1 it is the plain (N x ld) state matrix.
+struct Layout {
+    double* G;
+    uint64_t blk;      // doubles per rank block = n_local * (ld + 2)
+    uint32_t n_local;
+    uint32_t ld;       // row stride in doubles (dim rounded up to even: rows stay 16-byte aligned)
+    uint32_t dim;
+    uint32_t world;
+};
+
+__device__ __forceinline__ void split_id(const Layout& L, uint32_t c, uint32_t& r, uint32_t& i) {
+    r = (L.world == 1) ? 0u : c / L.n_local;
+    i = c - r * L.n_local;
+}
+__device__ __forceinline__ double* row_ptr(const Layout& L, uint32_t c) {
+    uint32_t r, i; split_id(L, c, r, i);
+    return L.G + (uint64_t)r * L.blk + (uint64_t)i * L.ld;
+}
+__device__ __forceinline__ double* delta_ptr(const Layout& L, uint32_t c) {
+    uint32_t r, i; split_id(L, c, r, i);
+    return L.G + (uint64_t)r * L.blk + (uint64_t)L.n_local * L.ld + i;
+}
+__device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
+    uint32_t r, i; split_id(L, c, r, i);
+    return L.G + (uint64_t)r * L.blk + (uint64_t)L.n_local * (L.ld + 1) + i;
+}
+
+struct PhaseArgs {
+    Layout L;
+    double* ll;            // [n_local] cached ln_like of the local chains (samplers.py:330 re-evaluates it)
+    double* hist_row;      // [n_local * ld] history row being appended (chain.py:51-54) or nullptr
+    double* llhist_row;    // [n_local] or nullptr
+    double* w_mean;        // [n_local * ld] Welford mean of each chain's own history (dream.py:128)
+    double* w_m2;          // [n_local * ld]
+    const double* tparams; // target parameter block
+    const double* cr_state;  // p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
+    unsigned long long* counters;  // accepted, rejected, nan
+    double* prop_buf;      // host-callback path: [n_local * ld] proposals by work item
+    double* aux_buf;       // host-callback path: [n_local * 2] (log_corr, ll_prop)
+    int32_t* ids_buf;      // host-callback path: [n_local] global id by work item (-1 = inactive)
+    int32_t* trace_i32;    // optional debug trace [n_local * TRACE_I32]
+    double* trace_f64;     // [n_local * TRACE_F64]
+    uint8_t* trace_mask;   // [n_local * dim]
+    PermKey pk;
+    uint64_t seed;
+    uint64_t t;            // absolute generation
+    uint32_t k;            // generation within this run_mcmc call (demc.py:78)
+    uint32_t N, lo;
+    uint32_t upd_off, n_upd, pool_off, M;   // position ranges in shuffle order
+    uint32_t mode;         // 0: work item = position (world == 1); 1: work item = local chain
+    uint32_t n_items;
+    uint32_t algo;
+    uint32_t P, n_cr;
+    uint32_t adapt_on;     // dream.py:92  burnin_gen > k
+    uint32_t cr_gate;      // dream.py:123 history length > n_cr_gen
+    uint32_t hist_len;     // rows of every chain's history before this generation
+    double gamma_scale, gamma_demc, epsilon, u_epsilon, p_snooker;
+};
+
+template <int LPC>
+__device__ __forceinline__ double gsum(double v) {
+#pragma unroll
+    for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int LPC>
+__device__ __forceinline__ int gsum_i(int v) {
+#pragma unroll
+    for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double box_muller(uint32_t w1, uint32_t w2) {
+    const double u1 = ((double)w1 + 1.0) * 2.3283064365386963e-10;
+    const double u2 = u01_32(w2);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+// ---------------------------------------------------------------------------------
+// Targets: ln_like in registers.  `v[DPL]` holds the lane's coordinates, pair chunk u
+// = coordinates (2*pi, 2*pi+1), pi = q + u*LPC.
+// ---------------------------------------------------------------------------------
+template <int TARGET, int LPC, int DPL>
+struct Target;
+
+// utils/d100_gauss.py:14-35, equicorrelated Gaussian in O(d):
+// ll = c0 - 0.5 (a S2 - b S1^2), z = y / sigma.  params [rho, c0, a, b, 1/sigma...]
+template <int LPC, int DPL>
+struct Target<TARGET_GAUSS, LPC, DPL> {
+    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < DPL / 2; ++u) {
+            const uint32_t j = 2u * (uint32_t)(q + u * LPC);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (j + e < dim) {
+                    const double z = v[2 * u + e] * tp[4 + j + e];
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+        }
+        s1 = gsum<LPC>(s1);
+        s2 = gsum<LPC>(s2);
+        return tp[1] - 0.5 * (tp[2] * s2 - tp[3] * s1 * s1);
+    }
+};
+
+// utils/dblgauss_rv.py:11-32 and its pairwise-block extension to even d:
+// params [lw1, lw2, (mx, my, 1/sx, 1/sy, rho, 1/(1-rho^2), ln_norm) x 2]
+template <int LPC, int DPL>
+struct Target<TARGET_MIXTURE, LPC, DPL> {
+    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
+        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < DPL / 2; ++u) {
+            const uint32_t j = 2u * (uint32_t)(q + u * LPC);
+            if (j + 1 < dim) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double* p = tp + 2 + 7 * c;
+                    const double a = (v[2 * u] - p[0]) * p[2];
+                    const double b = (v[2 * u + 1] - p[1]) * p[3];
+                    const double qq = (a * a - 2.0 * p[4] * a * b + b * b) * p[5];
+                    if (c == 0) q0 += qq; else q1 += qq;
+                }
+            }
+        }
+        q0 = gsum<LPC>(q0);
+        q1 = gsum<LPC>(q1);
+        const double npairs = (double)(dim / 2);
+        const double c0 = tp[0] + npairs * tp[8] - 0.5 * q0;
+        const double c1 = tp[1] + npairs * tp[15] - 0.5 * q1;
+        const double m = fmax(c0, c1);
+        return m + log(exp(c0 - m) + exp(c1 - m));
+    }
+};
+
+// utils/banana_rv.py:26-37; params [mu1, mu2, 1/s1, 1/s2, rho, 1/(1-rho^2), ln_norm, a, b]; d = 2, LPC = 1
+template <int LPC, int DPL>
+struct Target<TARGET_BANANA, LPC, DPL> {
+    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
+        const double a = tp[7], b = tp[8];
+        const double x1 = v[0] / a;
+        const double x2 = (v[1] - b * (x1 * x1 + a * a)) * a;
+        const double u = (x1 - tp[0]) * tp[2];
+        const double w = (x2 - tp[1]) * tp[3];
+        return tp[6] - 0.5 * (u * u - 2.0 * tp[4] * u * w + w * w) * tp[5];
+    }
+};
+
+template <int LPC, int DPL>
+struct Target<TARGET_HOST, LPC, DPL> {
+    static __device__ __forceinline__ double eval(const double*, int, uint32_t, const double*) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------
+template <int DPL>
+struct Work {
+    double x[DPL];     // current state (lane's coordinates)
+    double p[DPL];     // proposal
+    double delta;      // CR statistic (dream.py:130)
+    double log_corr;   // snooker Jacobian term
+    double gamma;
+    int cr_idx, d_prime, jump, snk;
+    uint32_t maskbits;
+};
+
+template <int LPC, int DPL>
+__device__ __forceinline__ void load_row(const double* row, int q, uint32_t ld, double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        double2 t = make_double2(0.0, 0.0);
+        if (2 * pi < ld) t = reinterpret_cast<const double2*>(row)[pi];
+        v[2 * u] = t.x;
+        v[2 * u + 1] = t.y;
+    }
+}
+template <int LPC, int DPL>
+__device__ __forceinline__ void store_row(double* row, int q, uint32_t ld, const double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        if (2 * pi < ld) reinterpret_cast<double2*>(row)[pi] = make_double2(v[2 * u], v[2 * u + 1]);
+    }
+}
+
+// Build the proposal of chain c (dream.py:43-93 / demc.py:161-182).
+template <int LPC, int DPL>
+__device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
+                                              uint32_t* s_part, Work<DPL>& wk) {
+    const uint32_t dim = a.L.dim, ld = a.L.ld;
+    const bool dream = a.algo == ALGO_DREAM;
+    const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
+    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
+
+    // ---- partner chains: lanes of the subgroup resolve them in parallel, hand over through LDS
+    const bool snk_possible = !dream && a.p_snooker > 0.0 && a.M >= 3;
+    const uint32_t npart = 2 * a.P + (snk_possible ? 3u : 0u);
+    for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC) {
+        uint32_t pos;
+        if (idx < 2 * a.P) {
+            const uint32_t p = idx >> 1;
+            const u32x4 wb = chain_block(a.seed, c, a.t, SLOT_PAIR0 + (p >> 1));
+            uint32_t ia, ib;
+            distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
+            pos = (idx & 1) ? ib : ia;
+        } else {
+            const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
+            uint32_t iz, i1, i2;
+            distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
+            const uint32_t s = idx - 2 * a.P;
+            pos = s == 0 ? iz : (s == 1 ? i1 : i2);
+        }
+        s_part[cw * MAX_PARTNERS + idx] = perm_fwd(a.pool_off + pos, a.pk);
+    }
+    __syncthreads();
+    const uint32_t* part = s_part + cw * MAX_PARTNERS;
+
+    // ---- own row and per-dimension draws
+    load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
+    double eps_n[DPL], eps_u[DPL];
+    uint32_t maskbits = 0;
+    wk.cr_idx = -1; wk.d_prime = (int)dim; wk.jump = 0; wk.snk = 0; wk.delta = 0.0; wk.log_corr = 0.0;
+    double cr = 1.0;
+    if (dream) {
+        // cr ~ Categorical(CR, p_cr)  (dream.py:51)
+        const double uc = u01_32(h0.x);
+        double cum = 0.0;
+        int idx = (int)a.n_cr - 1;
+        bool found = false;
+        for (int m = 0; m < (int)a.n_cr; ++m) {          // first m with uc < cumsum(p_cr)[m]
+            cum += a.cr_state[m];
+            if (!found && uc < cum) { idx = m; found = true; }
+        }
+        wk.cr_idx = idx;
+        cr = (double)(idx + 1) / (double)a.n_cr;     // dream.py:113
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t j = 2u * (uint32_t)(q + u * LPC) + e;
+            const int s = 2 * u + e;
+            eps_n[s] = 0.0; eps_u[s] = 0.0;
+            if (j < dim) {
+                const u32x4 wj = chain_block(a.seed, c, a.t, SLOT_DIM0 + j);
+                if (a.epsilon > 0.0) eps_n[s] = a.epsilon * box_muller(wj.z, wj.w);       // util.py:5-16
+                if (dream) {
+                    if (a.u_epsilon > 0.0) eps_u[s] = -a.u_epsilon + (2.0 * a.u_epsilon) * u01_32(wj.y);  // util.py:18-28
+                    if (u01_32(wj.x) <= cr) { maskbits |= 1u << s; ++cnt; }               // dream.py:52-53
+                }
+            }
+        }
+    }
+    if (dream) {
+        cnt = gsum_i<LPC>(cnt);
+        if (cnt == 0) {                                // dream.py:55-57: force one dimension
+            const uint32_t f = mulhi32(h0.y, dim);
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) {
+                const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+                if (j == f) maskbits |= 1u << s;
+            }
+            cnt = 1;
+        }
+        wk.d_prime = cnt;
+    }
+    wk.maskbits = maskbits;
+
+    if (dream) {
+        // gamma (dream.py:61,77-80)
+        const double gamma_base = a.gamma_scale * 2.38 / sqrt(2.0 * (double)a.P * (double)cnt);
+        double gamma = gamma_base;
+        if (a.k % 5 == 0 && !(u01_32(h0.z) < 0.2)) { gamma = 1.0; wk.jump = 1; }
+        wk.gamma = gamma;
+        // sum over pairs of (A_p - B_p)  (dream.py:65-68,85-86), p = 0 first
+        double sum[DPL];
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) sum[s] = 0.0;
+        for (uint32_t p = 0; p < a.P; ++p) {
+            double ra[DPL], rb[DPL];
+            load_row<LPC, DPL>(row_ptr(a.L, part[2 * p]), q, ld, ra);
+            load_row<LPC, DPL>(row_ptr(a.L, part[2 * p + 1]), q, ld, rb);
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) sum[s] = (p == 0) ? (ra[s] - rb[s]) : (sum[s] + (ra[s] - rb[s]));
+        }
+        // proposal (dream.py:85-89)
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) {
+            const double jump = (1.0 + eps_u[s]) * gamma * sum[s] + eps_n[s];
+            wk.p[s] = ((maskbits >> s) & 1u) ? (jump + wk.x[s]) : wk.x[s];
+        }
+        // CR statistic (dream.py:92-93,119-130): BEFORE the accept test, from the proposed jump
+        if (a.adapt_on && a.cr_gate) {
+            const uint32_t li = c - a.lo;
+            double m2[DPL];
+            load_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+            double dl = 0.0;
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) {
+                const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+                if (j < dim) {
+                    double sd = sqrt(m2[s] / (double)a.hist_len);
+                    if (sd == 0.0) sd = 1e-12;
+                    const double df = wk.x[s] - wk.p[s];
+                    dl += (df * df) / (sd * sd);
+                }
+            }
+            wk.delta = gsum<LPC>(dl);
+        }
+    } else {
+        // DE-MC (demc.py:161-182)
+        double gamma = a.gamma_demc;
+        if (a.k % 10 == 0 && !(u01_32(h0.z) < 0.1)) { gamma = 1.0; wk.jump = 1; }
+        wk.gamma = gamma;
+        double ra[DPL], rb[DPL];
+        load_row<LPC, DPL>(row_ptr(a.L, part[0]), q, ld, ra);
+        load_row<LPC, DPL>(row_ptr(a.L, part[1]), q, ld, rb);
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) {
+            double pv = gamma * (ra[s] - rb[s]);
+            pv = pv + wk.x[s];
+            pv = pv + eps_n[s];
+            wk.p[s] = pv;
+        }
+        if (snk_possible && u01_32(h0.w) < a.p_snooker) {
+            // snooker update (ter Braak & Vrugt 2008) -- extension, absent from the reference
+            double rz[DPL], r1[DPL], r2[DPL];
+            load_row<LPC, DPL>(row_ptr(a.L, part[2]), q, ld, rz);
+            load_row<LPC, DPL>(row_ptr(a.L, part[3]), q, ld, r1);
+            load_row<LPC, DPL>(row_ptr(a.L, part[4]), q, ld, r2);
+            double n2 = 0.0, dot = 0.0;
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) {
+                const double df = wk.x[s] - rz[s];
+                n2 += df * df;
+                dot += (r1[s] - r2[s]) * df;
+            }
+            n2 = gsum<LPC>(n2);
+            dot = gsum<LPC>(dot);
+            if (n2 > 0.0) {
+                const double gs = (1.2 + u01_32(h1.z)) * (dot / n2);
+                double n2p = 0.0;
+#pragma unroll
+                for (int s = 0; s < DPL; ++s) {
+                    const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+                    const double df = wk.x[s] - rz[s];
+                    double pv = wk.x[s] + gs * df;
+                    pv = pv + eps_n[s];
+                    if (j >= dim) pv = wk.x[s];
+                    wk.p[s] = pv;
+                    const double dn = pv - rz[s];
+                    n2p += dn * dn;
+                }
+                n2p = gsum<LPC>(n2p);
+                wk.log_corr = 0.5 * (double)(dim - 1) * (log(n2p) - log(n2));
+                wk.snk = 1;
+            }
+        }
+    }
+    if (a.trace_i32 && active && q == 0) {
+        int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
+        tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
+        for (uint32_t i = 0; i < MAX_PARTNERS; ++i) tr[5 + i] = i < npart ? (int32_t)part[i] : -1;
+    }
+    if (a.trace_mask && active) {
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) {
+            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+            if (j < dim) a.trace_mask[(uint64_t)(c - a.lo) * dim + j] = (uint8_t)((maskbits >> s) & 1u);
+        }
+    }
+}
+
+// Metropolis test (samplers.py:328-336), append (chain.py:51-54), Welford moments, CR outputs.
+template <int LPC, int DPL>
+__device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bool active, int q,
+                                              const Work<DPL>& wk, double ll_prop) {
+    const uint32_t ld = a.L.ld, dim = a.L.dim;
+    const uint32_t li = c - a.lo;
+    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
+    const double ll_cur = a.ll[li];
+    double alpha = exp((ll_prop + wk.log_corr) - ll_cur);
+    const bool is_nan = alpha != alpha;
+    alpha = fmin(1.0, alpha);
+    alpha = fmax(0.0, alpha);                            // np.clip(np.min((1, .)), 0, 1); NaN stays NaN in NumPy
+    const bool accepted = !is_nan && (u01_53(h1.x, h1.y) < alpha);
+
+    const unsigned long long lead = __ballot(active && q == 0);
+    const unsigned long long acc = __ballot(active && q == 0 && accepted);
+    const unsigned long long nn = __ballot(active && q == 0 && is_nan);
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)__popcll(acc));
+        atomicAdd(&a.counters[1], (unsigned long long)(__popcll(lead) - __popcll(acc)));
+        if (nn) atomicAdd(&a.counters[2], (unsigned long long)__popcll(nn));
+    }
+    if (!active) return;
+    double nv[DPL];
+#pragma unroll
+    for (int s = 0; s < DPL; ++s) nv[s] = accepted ? wk.p[s] : wk.x[s];
+    const double new_ll = accepted ? ll_prop : ll_cur;
+    if (accepted) {
+        store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
+        if (q == 0) a.ll[li] = new_ll;
+    }
+    if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint64_t)li * ld, q, ld, nv);
+    if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
+    if (a.algo == ALGO_DREAM) {
+        if (a.adapt_on) {
+            // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
+            double mean[DPL], m2[DPL];
+            load_row<LPC, DPL>(a.w_mean + (uint64_t)li * ld, q, ld, mean);
+            load_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+            const double cntp = (double)(a.hist_len + 1);
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) {
+                const double d1 = nv[s] - mean[s];
+                mean[s] = mean[s] + d1 / cntp;
+                m2[s] = m2[s] + d1 * (nv[s] - mean[s]);
+            }
+            store_row<LPC, DPL>(a.w_mean + (uint64_t)li * ld, q, ld, mean);
+            store_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+        }
+        if (q == 0) {
+            const bool gated = a.adapt_on && a.cr_gate;
+            *delta_ptr(a.L, c) = gated ? wk.delta : 0.0;
+            *cridx_ptr(a.L, c) = gated ? (double)wk.cr_idx : -1.0;
+        }
+    }
+    if (a.trace_i32 && q == 0) {
+        a.trace_i32[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
+        double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
+        tf[0] = alpha; tf[1] = ll_prop; tf[2] = wk.delta; tf[3] = wk.gamma;
+    }
+    (void)dim;
+}
+
+// Which chain does this subgroup update?  mode 0: work item = position in shuffle order (all items
+// active); mode 1: work item = local chain, active iff its position falls in the phase's group.
+__device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, uint32_t& c) {
+    bool active = w < a.n_items;
+    if (a.mode == 0) {
+        c = perm_fwd(a.upd_off + (active ? w : 0u), a.pk);
+    } else {
+        c = a.lo + (active ? w : 0u);
+        const uint32_t pos = perm_inv(c, a.pk);
+        active = active && (pos - a.upd_off) < a.n_upd;
+    }
+    return active;
+}
+
+template <int TARGET, int LPC, int DPL>
+__global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
+    __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    uint32_t c;
+    const bool active = resolve_chain(a, w, c);
+    if (LPC == WAVE && !active) return;          // whole wavefront idle
+    Work<DPL> wk;
+    make_proposal<LPC, DPL>(a, c, active, q, cw, s_part, wk);
+    const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, a.tparams);
+    finish_update<LPC, DPL>(a, c, active, q, wk, ll_prop);
+}
+
+// Host-callback ln_like_fn: proposals out ...
+template <int LPC, int DPL>
+__global__ __launch_bounds__(WAVE) void phase_propose_kernel(const PhaseArgs a) {
+    __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    uint32_t c;
+    const bool active = resolve_chain(a, w, c);
+    if (w < a.n_items && q == 0) a.ids_buf[w] = active ? (int32_t)c : -1;
+    if (LPC == WAVE && !active) return;
+    Work<DPL> wk;
+    make_proposal<LPC, DPL>(a, c, active, q, cw, s_part, wk);
+    if (!active) return;
+    store_row<LPC, DPL>(a.prop_buf + (uint64_t)w * a.L.ld, q, a.L.ld, wk.p);
+    if (q == 0) {
+        a.aux_buf[2 * (uint64_t)w] = wk.log_corr;
+        // CR statistic travels through the exchange slots directly
+        if (a.algo == ALGO_DREAM) {
+            const bool gated = a.adapt_on && a.cr_gate;
+            *delta_ptr(a.L, c) = gated ? wk.delta : 0.0;
+            *cridx_ptr(a.L, c) = gated ? (double)wk.cr_idx : -1.0;
+        }
+    }
+}
+
+// ... and ln_like values back in (aux_buf[2w+1]).
+template <int LPC, int DPL>
+__global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    bool active = w < a.n_items;
+    int32_t id = active ? a.ids_buf[w] : -1;
+    active = active && id >= 0;
+    if (LPC == WAVE && !active) return;
+    const uint32_t c = active ? (uint32_t)id : a.lo;
+    Work<DPL> wk;
+    load_row<LPC, DPL>(row_ptr(a.L, c), q, a.L.ld, wk.x);
+    load_row<LPC, DPL>(a.prop_buf + (uint64_t)(active ? w : 0u) * a.L.ld, q, a.L.ld, wk.p);
+    wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
+    const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
+    wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0;
+    // finish_update rewrites the CR slots: carry the values written by the propose kernel
+    if (a.algo == ALGO_DREAM && active) {
+        wk.delta = *delta_ptr(a.L, c);
+        wk.cr_idx = (int)*cridx_ptr(a.L, c);
+    }
+    PhaseArgs b = a;
+    if (a.algo == ALGO_DREAM) b.cr_gate = (wk.cr_idx >= 0) ? 1u : 0u;
+    finish_update<LPC, DPL>(b, c, active, q, wk, ll_prop);
+}
+
+// ---------------------------------------------------------------------------------
+// Crossover-probability re-estimation (dream.py:125-140), once per generation, from the
+// (delta, cr_idx) slots of ALL N chains of the exchange buffer: identical on every rank.
+// cr_state: p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
+// ---------------------------------------------------------------------------------
+constexpr int ADAPT_THREADS = 1024;
+__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state) {
+    __shared__ double s_d[ADAPT_THREADS];
+    __shared__ double s_n[ADAPT_THREADS];
+    __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
+    const int tid = threadIdx.x;
+    double acc_d[MAX_CR], acc_n[MAX_CR];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
+    for (uint32_t c = tid; c < N; c += ADAPT_THREADS) {
+        const int idx = (int)*cridx_ptr(L, c);
+        const double dl = *delta_ptr(L, c);
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) {
+            if (idx == m) { acc_d[m] += dl; acc_n[m] += 1.0; }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) {
+        if (m < (int)n_cr) {                       // uniform
+            s_d[tid] = acc_d[m]; s_n[tid] = acc_n[m];
+            __syncthreads();
+            for (int o = ADAPT_THREADS / 2; o > 0; o >>= 1) {
+                if (tid < o) { s_d[tid] += s_d[tid + o]; s_n[tid] += s_n[tid + o]; }
+                __syncthreads();
+            }
+            if (tid == 0) { tot_d[m] = s_d[0]; tot_n[m] = s_n[0]; }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        double* p_cr = cr_state; double* delta_m = cr_state + MAX_CR; double* n_upd = cr_state + 2 * MAX_CR;
+        bool any = false;
+        for (uint32_t m = 0; m < n_cr; ++m) {
+            if (tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
+        }
+        if (any) {
+            uint32_t nz = 0;
+            for (uint32_t m = 0; m < n_cr; ++m) nz += n_upd[m] != 0.0 ? 1u : 0u;
+            if (nz == n_cr) for (uint32_t m = 0; m < n_cr; ++m) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
+            double s = 0.0;
+            for (uint32_t m = 0; m < n_cr; ++m) s += p_cr[m];
+            for (uint32_t m = 0; m < n_cr; ++m) p_cr[m] = p_cr[m] / s;                              // dream.py:140
+        }
+    }
+}
+
+// Welford moments of every local chain's history rows [0, rows) recomputed from the history
+// buffer (only needed when adaptation resumes after generations run without it).
+__global__ void welford_rebuild_kernel(const double* hist, uint64_t row_stride, uint64_t n_elem, uint32_t rows,
+                                       double* w_mean, double* w_m2) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elem) return;
+    double mean = 0.0, m2 = 0.0;
+    for (uint32_t g = 0; g < rows; ++g) {
+        const double v = hist[(uint64_t)g * row_stride + e];
+        const double d1 = v - mean;
+        mean = mean + d1 / (double)(g + 1);
+        m2 = m2 + d1 * (v - mean);
+    }
+    w_mean[e] = mean;
+    w_m2[e] = m2;
+}
+
+// chain.py:25-27: state0 = theta_0 + N(0, diag(varepsilon)) for the local block of the exchange buffer
+__global__ void init_jitter_kernel(Layout L, uint32_t lo, uint64_t seed, const double* theta0, const double* var,
+                                   int jitter) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)L.n_local * L.ld) return;
+    const uint32_t i = (uint32_t)(e / L.ld), j = (uint32_t)(e % L.ld);
+    double v = 0.0;
+    if (j < L.dim) {
+        v = theta0[j];
+        if (jitter) {
+            const u32x4 w = chain_block(seed, lo + i, T_INIT, SLOT_DIM0 + j);
+            v = v + sqrt(var[j]) * box_muller(w.z, w.w);
+        }
+    }
+    row_ptr(L, lo + i)[j] = v;
+}
+
+// ln_like of n points (row stride ld) with the device target
+template <int TARGET, int LPC, int DPL>
+__global__ __launch_bounds__(WAVE) void eval_ll_kernel(const double* X, uint32_t n, uint32_t ld, uint32_t dim,
+                                                      const double* tparams, double* out) {
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    const bool active = w < n;
+    double v[DPL];
+    load_row<LPC, DPL>(X + (uint64_t)(active ? w : 0u) * ld, q, ld, v);
+    const double ll = Target<TARGET, LPC, DPL>::eval(v, q, dim, tparams);
+    if (active && q == 0) out[w] = ll;
+}
+
+// per-dimension sum / centred second moment over history rows (param_est, demc.py:235-248)
+__global__ void moments_sum_kernel(const double* hist, uint64_t row_stride, uint32_t n_local, uint32_t ld,
+                                   uint32_t dim, uint64_t g_lo, uint64_t g_hi, uint32_t first_chain_of_g_lo,
+                                   const double* shift, double* out_sum, double* out_sq) {
+    // one block per dimension; rows = (g, i) with g in [g_lo, g_hi), i >= first_chain_of_g_lo when g == g_lo
+    const uint32_t j = blockIdx.x;
+    if (j >= dim) return;
+    __shared__ double s_a[256], s_b[256];
+    const double sh = shift ? shift[j] : 0.0;
+    double sa = 0.0, sb = 0.0;
+    const uint64_t total = (g_hi - g_lo) * (uint64_t)n_local;
+    for (uint64_t r = threadIdx.x; r < total; r += blockDim.x) {
+        const uint64_t g = g_lo + r / n_local;
+        const uint32_t i = (uint32_t)(r % n_local);
+        if (g == g_lo && i < first_chain_of_g_lo) continue;
+        const double v = hist[g * row_stride + (uint64_t)i * ld + j] - sh;
+        sa += v;
+        sb += v * v;
+    }
+    s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_sum[j] = s_a[0]; out_sq[j] = s_b[0]; }
+}
+
+}  // namespace bpm

@@ -1,0 +1,824 @@
+// Host side of libbipymc_hip.so: the sampler object behind the C ABI of
+// include/bipymc_hip.h.  It owns the device state (replicated chain-state matrix,
+// log-like cache, history, Welford moments, CR statistics), runs the generation
+// loop of bipymc/demc.py:63-151 as back-to-back kernel launches on one HIP stream
+// and, for world_size > 1, replaces the two MPI_Allgathers per generation
+// (demc.py:93-94,116-117) with in-place RCCL all-gathers on the same stream.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bipymc_hip.h"
+#include "kernels.h"
+#include "rocrand_check.h"
+
+using namespace bpm;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+#define HIPCK(expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                        std::to_string(__LINE__) + ")");                                               \
+    } while (0)
+#define CK(expr)                 \
+    do {                         \
+        int _r = (expr);         \
+        if (_r != 0) return _r;  \
+    } while (0)
+
+// ---- RCCL, loaded on demand (single-GPU use needs no communicator library) -------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static Rccl g_rccl;
+static int load_rccl() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(std::string("cannot load RCCL: ") + dlerror());
+#define SYM(f)                                                          \
+    g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(lib, "nccl" #f)); \
+    if (!g_rccl.f) return fail("RCCL symbol nccl" #f " missing");
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(AllGather) SYM(AllReduce) SYM(CommDestroy) SYM(GetErrorString)
+#undef SYM
+    g_rccl.lib = lib;
+    return 0;
+}
+#define NCCLCK(expr)                                                                              \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess) return fail(std::string(#expr) + " failed: " + g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+// ---- kernel dispatch ---------------------------------------------------------------
+typedef void (*PhaseLaunch)(const PhaseArgs&, hipStream_t);
+typedef void (*EvalLaunch)(const double*, uint32_t, uint32_t, uint32_t, const double*, double*, hipStream_t);
+
+static inline uint32_t grid_for(uint32_t n_items, int lpc) {
+    const uint32_t cpw = WAVE / lpc;
+    return (n_items + cpw - 1) / cpw;
+}
+template <int T, int LPC, int DPL>
+static void launch_fused(const PhaseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((phase_fused_kernel<T, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+}
+template <int LPC, int DPL>
+static void launch_propose(const PhaseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((phase_propose_kernel<LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+}
+template <int LPC, int DPL>
+static void launch_commit(const PhaseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((phase_commit_kernel<LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+}
+template <int T, int LPC, int DPL>
+static void launch_eval(const double* X, uint32_t n, uint32_t ld, uint32_t dim, const double* tp, double* out,
+                        hipStream_t s) {
+    hipLaunchKernelGGL((eval_ll_kernel<T, LPC, DPL>), dim3(grid_for(n, LPC)), dim3(WAVE), 0, s, X, n, ld, dim, tp, out);
+}
+
+struct Shape {
+    int lpc, dpl, idx;
+};
+// lanes per chain / coordinates per lane for a row of ld doubles (ld even)
+static bool pick_shape(uint32_t ld, Shape& sh) {
+    const uint32_t np = ld / 2;
+    if (np <= 1) sh = {1, 2, 0};
+    else if (np <= 4) sh = {4, 2, 1};
+    else if (np <= 16) sh = {16, 2, 2};
+    else if (np <= 64) sh = {64, 2, 3};
+    else if (np <= 128) sh = {64, 4, 4};
+    else if (np <= 256) sh = {64, 8, 5};
+    else return false;
+    return true;
+}
+#define SHAPE_TABLE(FN, ...)                                                                     \
+    {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
+     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>}
+#define COMMA ,
+static PhaseLaunch g_fused_gauss[6] = SHAPE_TABLE(launch_fused, TARGET_GAUSS COMMA);
+static PhaseLaunch g_fused_mixture[6] = SHAPE_TABLE(launch_fused, TARGET_MIXTURE COMMA);
+static PhaseLaunch g_propose[6] = SHAPE_TABLE(launch_propose, );
+static PhaseLaunch g_commit[6] = SHAPE_TABLE(launch_commit, );
+static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
+static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
+
+// ---- the sampler ------------------------------------------------------------------------
+struct bpm_sampler {
+    bpm_config_t cfg{};
+    std::vector<double> tparams_h;
+    uint32_t N = 0, dim = 0, ld = 0, n_local = 0, lo = 0, world = 1, rank = 0;
+    Shape shape{};
+    Layout L{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* G = nullptr;
+    double* ll = nullptr;
+    double* hist = nullptr;
+    double* llhist = nullptr;
+    int64_t hist_cap = 0;      // rows allocated
+    int64_t hist_rows = 0;     // rows stored (0 when keep_history == 0 and nothing stored)
+    int64_t rows_logical = 0;  // len(chain.chain) of the reference: 1 + generations since (re)initialisation
+    double* w_mean = nullptr;
+    double* w_m2 = nullptr;
+    int64_t w_rows = 0;        // history rows folded into the Welford moments
+    double* tparams = nullptr;
+    double* cr_state = nullptr;            // p_cr | delta_m | n_cr_updates (MAX_CR each)
+    unsigned long long* counters = nullptr;  // device: accepted, rejected, nan
+    double* prop_buf = nullptr;
+    double* aux_buf = nullptr;
+    int32_t* ids_buf = nullptr;
+    int32_t* trace_i32 = nullptr;
+    double* trace_f64 = nullptr;
+    uint8_t* trace_mask = nullptr;
+    double* scratch = nullptr;   // small device scratch (theta0, var, moments)
+    size_t scratch_doubles = 0;
+    ncclComm_t comm = nullptr;
+    // run state
+    bpm_run_opts_t opts{};
+    bool run_open = false;
+    int64_t k_gen = 0, t_abs = 0;
+    int phase = 0;               // host-callback: next half generation to propose (0/1)
+    bool proposed = false;
+    bool state_set = false;
+    int64_t n_outlier_resets = 0;
+    // per-generation cache (host-callback path keeps it between propose and commit)
+    PhaseArgs cur_args[2];
+    bool gen_adapt_on = false;
+};
+
+static int check_handle(bpm_handle_t h) {
+    if (!h) return fail("null handle");
+    return 0;
+}
+
+static int set_device(bpm_sampler* s) {
+    HIPCK(hipSetDevice(s->cfg.device));
+    return 0;
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t n) {
+    HIPCK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+static int ensure_history(bpm_sampler* s, int64_t rows) {
+    if (!s->cfg.keep_history) rows = std::min<int64_t>(rows, 1);
+    if (rows <= s->hist_cap) return 0;
+    int64_t cap = std::max<int64_t>(rows, s->hist_cap + s->hist_cap / 2);
+    const size_t row_d = (size_t)s->n_local * s->ld;
+    double* nh = nullptr;
+    double* nl = nullptr;
+    CK(dev_alloc(&nh, (size_t)cap * row_d));
+    CK(dev_alloc(&nl, (size_t)cap * s->n_local));
+    if (s->hist_rows > 0) {
+        HIPCK(hipMemcpyAsync(nh, s->hist, (size_t)s->hist_rows * row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        HIPCK(hipMemcpyAsync(nl, s->llhist, (size_t)s->hist_rows * s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    }
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (s->hist) HIPCK(hipFree(s->hist));
+    if (s->llhist) HIPCK(hipFree(s->llhist));
+    s->hist = nh;
+    s->llhist = nl;
+    s->hist_cap = cap;
+    return 0;
+}
+
+static int eval_local_ll(bpm_sampler* s) {
+    // ln_like of the local chains' current state into the cache (device targets only)
+    const double* Xl = s->G + (uint64_t)s->rank * s->L.blk;
+    switch (s->cfg.target_id) {
+        case BPM_TARGET_GAUSS_EQUICORR: g_eval_gauss[s->shape.idx](Xl, s->n_local, s->ld, s->dim, s->tparams, s->ll, s->stream); break;
+        case BPM_TARGET_MIXTURE_PAIRS: g_eval_mixture[s->shape.idx](Xl, s->n_local, s->ld, s->dim, s->tparams, s->ll, s->stream); break;
+        case BPM_TARGET_BANANA_2D: launch_eval<TARGET_BANANA, 1, 2>(Xl, s->n_local, s->ld, s->dim, s->tparams, s->ll, s->stream); break;
+        default: return 0;  // host callback: caller supplies values via bpm_set_loglike
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// after the state matrix was (re)initialised: history := [state], moments reset
+static int reset_history(bpm_sampler* s) {
+    CK(eval_local_ll(s));
+    s->hist_rows = 0;
+    s->rows_logical = 1;
+    s->w_rows = 0;
+    CK(ensure_history(s, 1));
+    const size_t row_d = (size_t)s->n_local * s->ld;
+    HIPCK(hipMemcpyAsync(s->hist, s->G + (uint64_t)s->rank * s->L.blk, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipMemcpyAsync(s->llhist, s->ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    s->hist_rows = 1;
+    // Welford over the single row: mean = row, m2 = 0
+    HIPCK(hipMemcpyAsync(s->w_mean, s->hist, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipMemsetAsync(s->w_m2, 0, row_d * sizeof(double), s->stream));
+    s->w_rows = 1;
+    s->state_set = true;
+    s->phase = 0;
+    s->proposed = false;
+    return 0;
+}
+
+extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
+extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
+
+extern "C" int bpm_get_unique_id(char out[BPM_UID_BYTES]) {
+    CK(load_rccl());
+    ncclUniqueId id;
+    NCCLCK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == BPM_UID_BYTES, "uid size");
+    std::memcpy(out, &id, BPM_UID_BYTES);
+    return 0;
+}
+
+extern "C" int bpm_destroy(bpm_handle_t s) {
+    if (!s) return 0;
+    hipSetDevice(s->cfg.device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
+    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters,
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
+    if (!cfg || !out) return fail("bpm_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != BPM_ABI_VERSION) return fail("bpm_create: ABI version mismatch");
+    if (cfg->algo != BPM_ALGO_DEMC && cfg->algo != BPM_ALGO_DREAM) return fail("bpm_create: unknown algo");
+    if (cfg->n_chains < 4) return fail("bpm_create: n_chains >= 4 required (samplers.py:249)");
+    if (cfg->dim < 1) return fail("bpm_create: dim >= 1 required");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail("bpm_create: bad rank/world_size");
+    if (cfg->n_chains % cfg->world_size != 0)
+        return fail("bpm_create: n_chains must be divisible by world_size (unequal blocks break Allgather, demc.py:39,93)");
+    if (cfg->algo == BPM_ALGO_DREAM) {
+        if (cfg->del_pairs < 1 || cfg->del_pairs > MAX_PAIRS) return fail("bpm_create: 1 <= del_pairs <= 10");
+        if (cfg->n_cr < 1 || cfg->n_cr > BPM_MAX_CR) return fail("bpm_create: 1 <= n_cr <= 8");
+    }
+    int ndev = 0;
+    HIPCK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("bpm_create: no HIP device (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("bpm_create: device ordinal out of range");
+
+    bpm_sampler* s = new bpm_sampler();
+    s->cfg = *cfg;
+    s->cfg.target_params = nullptr;
+    s->cfg.nccl_uid = nullptr;
+    s->N = (uint32_t)cfg->n_chains;
+    s->dim = (uint32_t)cfg->dim;
+    s->ld = (s->dim + 1u) & ~1u;
+    s->world = (uint32_t)cfg->world_size;
+    s->rank = (uint32_t)cfg->rank;
+    s->n_local = s->N / s->world;
+    s->lo = s->rank * s->n_local;
+    if (!pick_shape(s->ld, s->shape)) { delete s; return fail("bpm_create: dim > 512 not supported"); }
+    const int tid = cfg->target_id;
+    const int np = cfg->n_target_params;
+    bool ok = true;
+    if (tid == BPM_TARGET_GAUSS_EQUICORR) ok = (np == 4 + (int)s->dim);
+    else if (tid == BPM_TARGET_MIXTURE_PAIRS) ok = (np == 16 && s->dim % 2 == 0);
+    else if (tid == BPM_TARGET_BANANA_2D) ok = (np == 9 && s->dim == 2);
+    else if (tid != BPM_TARGET_HOST_CALLBACK) ok = false;
+    if (!ok || (np > 0 && !cfg->target_params)) { delete s; return fail("bpm_create: target id / parameter block / dim mismatch"); }
+    if (np > 0) s->tparams_h.assign(cfg->target_params, cfg->target_params + np);
+    if (cfg->algo == BPM_ALGO_DEMC) { s->cfg.del_pairs = 1; s->cfg.n_cr = 1; }
+
+#define CKD(expr)                                   \
+    do {                                            \
+        int _r = (expr);                            \
+        if (_r != 0) { bpm_destroy(s); return _r; } \
+    } while (0)
+#define HIPCKD(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            bpm_destroy(s);                                                                      \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(_e));               \
+        }                                                                                        \
+    } while (0)
+    HIPCKD(hipSetDevice(cfg->device));
+    HIPCKD(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCKD(hipEventCreate(&s->ev0));
+    HIPCKD(hipEventCreate(&s->ev1));
+    s->L.blk = (uint64_t)s->n_local * (s->ld + 2);
+    s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
+    const size_t row_d = (size_t)s->n_local * s->ld;
+    CKD(dev_alloc(&s->G, (size_t)s->world * s->L.blk));
+    HIPCKD(hipMemsetAsync(s->G, 0, (size_t)s->world * s->L.blk * sizeof(double), s->stream));
+    s->L.G = s->G;
+    CKD(dev_alloc(&s->ll, s->n_local));
+    CKD(dev_alloc(&s->w_mean, row_d));
+    CKD(dev_alloc(&s->w_m2, row_d));
+    CKD(dev_alloc(&s->tparams, (size_t)np));
+    if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    CKD(dev_alloc(&s->cr_state, 3 * MAX_CR));
+    {
+        double init[3 * MAX_CR] = {0};
+        for (int m = 0; m < s->cfg.n_cr; ++m) init[m] = 1.0 / s->cfg.n_cr;   // dream.py:114
+        HIPCKD(hipMemcpyAsync(s->cr_state, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+        HIPCKD(hipStreamSynchronize(s->stream));
+    }
+    CKD(dev_alloc(&s->counters, 4));
+    HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
+    s->scratch_doubles = 4 * (size_t)s->ld + 64;
+    CKD(dev_alloc(&s->scratch, s->scratch_doubles));
+    if (tid == BPM_TARGET_HOST_CALLBACK) {
+        CKD(dev_alloc(&s->prop_buf, row_d));
+        CKD(dev_alloc(&s->aux_buf, 2 * (size_t)s->n_local));
+        CKD(dev_alloc(&s->ids_buf, s->n_local));
+    }
+    if (s->world > 1) {
+        if (!cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
+        CKD(load_rccl());
+        ncclUniqueId id;
+        std::memcpy(&id, cfg->nccl_uid, BPM_UID_BYTES);
+        ncclResult_t r = g_rccl.CommInitRank(&s->comm, (int)s->world, id, (int)s->rank);
+        if (r != ncclSuccess) { std::string m = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r); bpm_destroy(s); return fail(m); }
+    }
+    HIPCKD(hipStreamSynchronize(s->stream));
+    *out = s;
+    return 0;
+}
+
+extern "C" int bpm_init_chains(bpm_handle_t s, const double* theta_0, const double* varepsilon) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!theta_0 || !varepsilon) return fail("bpm_init_chains: null argument");
+    int jitter = 1;
+    for (uint32_t j = 0; j < s->dim; ++j) {
+        if (varepsilon[j] < 0.0) return fail("bpm_init_chains: varepsilon must be >= 0 (chain.py:22)");
+        if (!(varepsilon[j] > 0.0)) jitter = 0;   // util.py:12: all > 0 or no noise at all
+    }
+    double* d_theta = s->scratch;
+    double* d_var = s->scratch + s->ld;
+    HIPCK(hipMemcpyAsync(d_theta, theta_0, s->dim * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipMemcpyAsync(d_var, varepsilon, s->dim * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    const uint64_t n_elem = (uint64_t)s->n_local * s->ld;
+    for (uint32_t r = 0; r < s->world; ++r) {   // every rank fills the whole replicated matrix: no exchange needed
+        hipLaunchKernelGGL(init_jitter_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s->stream, s->L,
+                           r * s->n_local, (uint64_t)s->cfg.seed, d_theta, d_var, jitter);
+    }
+    HIPCK(hipGetLastError());
+    CK(reset_history(s));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_set_state(bpm_handle_t s, const double* X) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!X) return fail("bpm_set_state: null argument");
+    for (uint32_t r = 0; r < s->world; ++r) {
+        HIPCK(hipMemcpy2DAsync(s->G + (uint64_t)r * s->L.blk, s->ld * sizeof(double),
+                               X + (uint64_t)r * s->n_local * s->dim, s->dim * sizeof(double), s->dim * sizeof(double),
+                               s->n_local, hipMemcpyHostToDevice, s->stream));
+    }
+    CK(reset_history(s));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_get_state(bpm_handle_t s, double* X) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!X) return fail("bpm_get_state: null argument");
+    for (uint32_t r = 0; r < s->world; ++r) {
+        HIPCK(hipMemcpy2DAsync(X + (uint64_t)r * s->n_local * s->dim, s->dim * sizeof(double),
+                               s->G + (uint64_t)r * s->L.blk, s->ld * sizeof(double), s->dim * sizeof(double),
+                               s->n_local, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_set_loglike(bpm_handle_t s, const double* ll_local) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!ll_local) return fail("bpm_set_loglike: null argument");
+    HIPCK(hipMemcpyAsync(s->ll, ll_local, s->n_local * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (s->hist_rows >= 1 && s->rows_logical == 1)   // initial row of the log-like history
+        HIPCK(hipMemcpyAsync(s->llhist, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_get_loglike(bpm_handle_t s, double* ll_local) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    HIPCK(hipMemcpyAsync(ll_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->state_set) return fail("ERROR: chains not initilized");   // demc.py:65-66
+    if (s->proposed) return fail("bpm_begin_run: a proposed half generation is awaiting bpm_commit");
+    bpm_run_opts_t d;
+    d.flip = 0.5; d.shuffle = 1; d._pad = 0; d.epsilon = -1.0; d.u_epsilon = -1.0; d.gamma = -1.0;
+    if (o) d = *o;
+    d.flip = std::min(1.0, std::max(0.0, d.flip));                                   // demc.py:73
+    if (d.epsilon < 0.0) d.epsilon = (s->cfg.algo == BPM_ALGO_DREAM) ? 1e-12 : 1e-15;   // dream.py:40 / demc.py:161
+    if (d.u_epsilon < 0.0) d.u_epsilon = 1e-2;                                        // dream.py:41
+    if (!(d.gamma > 0.0)) d.gamma = 2.38 / std::sqrt(2.0 * (double)s->dim);            // demc.py:162
+    s->opts = d;
+    s->k_gen = 0;                                                                    // demc.py:78
+    s->phase = 0;
+    unsigned long long init[4] = {0ull, 1ull, 0ull, 0ull};                            // demc.py:67-68
+    HIPCK(hipMemcpyAsync(s->counters, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    s->run_open = true;
+    return 0;
+}
+
+static int allgather_state(bpm_sampler* s) {
+    if (s->world == 1) return 0;
+    NCCLCK(g_rccl.AllGather(s->G + (uint64_t)s->rank * s->L.blk, s->G, (size_t)s->L.blk, ncclDouble, s->comm, s->stream));
+    return 0;
+}
+
+// Everything of one generation that is decided on the host: flip, shuffle key, group ranges
+// (demc.py:81-86,95-100), gating flags (dream.py:92,123), history row.
+static int prepare_generation(bpm_sampler* s) {
+    const bool dream = s->cfg.algo == BPM_ALGO_DREAM;
+    const uint64_t t = (uint64_t)s->t_abs;
+    const bool flip = flip_draw(s->cfg.seed, t, s->opts.flip);
+    const PermKey pk = make_perm_key(s->cfg.seed, t, s->N, s->opts.shuffle != 0);
+    const uint32_t n_first = (s->N + 1) / 2, n_second = s->N - n_first;    // np.array_split: first gets ceil
+    uint32_t a_off = 0, a_n = n_first, b_off = n_first, b_n = n_second;
+    if (flip) { std::swap(a_off, b_off); std::swap(a_n, b_n); }
+    const bool adapt_on = dream && (s->cfg.burnin_gen > s->k_gen);          // dream.py:92
+    s->gen_adapt_on = adapt_on;
+    if (adapt_on && s->w_rows != s->rows_logical) {
+        if (!s->cfg.keep_history || s->hist_rows != s->rows_logical)
+            return fail("CR adaptation needs the chain history (keep_history=1) to rebuild its moments");
+        const uint64_t n_elem = (uint64_t)s->n_local * s->ld;
+        hipLaunchKernelGGL(welford_rebuild_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s->stream,
+                           s->hist, n_elem, n_elem, (uint32_t)s->hist_rows, s->w_mean, s->w_m2);
+        HIPCK(hipGetLastError());
+        s->w_rows = s->rows_logical;
+    }
+    double* hist_row = nullptr;
+    double* llhist_row = nullptr;
+    if (s->cfg.keep_history) {
+        CK(ensure_history(s, s->hist_rows + 1));
+        hist_row = s->hist + (uint64_t)s->hist_rows * s->n_local * s->ld;
+        llhist_row = s->llhist + (uint64_t)s->hist_rows * s->n_local;
+    }
+    for (int ph = 0; ph < 2; ++ph) {
+        PhaseArgs& a = s->cur_args[ph];
+        std::memset(&a, 0, sizeof(a));
+        a.L = s->L;
+        a.ll = s->ll;
+        a.hist_row = hist_row;
+        a.llhist_row = llhist_row;
+        a.w_mean = s->w_mean;
+        a.w_m2 = s->w_m2;
+        a.tparams = s->tparams;
+        a.cr_state = s->cr_state;
+        a.counters = s->counters;
+        a.prop_buf = s->prop_buf;
+        a.aux_buf = s->aux_buf;
+        a.ids_buf = s->ids_buf;
+        a.trace_i32 = s->trace_i32;
+        a.trace_f64 = s->trace_f64;
+        a.trace_mask = s->trace_mask;
+        a.pk = pk;
+        a.seed = s->cfg.seed;
+        a.t = t;
+        a.k = (uint32_t)s->k_gen;
+        a.N = s->N;
+        a.lo = s->lo;
+        a.upd_off = ph == 0 ? a_off : b_off;
+        a.n_upd = ph == 0 ? a_n : b_n;
+        a.pool_off = ph == 0 ? b_off : a_off;
+        a.M = ph == 0 ? b_n : a_n;
+        a.mode = s->world == 1 ? 0u : 1u;
+        a.n_items = s->world == 1 ? a.n_upd : s->n_local;
+        a.algo = (uint32_t)s->cfg.algo;
+        a.P = (uint32_t)s->cfg.del_pairs;
+        a.n_cr = (uint32_t)s->cfg.n_cr;
+        a.adapt_on = adapt_on ? 1u : 0u;
+        a.cr_gate = (s->rows_logical > s->cfg.n_cr_gen) ? 1u : 0u;          // dream.py:123
+        a.hist_len = (uint32_t)s->rows_logical;
+        a.gamma_scale = s->cfg.gamma_scale;
+        a.gamma_demc = s->opts.gamma;
+        a.epsilon = s->opts.epsilon;
+        a.u_epsilon = s->opts.u_epsilon;
+        a.p_snooker = s->cfg.p_snooker;
+    }
+    return 0;
+}
+
+static int finish_generation(bpm_sampler* s) {
+    if (s->gen_adapt_on) {
+        hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
+                           s->cr_state);
+        HIPCK(hipGetLastError());
+        s->w_rows += 1;
+    }
+    if (s->cfg.keep_history) s->hist_rows += 1;
+    s->rows_logical += 1;
+    s->k_gen += 1;      // demc.py:134
+    s->t_abs += 1;
+    return 0;
+}
+
+static int run_generation_fused(bpm_sampler* s) {
+    CK(prepare_generation(s));
+    PhaseLaunch fn = nullptr;
+    switch (s->cfg.target_id) {
+        case BPM_TARGET_GAUSS_EQUICORR: fn = g_fused_gauss[s->shape.idx]; break;
+        case BPM_TARGET_MIXTURE_PAIRS: fn = g_fused_mixture[s->shape.idx]; break;
+        case BPM_TARGET_BANANA_2D: fn = launch_fused<TARGET_BANANA, 1, 2>; break;
+        default: return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
+    }
+    for (int ph = 0; ph < 2; ++ph) {
+        if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
+        CK(allgather_state(s));
+    }
+    HIPCK(hipGetLastError());
+    return finish_generation(s);
+}
+
+extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
+    if (n_gens < 0) return fail("bpm_step: n_gens < 0");
+    if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    for (int64_t g = 0; g < n_gens; ++g) CK(run_generation_fused(s));
+    return 0;
+}
+
+extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    HIPCK(hipEventRecord(s->ev0, s->stream));
+    CK(bpm_step(s, n_gens));
+    HIPCK(hipEventRecord(s->ev1, s->stream));
+    HIPCK(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return 0;
+}
+
+extern "C" int bpm_synchronize(bpm_handle_t s) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, int32_t* n_out) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->run_open) return fail("bpm_propose: call bpm_begin_run first");
+    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail("bpm_propose: sampler has a device target; use bpm_step");
+    if (s->proposed) return fail("bpm_propose: previous proposals not committed");
+    if (!out_prop || !out_ids || !n_out) return fail("bpm_propose: null argument");
+    if (s->phase == 0) CK(prepare_generation(s));
+    const PhaseArgs& a = s->cur_args[s->phase];
+    HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
+    if (a.n_items > 0) g_propose[s->shape.idx](a, s->stream);
+    HIPCK(hipGetLastError());
+    std::vector<int32_t> ids(s->n_local);
+    std::vector<double> props((size_t)s->n_local * s->ld);
+    HIPCK(hipMemcpyAsync(ids.data(), s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(props.data(), s->prop_buf, props.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    // compact the active work items (work-item order is kept; commit uses the same order)
+    int32_t n = 0;
+    for (uint32_t w = 0; w < a.n_items; ++w) {
+        if (ids[w] < 0) continue;
+        std::memcpy(out_prop + (size_t)n * s->dim, props.data() + (size_t)w * s->ld, s->dim * sizeof(double));
+        out_ids[n++] = ids[w];
+    }
+    *n_out = n;
+    s->proposed = true;
+    return 0;
+}
+
+extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed) return fail("bpm_commit: nothing proposed");
+    const PhaseArgs& a = s->cur_args[s->phase];
+    // scatter the values back to work-item order
+    std::vector<int32_t> ids(s->n_local);
+    HIPCK(hipMemcpyAsync(ids.data(), s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    std::vector<double> aux(2 * (size_t)s->n_local);
+    HIPCK(hipMemcpyAsync(aux.data(), s->aux_buf, aux.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    size_t n = 0;
+    for (uint32_t w = 0; w < a.n_items; ++w) {
+        if (ids[w] < 0) continue;
+        if (!ll_prop) return fail("bpm_commit: null ll_prop");
+        aux[2 * (size_t)w + 1] = ll_prop[n++];
+    }
+    HIPCK(hipMemcpyAsync(s->aux_buf, aux.data(), aux.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (a.n_items > 0) g_commit[s->shape.idx](a, s->stream);
+    HIPCK(hipGetLastError());
+    CK(allgather_state(s));
+    HIPCK(hipStreamSynchronize(s->stream));
+    s->proposed = false;
+    if (s->phase == 0) {
+        s->phase = 1;
+    } else {
+        s->phase = 0;
+        CK(finish_generation(s));
+    }
+    return 0;
+}
+
+extern "C" int bpm_reserve_history(bpm_handle_t s, int64_t total_rows) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    return ensure_history(s, total_rows);
+}
+
+extern "C" int bpm_get_history(bpm_handle_t s, int64_t g_lo, int64_t g_hi, double* out) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (g_lo < 0 || g_hi < g_lo || g_hi > s->hist_rows) return fail("bpm_get_history: generation range out of bounds");
+    if (g_hi == g_lo) return 0;
+    if (!out) return fail("bpm_get_history: null argument");
+    const size_t rows = (size_t)(g_hi - g_lo) * s->n_local;
+    HIPCK(hipMemcpy2DAsync(out, s->dim * sizeof(double), s->hist + (uint64_t)g_lo * s->n_local * s->ld,
+                           s->ld * sizeof(double), s->dim * sizeof(double), rows, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_get_loglike_history(bpm_handle_t s, int64_t g_lo, int64_t g_hi, double* out) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (g_lo < 0 || g_hi < g_lo || g_hi > s->hist_rows) return fail("bpm_get_loglike_history: range out of bounds");
+    if (g_hi == g_lo) return 0;
+    HIPCK(hipMemcpyAsync(out, s->llhist + (uint64_t)g_lo * s->n_local, (size_t)(g_hi - g_lo) * s->n_local * sizeof(double),
+                         hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int bpm_get_stats(bpm_handle_t s, bpm_stats_t* out) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!out) return fail("bpm_get_stats: null argument");
+    unsigned long long c[4];
+    double cr[3 * MAX_CR];
+    HIPCK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(cr, s->cr_state, sizeof(cr), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->local_n_accepted = (int64_t)c[0];
+    out->local_n_rejected = (int64_t)c[1];
+    out->n_nan_alpha = (int64_t)c[2];
+    out->k_gen = s->k_gen;
+    out->t_abs = s->t_abs;
+    out->history_rows = s->hist_rows;
+    out->n_outlier_resets = s->n_outlier_resets;
+    out->n_cr = s->cfg.n_cr;
+    for (int m = 0; m < MAX_CR; ++m) {
+        out->p_cr[m] = cr[m];
+        out->delta_m[m] = cr[MAX_CR + m];
+        out->n_cr_updates[m] = cr[2 * MAX_CR + m];
+    }
+    return 0;
+}
+
+extern "C" int bpm_set_adapt_state(bpm_handle_t s, const double* p_cr, const double* delta_m, const double* n_cr_updates,
+                                   int64_t t_abs) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    double cr[3 * MAX_CR] = {0};
+    for (int m = 0; m < s->cfg.n_cr; ++m) {
+        cr[m] = p_cr ? p_cr[m] : 1.0 / s->cfg.n_cr;
+        cr[MAX_CR + m] = delta_m ? delta_m[m] : 0.0;
+        cr[2 * MAX_CR + m] = n_cr_updates ? n_cr_updates[m] : 0.0;
+    }
+    HIPCK(hipMemcpyAsync(s->cr_state, cr, sizeof(cr), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (t_abs >= 0) s->t_abs = t_abs;
+    return 0;
+}
+
+extern "C" int bpm_eval_loglike(bpm_handle_t s, const double* X, int32_t n, double* out) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (n <= 0) return 0;
+    if (!X || !out) return fail("bpm_eval_loglike: null argument");
+    double* dX = nullptr;
+    double* dO = nullptr;
+    CK(dev_alloc(&dX, (size_t)n * s->ld));
+    CK(dev_alloc(&dO, (size_t)n));
+    HIPCK(hipMemsetAsync(dX, 0, (size_t)n * s->ld * sizeof(double), s->stream));
+    HIPCK(hipMemcpy2DAsync(dX, s->ld * sizeof(double), X, s->dim * sizeof(double), s->dim * sizeof(double), n,
+                           hipMemcpyHostToDevice, s->stream));
+    switch (s->cfg.target_id) {
+        case BPM_TARGET_GAUSS_EQUICORR: g_eval_gauss[s->shape.idx](dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
+        case BPM_TARGET_MIXTURE_PAIRS: g_eval_mixture[s->shape.idx](dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
+        case BPM_TARGET_BANANA_2D: launch_eval<TARGET_BANANA, 1, 2>(dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
+        default: hipFree(dX); hipFree(dO); return fail("bpm_eval_loglike: host-callback target has no device ln_like");
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(out, dO, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    HIPCK(hipFree(dX));
+    HIPCK(hipFree(dO));
+    return 0;
+}
+
+// ---- debug / parity hooks -----------------------------------------------------------------
+extern "C" int bpm_set_trace(bpm_handle_t s, int32_t on) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (on && !s->trace_i32) {
+        CK(dev_alloc(&s->trace_i32, (size_t)s->n_local * TRACE_I32));
+        CK(dev_alloc(&s->trace_f64, (size_t)s->n_local * TRACE_F64));
+        CK(dev_alloc(&s->trace_mask, (size_t)s->n_local * s->dim));
+        HIPCK(hipMemset(s->trace_i32, 0xFF, (size_t)s->n_local * TRACE_I32 * sizeof(int32_t)));
+        HIPCK(hipMemset(s->trace_f64, 0, (size_t)s->n_local * TRACE_F64 * sizeof(double)));
+        HIPCK(hipMemset(s->trace_mask, 0, (size_t)s->n_local * s->dim));
+    } else if (!on && s->trace_i32) {
+        HIPCK(hipFree(s->trace_i32)); HIPCK(hipFree(s->trace_f64)); HIPCK(hipFree(s->trace_mask));
+        s->trace_i32 = nullptr; s->trace_f64 = nullptr; s->trace_mask = nullptr;
+    }
+    return 0;
+}
+
+// trace of the LAST generation: out_i32 [n_local*32] = (cr_idx, d_prime, jump, accepted, snooker, partners[23]..),
+// out_f64 [n_local*4] = (alpha, ll_prop, delta, gamma), out_mask [n_local*dim]
+extern "C" int bpm_get_trace(bpm_handle_t s, int32_t* out_i32, double* out_f64, uint8_t* out_mask) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->trace_i32) return fail("bpm_get_trace: tracing is off");
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (out_i32) HIPCK(hipMemcpy(out_i32, s->trace_i32, (size_t)s->n_local * TRACE_I32 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_f64) HIPCK(hipMemcpy(out_f64, s->trace_f64, (size_t)s->n_local * TRACE_F64 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_mask) HIPCK(hipMemcpy(out_mask, s->trace_mask, (size_t)s->n_local * s->dim, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// the host-side per-generation decisions, for parity against oracle/philox_ref.py
+extern "C" int bpm_debug_perm(bpm_handle_t s, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,
+                              int32_t* out_inverse, int32_t* out_flip) {
+    CK(check_handle(s));
+    const PermKey pk = make_perm_key(s->cfg.seed, (uint64_t)t, s->N, shuffle != 0);
+    for (uint32_t x = 0; x < s->N; ++x) {
+        if (out_order) out_order[x] = (int32_t)perm_fwd(x, pk);
+        if (out_inverse) out_inverse[x] = (int32_t)perm_inv(x, pk);
+    }
+    if (out_flip) *out_flip = flip_draw(s->cfg.seed, (uint64_t)t, flip_prob) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uint32_t* out_mine, uint32_t* out_rocrand) {
+    if (n <= 0 || !out_mine || !out_rocrand) return fail("bpm_selftest_philox: bad argument");
+    HIPCK(hipSetDevice(device));
+    uint32_t* d = nullptr;
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 8 * sizeof(uint32_t)));
+    launch_rocrand_check(d, n, seed);
+    HIPCK(hipGetLastError());
+    HIPCK(hipDeviceSynchronize());
+    std::vector<uint32_t> h((size_t)n * 8);
+    HIPCK(hipMemcpy(h.data(), d, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCK(hipFree(d));
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(out_mine + 4 * (size_t)i, h.data() + 8 * (size_t)i, 16);
+        std::memcpy(out_rocrand + 4 * (size_t)i, h.data() + 8 * (size_t)i + 4, 16);
+    }
+    return 0;
+}

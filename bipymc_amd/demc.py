@@ -1,0 +1,310 @@
+"""Parallel DE-MC sampler on MI355X -- drop-in for `bipymc.demc.DeMcMpi`
+(reference: bipymc/demc.py:10-338; base classes bipymc/samplers.py:10-84, 237-336).
+
+Same constructor, `run_mcmc(n, **kwargs)`, `param_est(n_burn)`, `acceptance_fraction`,
+`am_chains`, `save_state` / `load_state`, `super_chain_mpi`, `gather_all_chains`,
+`iter_local_chains`, `iter_all_chains`, `get_chain`, `get_chain_rank`.  The generation loop
+(demc.py:79-140) runs inside libbipymc_hip.so (include/bipymc_hip.h): this class only
+translates arguments, drives `bpm_step`, and assembles results.
+
+Differences a caller can see (see DESIGN.md "Deviations"):
+  * randomness comes from counter-based Philox streams keyed by `seed=` (default: one
+    draw from `np.random`, so `np.random.seed(42)` before construction still pins a run);
+  * `mpi_comm` may be None (single GPU), "torch" / a torch.distributed group, or an
+    mpi4py-style communicator; one process drives one GPU;
+  * a `ln_like_fn` that is the bound `ln_like` of a shipped target object
+    (bipymc_amd.utils.*) is evaluated on the GPU; any other callable is called on the host
+    once per chain update with a 1-D float64 array, exactly like the reference.
+"""
+from __future__ import division, print_function
+
+import numpy as np
+
+from . import _lib as L
+from . import comm as _comm
+from .chain import DetachedChain, McmcChain
+from .utils import _target
+
+
+def _default_engine_factory(**kw):
+    from .engine import HipEngine
+    return HipEngine(**kw)
+
+
+class DeMcMpi(object):
+    """!
+    @brief DE-MC population sampler, one process per MI355X.
+    """
+    _ALGO = L.ALGO_DEMC
+
+    def __init__(self, ln_like_fn, theta_0=None, varepsilon=1e-6, n_chains=8,
+                 mpi_comm=None, ln_kwargs={}, **kwargs):
+        assert n_chains >= 4                                   # samplers.py:249
+        varepsilon = np.asarray(varepsilon, dtype=np.float64)
+        self.n_chains = int(n_chains)
+        self.comm = _comm.wrap(mpi_comm)
+        self.local_n_accepted = 0
+        self.local_n_rejected = 1                              # demc.py:18
+        self.n_accepted = 1                                    # samplers.py:30-31
+        self.n_rejected = 0
+        if theta_0 is not None:
+            self.dim = len(np.asarray(theta_0).reshape(-1))
+        else:
+            self.dim = int(kwargs.get("dim", 1))
+        self.h5_file = kwargs.get("h5_file", "sampler_checkpoint.h5")
+        self.warm_start = kwargs.get("warm_start", False)
+        self.checkpoint = kwargs.get("checkpoint", 0)
+        self.log_like_fn = ln_like_fn
+        self._ln_kwargs = dict(ln_kwargs)
+        self._freeze_ln_like_fn(**self._ln_kwargs)
+        if self.n_chains % self.comm.size != 0:
+            raise ValueError("n_chains must be a multiple of the communicator size "
+                             "(unequal blocks break the reference's Allgather too, demc.py:39,93)")
+        # ---- device engine --------------------------------------------
+        seed = kwargs.get("seed", None)
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 62)) if self.comm.rank == 0 else None
+        self.seed = int(self.comm.bcast(seed, root=0))
+        self._target_id, self._target_params = _target.resolve(ln_like_fn, self._ln_kwargs, self.dim)
+        if kwargs.get("force_host_callback", False):
+            self._target_id, self._target_params = L.TARGET_HOST_CALLBACK, None
+        factory = kwargs.get("engine_factory", _default_engine_factory)
+        uid = None
+        if self.comm.size > 1 and kwargs.get("engine_needs_uid", True):
+            if self.comm.rank == 0:
+                from .engine import HipEngine
+                uid = HipEngine.unique_id() if factory is _default_engine_factory else b"\0" * L.UID_BYTES
+            uid = self.comm.bcast(uid, root=0)
+        self._engine = factory(
+            algo=self._ALGO, n_chains=self.n_chains, dim=self.dim, target_id=self._target_id,
+            target_params=self._target_params, seed=self.seed,
+            device=kwargs.get("device", self._default_device()), rank=self.comm.rank, world_size=self.comm.size,
+            nccl_uid=uid, p_snooker=kwargs.get("p_snooker", 0.0), outlier_every=kwargs.get("outlier_every", 0),
+            keep_history=kwargs.get("keep_history", True), **self._engine_kwargs(kwargs))
+        self.n_local = self.n_chains // self.comm.size
+        self._hist_cache = None
+        self._hist_cache_rows = -1
+        self.am_chains = []
+        if not self.warm_start:
+            self.init_chains(theta_0, varepsilon, **kwargs)
+        else:
+            self.init_warmstart_chain(self.h5_file)
+
+    # ---- hooks for DreamMpi --------------------------------------------
+    def _engine_kwargs(self, kwargs):
+        return {}
+
+    def _default_device(self):
+        import os
+        return int(os.environ.get("LOCAL_RANK", "0")) if self.comm.size > 1 else 0
+
+    # ---- samplers.py:36-47 -----------------------------------------------
+    def _freeze_ln_like_fn(self, **kwargs):
+        self._frozen_ln_like_fn = lambda theta: self.log_like_fn(theta, **kwargs)
+
+    @property
+    def frozen_ln_like_fn(self):
+        return self._frozen_ln_like_fn
+
+    @property
+    def uses_device_target(self):
+        return self._target_id != L.TARGET_HOST_CALLBACK
+
+    # ---- chains ------------------------------------------------------------
+    def init_chains(self, theta_0, varepsilon=1e-6, **kwargs):
+        """demc.py:34-44: contiguous id blocks per rank; chain.py:25-27 jitter on the device."""
+        rank_chain_ids = np.array_split(np.array(range(self.n_chains)), self.comm.size)[self.comm.rank]
+        self.rank_chain_ids = rank_chain_ids
+        if theta_0 is None:
+            theta_0 = np.zeros(self.dim)
+        self._engine.init_chains(theta_0, np.asarray(varepsilon, dtype=np.float64))
+        self._after_state_reset()
+
+    def init_warmstart_chain(self, h5_file):
+        """demc.py:46-51."""
+        self.init_chains(np.zeros(self.dim), 0.0)
+        self.load_state(h5_file)
+
+    def _after_state_reset(self):
+        self.am_chains = [McmcChain(self, int(c), i) for i, c in enumerate(self.rank_chain_ids)]
+        self._hist_cache = None
+        self._hist_cache_rows = -1
+        self._warm_prefix = None
+        if not self.uses_device_target:
+            X = self._engine.get_state()
+            lo = self.comm.rank * self.n_local
+            ll = np.array([self._call_ln_like(X[lo + i]) for i in range(self.n_local)], dtype=np.float64)
+            self._engine.set_loglike(ll)
+
+    def _call_ln_like(self, theta):
+        v = self._frozen_ln_like_fn(np.array(theta, dtype=np.float64))
+        return float(np.asarray(v).reshape(-1)[0]) if np.ndim(v) else float(v)
+
+    def _get_local_chain_state(self):
+        """demc.py:53-57."""
+        lo = self.comm.rank * self.n_local
+        return self._engine.get_state()[lo:lo + self.n_local]
+
+    def _local_history(self):
+        rows = self._engine.history_rows()
+        if self._hist_cache is None or rows != self._hist_cache_rows:
+            h = self._engine.get_history(0, rows)
+            if self._warm_prefix is not None:
+                h = np.concatenate([self._warm_prefix, h[1:]], axis=0)
+            self._hist_cache = h
+            self._hist_cache_rows = rows
+        return self._hist_cache
+
+    # ---- the run ---------------------------------------------------------------
+    def run_mcmc(self, n, **kwargs):
+        self._mcmc_run(n, **kwargs)
+
+    def _n_generations(self, n):
+        """Iterations of `while j < int((n - n_chains) / size)` (demc.py:79): j grows by the
+        number of local chains per generation."""
+        target = int((n - self.n_chains) / self.comm.size)
+        return max(0, -(-target // self.n_local))
+
+    def _run_opts(self, kwargs):
+        return dict(flip=kwargs.get("flip", 0.5), shuffle=kwargs.get("shuffle", True),
+                    epsilon=kwargs.get("epsilon", None), u_epsilon=kwargs.get("u_epsilon", None),
+                    gamma=kwargs.get("gamma", None))
+
+    def _mcmc_run(self, n, **kwargs):
+        if not self.am_chains:
+            raise RuntimeError("ERROR: chains not initilized")       # demc.py:65-66
+        n_gens = self._n_generations(n)
+        eng = self._engine
+        eng.begin_run(**self._run_opts(kwargs))
+        eng.reserve_history(eng.history_rows() + n_gens)
+        done = 0
+        chunk = int(self.checkpoint) if self.checkpoint and self.checkpoint > 0 else n_gens
+        while done < n_gens:
+            todo = min(chunk, n_gens - done)
+            if self.uses_device_target:
+                eng.step(todo)
+            else:
+                for _ in range(todo):
+                    self._host_generation()
+            done += todo
+            if self.checkpoint and self.checkpoint > 0 and done % self.checkpoint == 0:
+                self.save_state(self.h5_file)                        # demc.py:138-140
+        eng.synchronize()
+        st = eng.stats()
+        self._last_stats = st
+        if st["n_nan_alpha"] > 0:
+            # np.random.choice(p=[nan, nan]) in the reference (samplers.py:336)
+            raise ValueError("probabilities contain NaN")
+        self.local_n_accepted = int(st["local_n_accepted"])
+        self.local_n_rejected = int(st["local_n_rejected"])
+        counts = self.comm.allgather((self.local_n_accepted, self.local_n_rejected))   # demc.py:143-150
+        self.n_accepted = int(sum(c[0] for c in counts))
+        self.n_rejected = int(sum(c[1] for c in counts))
+        self._hist_cache = None
+        self.comm.Barrier()
+
+    def _host_generation(self):
+        """One generation with a Python ln_like_fn: two propose/commit half generations."""
+        for _ in range(2):
+            props, _ids = self._engine.propose()
+            ll = np.array([self._call_ln_like(p) for p in props], dtype=np.float64)
+            self._engine.commit(ll)
+
+    @property
+    def acceptance_fraction(self):
+        """samplers.py:75-80."""
+        return self.n_accepted / (self.n_accepted + self.n_rejected)
+
+    # ---- results -----------------------------------------------------------------
+    def param_est(self, n_burn, collection_rank=0):
+        """demc.py:235-248."""
+        self.comm.Barrier()
+        chain_slice = self.super_chain_mpi(collection_rank)
+        if self.comm.rank == collection_rank:
+            chain_slice = chain_slice[n_burn:, :]
+            mean_theta = np.mean(chain_slice, axis=0)
+            std_theta = np.std(chain_slice, axis=0)
+            return mean_theta, std_theta, chain_slice
+        return None, None, None
+
+    def super_chain_mpi(self, collection_rank=0):
+        return self._super_chain(collection_rank)
+
+    def _super_chain(self, collection_rank=0):
+        """demc.py:260-270: row g*n_chains + i = chain i at generation g.  The device history is
+        already generation-major, so this is a concatenation along the chain axis."""
+        local = self._local_history()                               # (T, n_local, d)
+        if self.comm.size == 1:
+            return local.reshape(-1, self.dim).copy()
+        parts = self.comm.allgather(local)
+        if self.comm.rank != collection_rank:
+            return None
+        return np.concatenate(parts, axis=1).reshape(-1, self.dim)
+
+    def gather_all_chains(self, collection_rank=0):
+        return list(self.iter_all_chains(collection_rank))
+
+    def iter_local_chains(self):
+        for chain in self.am_chains:
+            yield chain
+
+    def iter_all_chains(self, collection_rank=0, verbose=0):
+        if self.comm.size == 1:
+            for chain in self.am_chains:
+                yield chain
+            return
+        parts = self.comm.allgather(self._local_history())
+        if self.comm.rank == collection_rank:
+            full = np.concatenate(parts, axis=1)
+            for c_id in range(self.n_chains):
+                yield DetachedChain(c_id, full[:, c_id, :])
+        else:
+            for c_id in range(self.n_chains):
+                yield None
+
+    def get_chain(self, c_id, collection_rank=0, verbose=0):
+        assert 0 <= c_id < self.n_chains
+        r = self.get_chain_rank(c_id)
+        if self.comm.size == 1 or (r == collection_rank and self.comm.rank == r):
+            return self.am_chains[c_id - self.comm.rank * self.n_local]
+        parts = self.comm.allgather(self._local_history()[:, c_id - r * self.n_local, :]
+                                    if self.comm.rank == r else None)
+        if self.comm.rank == collection_rank:
+            return DetachedChain(c_id, parts[r])
+        return None
+
+    def get_chain_rank(self, c_id):
+        """demc.py:327-338."""
+        assert 0 <= c_id < self.n_chains
+        return int(c_id // self.n_local)
+
+    # ---- checkpoint (demc.py:198-233; chain.py:59-93) --------------------------------
+    def save_state(self, h5_file=""):
+        from . import checkpoint
+        if not h5_file:
+            h5_file = self.h5_file
+        full = self._super_chain(0)
+        if self.comm.rank == 0:
+            T = full.shape[0] // self.n_chains
+            checkpoint.write(h5_file, full.reshape(T, self.n_chains, self.dim), self._adapt_state())
+        self.comm.Barrier()
+
+    def load_state(self, h5_file=""):
+        from . import checkpoint
+        if not h5_file:
+            h5_file = self.h5_file
+        hist, adapt = checkpoint.read(h5_file, self.n_chains, self.dim)   # (T, N, d)
+        self._engine.set_state(hist[-1])
+        self._after_state_reset()
+        lo = self.comm.rank * self.n_local
+        self._warm_prefix = hist[:, lo:lo + self.n_local, :].copy()
+        self._restore_adapt_state(adapt)
+        self.comm.Barrier()
+
+    def _adapt_state(self):
+        st = self._engine.stats()
+        return dict(t_abs=int(st["t_abs"]), seed=self.seed)
+
+    def _restore_adapt_state(self, adapt):
+        if adapt and "t_abs" in adapt:
+            self._engine.set_adapt_state(t_abs=int(adapt["t_abs"]))

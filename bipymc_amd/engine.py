@@ -1,0 +1,210 @@
+"""Thin object wrapper over the C ABI: one `HipEngine` = one `bpm_handle_t`.
+
+Mirrors, call for call, what DeMcMpi/DreamMpi need from the device: construction
+(demc.py:14-32, dream.py:17-30), chain initialisation (chain.py:25-27), the
+generation loop (demc.py:63-151), history (chain.py:51-54) and statistics.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class HipEngine(object):
+    def __init__(self, algo, n_chains, dim, target_id, target_params, seed, device=0, rank=0, world_size=1,
+                 nccl_uid=None, gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
+                 p_snooker=0.0, outlier_every=0, keep_history=True):
+        self._h = C.c_void_p()
+        self.lib = L.load()
+        self.n_chains, self.dim = int(n_chains), int(dim)
+        self.rank, self.world_size = int(rank), int(world_size)
+        if self.n_chains % self.world_size != 0:
+            raise ValueError("n_chains must be divisible by the communicator size")
+        self.n_local = self.n_chains // self.world_size
+        self.lo = self.rank * self.n_local
+        tp = np.ascontiguousarray(target_params if target_params is not None else [], dtype=np.float64)
+        cfg = L.BpmConfig()
+        cfg.abi_version = L.ABI_VERSION
+        cfg.algo = int(algo)
+        cfg.n_chains = self.n_chains
+        cfg.dim = self.dim
+        cfg.target_id = int(target_id)
+        cfg.n_target_params = int(tp.size)
+        cfg.target_params = _dptr(tp) if tp.size else None
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.device = int(device)
+        cfg.rank = self.rank
+        cfg.world_size = self.world_size
+        cfg.nccl_uid = bytes(nccl_uid) if nccl_uid is not None else None
+        cfg.gamma_scale = float(gamma_scale)
+        cfg.del_pairs = int(del_pairs)
+        cfg.burnin_gen = int(burnin_gen)
+        cfg.n_cr_gen = int(n_cr_gen)
+        cfg.n_cr = int(n_cr)
+        cfg.p_snooker = float(p_snooker)
+        cfg.outlier_every = int(outlier_every)
+        cfg.keep_history = 1 if keep_history else 0
+        L.check(self.lib.bpm_create(C.byref(cfg), C.byref(self._h)))
+        self.algo, self.target_id = int(algo), int(target_id)
+        self.n_cr = int(n_cr) if algo == L.ALGO_DREAM else 1
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(L.UID_BYTES)
+        L.check(L.load().bpm_get_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.bpm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ------------------------------------------------------
+    def init_chains(self, theta_0, varepsilon):
+        t0 = np.ascontiguousarray(np.asarray(theta_0, dtype=np.float64).reshape(-1))
+        if t0.size != self.dim:
+            raise ValueError("theta_0 has %d entries, dim is %d" % (t0.size, self.dim))
+        var = np.ascontiguousarray(np.broadcast_to(np.asarray(varepsilon, dtype=np.float64), (self.dim,)))
+        L.check(self.lib.bpm_init_chains(self._h, _dptr(t0), _dptr(var)))
+
+    def set_state(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.shape != (self.n_chains, self.dim):
+            raise ValueError("state must have shape (n_chains, dim)")
+        L.check(self.lib.bpm_set_state(self._h, _dptr(X)))
+
+    def get_state(self):
+        X = np.empty((self.n_chains, self.dim), dtype=np.float64)
+        L.check(self.lib.bpm_get_state(self._h, _dptr(X)))
+        return X
+
+    def set_loglike(self, ll_local):
+        ll = np.ascontiguousarray(ll_local, dtype=np.float64)
+        assert ll.shape == (self.n_local,)
+        L.check(self.lib.bpm_set_loglike(self._h, _dptr(ll)))
+
+    def get_loglike(self):
+        ll = np.empty(self.n_local, dtype=np.float64)
+        L.check(self.lib.bpm_get_loglike(self._h, _dptr(ll)))
+        return ll
+
+    # ---- running ----------------------------------------------------
+    def begin_run(self, flip=0.5, shuffle=True, epsilon=None, u_epsilon=None, gamma=None):
+        o = L.BpmRunOpts()
+        o.flip = float(flip)
+        o.shuffle = 1 if shuffle else 0
+        o.epsilon = -1.0 if epsilon is None else float(epsilon)
+        o.u_epsilon = -1.0 if u_epsilon is None else float(u_epsilon)
+        o.gamma = -1.0 if gamma is None else float(gamma)
+        L.check(self.lib.bpm_begin_run(self._h, C.byref(o)))
+
+    def step(self, n_gens):
+        L.check(self.lib.bpm_step(self._h, int(n_gens)))
+
+    def step_timed(self, n_gens):
+        ms = C.c_float(0.0)
+        L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms)))
+        return float(ms.value)
+
+    def synchronize(self):
+        L.check(self.lib.bpm_synchronize(self._h))
+
+    def propose(self):
+        prop = np.empty((self.n_local, self.dim), dtype=np.float64)
+        ids = np.empty(self.n_local, dtype=np.int32)
+        n = C.c_int32(0)
+        L.check(self.lib.bpm_propose(self._h, _dptr(prop), _iptr(ids), C.byref(n)))
+        return prop[:n.value], ids[:n.value]
+
+    def commit(self, ll_prop):
+        ll = np.ascontiguousarray(ll_prop, dtype=np.float64)
+        L.check(self.lib.bpm_commit(self._h, _dptr(ll) if ll.size else None))
+
+    def reserve_history(self, rows):
+        L.check(self.lib.bpm_reserve_history(self._h, int(rows)))
+
+    # ---- results ----------------------------------------------------
+    def stats(self):
+        st = L.BpmStats()
+        L.check(self.lib.bpm_get_stats(self._h, C.byref(st)))
+        n = st.n_cr
+        return dict(local_n_accepted=st.local_n_accepted, local_n_rejected=st.local_n_rejected,
+                    n_nan_alpha=st.n_nan_alpha, k_gen=st.k_gen, t_abs=st.t_abs, history_rows=st.history_rows,
+                    n_outlier_resets=st.n_outlier_resets,
+                    p_cr=np.array(st.p_cr[:n]), delta_m=np.array(st.delta_m[:n]),
+                    n_cr_updates=np.array(st.n_cr_updates[:n]))
+
+    def history_rows(self):
+        return int(self.stats()["history_rows"])
+
+    def get_history(self, g_lo=0, g_hi=None):
+        """(g_hi - g_lo, n_local, dim): row g, local chain i."""
+        if g_hi is None:
+            g_hi = self.history_rows()
+        out = np.empty((max(0, g_hi - g_lo), self.n_local, self.dim), dtype=np.float64)
+        L.check(self.lib.bpm_get_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
+        return out
+
+    def get_loglike_history(self, g_lo=0, g_hi=None):
+        if g_hi is None:
+            g_hi = self.history_rows()
+        out = np.empty((max(0, g_hi - g_lo), self.n_local), dtype=np.float64)
+        L.check(self.lib.bpm_get_loglike_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
+        return out
+
+    def set_adapt_state(self, p_cr=None, delta_m=None, n_cr_updates=None, t_abs=-1):
+        keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None
+                for a in (p_cr, delta_m, n_cr_updates)]
+        L.check(self.lib.bpm_set_adapt_state(self._h, *[None if a is None else _dptr(a) for a in keep], int(t_abs)))
+
+    def eval_loglike(self, X):
+        X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64)
+        assert X.shape[1] == self.dim
+        out = np.empty(X.shape[0], dtype=np.float64)
+        L.check(self.lib.bpm_eval_loglike(self._h, _dptr(X), X.shape[0], _dptr(out)))
+        return out
+
+    # ---- parity hooks -------------------------------------------------
+    def set_trace(self, on=True):
+        L.check(self.lib.bpm_set_trace(self._h, 1 if on else 0))
+
+    def get_trace(self):
+        ti = np.empty((self.n_local, L.TRACE_I32), dtype=np.int32)
+        tf = np.empty((self.n_local, L.TRACE_F64), dtype=np.float64)
+        tm = np.empty((self.n_local, self.dim), dtype=np.uint8)
+        L.check(self.lib.bpm_get_trace(self._h, _iptr(ti), _dptr(tf), tm.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return dict(cr_idx=ti[:, 0], d_prime=ti[:, 1], jump=ti[:, 2], accepted=ti[:, 3], snooker=ti[:, 4],
+                    partners=ti[:, 5:5 + L.MAX_PARTNERS], alpha=tf[:, 0], ll_prop=tf[:, 1], delta=tf[:, 2],
+                    gamma=tf[:, 3], mask=tm.astype(bool))
+
+    def debug_perm(self, t, shuffle=True, flip_prob=0.5):
+        order = np.empty(self.n_chains, dtype=np.int32)
+        inv = np.empty(self.n_chains, dtype=np.int32)
+        flip = C.c_int32(0)
+        L.check(self.lib.bpm_debug_perm(self._h, int(t), 1 if shuffle else 0, float(flip_prob), _iptr(order),
+                                        _iptr(inv), C.byref(flip)))
+        return order, inv, bool(flip.value)
+
+
+def selftest_philox(n=4096, seed=42, device=0):
+    lib = L.load()
+    mine = np.empty((n, 4), dtype=np.uint32)
+    ref = np.empty((n, 4), dtype=np.uint32)
+    L.check(lib.bpm_selftest_philox(int(device), int(n), int(seed), mine.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    ref.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return mine, ref

@@ -1,0 +1,167 @@
+/*
+ * bipymc_hip.h -- C ABI of the MI355X-native DE-MC / DREAM population sampler.
+ *
+ * This is the drop-in boundary for the per-generation hot path of
+ * wgurecky/bipymc's parallel samplers (reference paths relative to
+ * /root/reference):
+ *
+ *   DeMcMpi._mcmc_run            bipymc/demc.py:63-151   generation driver, a/b pools, 2x Allgather
+ *   DeMcMpi._update_chain_pool   bipymc/demc.py:153-196  DE-MC proposal + Metropolis
+ *   DreamMpi._update_chain_pool  bipymc/dream.py:32-107  DREAM proposal (CR mask, multi-pair jump, jitter)
+ *   DreamMpi._update_cr_ratios   bipymc/dream.py:119-140 crossover-probability adaptation
+ *   DeMc._mut_prop_ratio / metropolis_accept  bipymc/samplers.py:328-336
+ *   var_ball / var_box           bipymc/util.py:5-28
+ *   McmcChain history            bipymc/chain.py:13-29,51-54,122-124
+ *   targets                      bipymc/utils/{d100_gauss,dblgauss_rv,banana_rv}.py
+ *   param_est / _super_chain     bipymc/demc.py:235-270
+ *
+ * The reference is pure Python and has no FFI of its own; the binding a
+ * maintainer would add is the ctypes stub in INTEGRATION.md (the host-side
+ * classes in bipymc_amd/{demc,dream}.py are that stub, written out).
+ *
+ * Conventions: opaque handle; every call returns 0 on success, non-zero on
+ * error, and bpm_last_error() returns the message of the calling thread's last
+ * failure.  No exceptions cross the boundary.  All buffers are caller-owned
+ * host memory, row-major float64 unless stated; the library copies.  One host
+ * thread per handle.  With world_size > 1 every rank must make the same
+ * sequence of collective calls (create, init/set_state, begin_run, step,
+ * propose/commit), exactly as all MPI ranks of the reference enter
+ * comm.Allgather / comm.Barrier in lock-step.
+ */
+#ifndef BIPYMC_HIP_H
+#define BIPYMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPM_ABI_VERSION 1
+
+/* algo */
+#define BPM_ALGO_DEMC 0  /* bipymc/demc.py:153-196 */
+#define BPM_ALGO_DREAM 1 /* bipymc/dream.py:32-107 */
+
+/* target ids: which ln_like_fn is evaluated on the device */
+#define BPM_TARGET_HOST_CALLBACK 0  /* arbitrary Python ln_like_fn (samplers.py:36-43): propose/commit */
+#define BPM_TARGET_GAUSS_EQUICORR 1 /* utils/d100_gauss.py:14-35; params [rho,c0,a,b,1/sigma_0..d-1] */
+#define BPM_TARGET_MIXTURE_PAIRS 2  /* utils/dblgauss_rv.py:11-32 (d=2) and its pairwise d-dim extension */
+#define BPM_TARGET_BANANA_2D 3      /* utils/banana_rv.py:11-37 */
+
+#define BPM_MAX_CR 8
+#define BPM_UID_BYTES 128
+
+typedef struct bpm_sampler* bpm_handle_t;
+
+/* Constructor arguments: DeMcMpi.__init__ (demc.py:14-32) / DreamMpi.__init__ (dream.py:17-30). */
+typedef struct bpm_config {
+    int32_t abi_version; /* BPM_ABI_VERSION */
+    int32_t algo;        /* BPM_ALGO_* */
+    int32_t n_chains;    /* global number of chains, >= 4 (samplers.py:249), divisible by world_size */
+    int32_t dim;         /* len(theta_0) or kwargs["dim"] (demc.py:20-23) */
+    int32_t target_id;   /* BPM_TARGET_* */
+    int32_t n_target_params;
+    const double* target_params; /* copied */
+    uint64_t seed;               /* np.random.seed(...) analogue: key of every Philox stream */
+    int32_t device;              /* HIP device ordinal */
+    int32_t rank;                /* comm.rank; owns chains array_split(range(N), size)[rank] (demc.py:39) */
+    int32_t world_size;          /* comm.size */
+    const char* nccl_uid;        /* BPM_UID_BYTES from bpm_get_unique_id on rank 0; NULL if world_size==1 */
+    /* DREAM kwargs (dream.py:20-27) */
+    double gamma_scale; /* 1.0 */
+    int32_t del_pairs;  /* 3 */
+    int32_t burnin_gen; /* 300 */
+    int32_t n_cr_gen;   /* 50 */
+    int32_t n_cr;       /* 3, <= BPM_MAX_CR */
+    /* build-defined extensions (absent from the reference) */
+    double p_snooker;      /* DE-MC only: probability of a snooker update (0 = off) */
+    int32_t outlier_every; /* DREAM burn-in: IQR outlier-chain reset every this many generations (0 = off) */
+    int32_t keep_history;  /* 1: append every generation (chain.py:51-54); 0: keep current state only */
+} bpm_config_t;
+
+/* run_mcmc(**kwargs) (demc.py:73-75,161-162; dream.py:40-41). */
+typedef struct bpm_run_opts {
+    double flip;      /* 0.5; clipped to [0,1] */
+    int32_t shuffle;  /* 1 */
+    int32_t _pad;
+    double epsilon;   /* < 0: default (DE-MC 1e-15, DREAM 1e-12); std of the normal jitter */
+    double u_epsilon; /* < 0: default 1e-2 (DREAM uniform jitter half-width) */
+    double gamma;     /* <= 0: default 2.38/sqrt(2 dim) (DE-MC only) */
+} bpm_run_opts_t;
+
+typedef struct bpm_stats {
+    int64_t local_n_accepted; /* demc.py:67,190 (this run, this rank) */
+    int64_t local_n_rejected; /* demc.py:68,193: starts at 1 */
+    int64_t n_nan_alpha;      /* updates whose Metropolis ratio was NaN (reference raises ValueError) */
+    int64_t k_gen;            /* generations done in the current run (demc.py:78,134) */
+    int64_t t_abs;            /* generations done since creation */
+    int64_t history_rows;     /* generations stored + 1 (row 0 = initial state) */
+    int64_t n_outlier_resets;
+    int32_t n_cr;
+    int32_t _pad;
+    double p_cr[BPM_MAX_CR];         /* dream.py:114 */
+    double delta_m[BPM_MAX_CR];      /* dream.py:117 */
+    double n_cr_updates[BPM_MAX_CR]; /* dream.py:115 */
+} bpm_stats_t;
+
+const char* bpm_last_error(void);
+int bpm_abi_version(void);
+
+/* rank 0 calls this and ships the bytes to the other ranks (mpi4py bcast / torch.distributed). */
+int bpm_get_unique_id(char out[BPM_UID_BYTES]);
+
+int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out);
+int bpm_destroy(bpm_handle_t h);
+
+/* McmcChain.__init__ for every chain (chain.py:25-27): state0 = theta_0 + N(0, diag(varepsilon)),
+ * varepsilon = VARIANCES, length dim (all > 0, else no jitter: util.py:12).  History := [state0]. */
+int bpm_init_chains(bpm_handle_t h, const double* theta_0, const double* varepsilon);
+/* Set the (N, dim) state matrix in global-id order (warm start, demc.py:46-51).  History := [X]. */
+int bpm_set_state(bpm_handle_t h, const double* X);
+int bpm_get_state(bpm_handle_t h, double* X);
+/* cached ln_like of the current state: all N values (host-callback targets must set the local ones). */
+int bpm_set_loglike(bpm_handle_t h, const double* ll_local); /* n_local values */
+int bpm_get_loglike(bpm_handle_t h, double* ll_local);
+
+/* _mcmc_run prologue (demc.py:67-78): counters reset, k_gen = 0, kwargs latched. */
+int bpm_begin_run(bpm_handle_t h, const bpm_run_opts_t* opts);
+/* n_gens iterations of the while loop of demc.py:79-140, entirely on the device. Asynchronous. */
+int bpm_step(bpm_handle_t h, int64_t n_gens);
+/* same, bracketed by HIP events on the sampler's stream; returns elapsed device time. */
+int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms);
+int bpm_synchronize(bpm_handle_t h);
+
+/* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
+ * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop
+ * (n_out rows of dim) and their global ids into out_ids (capacity n_local each); the caller evaluates
+ * ln_like_fn row by row and hands the values to bpm_commit, which does the Metropolis test
+ * (samplers.py:328-336), the append (chain.py:51-54) and, after the second phase, k_gen += 1. */
+int bpm_propose(bpm_handle_t h, double* out_prop, int32_t* out_ids, int32_t* n_out);
+int bpm_commit(bpm_handle_t h, const double* ll_prop);
+
+/* history of this rank's chains: out[(g - g_lo) * n_local * dim + i * dim + j], g in [g_lo, g_hi) */
+int bpm_get_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);
+int bpm_get_loglike_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);
+int bpm_reserve_history(bpm_handle_t h, int64_t total_rows);
+int bpm_get_stats(bpm_handle_t h, bpm_stats_t* out);
+/* checkpoint what the reference forgets: p_cr, delta_m, n_cr_updates, t_abs */
+int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_m, const double* n_cr_updates,
+                        int64_t t_abs);
+
+/* test hooks (no sampler state involved) */
+int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* device target on n points */
+int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uint32_t* out_mine, uint32_t* out_rocrand);
+/* per-generation host decisions (flip, shuffle order and its inverse) for generation t */
+int bpm_debug_perm(bpm_handle_t h, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,
+                   int32_t* out_inverse, int32_t* out_flip);
+/* per-chain integer/float trace of the LAST generation (parity tests):
+ * out_i32[n_local*32] = (cr_idx, d_prime, gamma_jump, accepted, snooker, partner ids[23], ...),
+ * out_f64[n_local*4] = (alpha, ll_prop, delta, gamma), out_mask[n_local*dim] = CR mask */
+int bpm_set_trace(bpm_handle_t h, int32_t on);
+int bpm_get_trace(bpm_handle_t h, int32_t* out_i32, double* out_f64, uint8_t* out_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIPYMC_HIP_H */

@@ -1,0 +1,88 @@
+"""The C-ABI library: builds, loads, and exports every symbol include/bipymc_hip.h declares.
+No compute call is made (no GPU in the CPU test tier)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def built():
+    so = os.path.join(ROOT, "bipymc_amd", "libbipymc_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bipymc_amd", "csrc")])
+    return so
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bipymc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bpm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from bipymc_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built]).decode()
+    exported = set(re.findall(r" T (bpm_[a-z_0-9]+)", out))
+    missing = [s for s in _declared_symbols() if s not in exported]
+    assert not missing, missing
+
+
+def test_library_loads_and_reports_abi(built):
+    from bipymc_amd import _lib
+    lib = _lib.load()
+    assert lib.bpm_abi_version() == _lib.ABI_VERSION
+    assert lib.bpm_last_error() is not None
+
+
+def test_struct_layouts_match_header(built, tmp_path):
+    """sizeof/offsetof of the three ABI structs as the C compiler sees them == ctypes."""
+    import ctypes as C
+    from bipymc_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bipymc_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bpm_config_t), sizeof(bpm_run_opts_t),'
+                   ' sizeof(bpm_stats_t), offsetof(bpm_config_t, seed), offsetof(bpm_config_t, gamma_scale),'
+                   ' offsetof(bpm_config_t, keep_history), offsetof(bpm_stats_t, p_cr));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = list(map(int, subprocess.check_output([str(exe)]).split()))
+    exp = [C.sizeof(_lib.BpmConfig), C.sizeof(_lib.BpmRunOpts), C.sizeof(_lib.BpmStats), _lib.BpmConfig.seed.offset,
+           _lib.BpmConfig.gamma_scale.offset, _lib.BpmConfig.keep_history.offset, _lib.BpmStats.p_cr.offset]
+    assert got == exp
+
+
+def test_no_gpu_means_loud_failure(built):
+    """The product has no CPU path: creating a sampler without a device is an error, not a fallback."""
+    import numpy as np
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    from bipymc_amd import _lib
+    from bipymc_amd.engine import HipEngine
+    with pytest.raises(_lib.BpmError):
+        HipEngine(algo=0, n_chains=8, dim=2, target_id=3, target_params=np.zeros(9), seed=1)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under bipymc_amd/ may import, include, link or load it."""
+    pkg = os.path.join(ROOT, "bipymc_amd")
+    bad = re.compile(r"^\s*(import\s+oracle|from\s+oracle|from\s+\.\.?oracle|#\s*include\s+\"[^\"]*oracle)|dlopen\([^)]*oracle|CDLL\([^)]*oracle",
+                     re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(text), os.path.join(dirpath, f)

@@ -1,0 +1,311 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same seeds.  Bit-exact on every integer quantity; float tolerances are written at each assert.
+
+Run on the GPU box with `pytest -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import philox_ref as P
+from oracle import sampler_ref as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL_STEP = 1e-12      # one generation: only libm (log/cos/exp) and reduction-order differences
+ATOL_STEP = 1e-15
+
+
+def _engine(**kw):
+    from bipymc_amd.engine import HipEngine
+    return HipEngine(**kw)
+
+
+def _gauss_params(d, rho=0.5):
+    return R.gauss_equicorr_params(rho, np.sqrt(np.arange(d) + 1.0))
+
+
+def _mix_params():
+    return R.mixture_pairs_params(0.25, 0.75, [0, 0], [2, 2], [0.25, 0.25], [0.25, 0.25], 0.8, -0.8)
+
+
+def _pair(algo, N, d, target_id, params, seed, **kw):
+    """(HipEngine, OracleSampler) with identical configuration."""
+    eng = _engine(algo=algo, n_chains=N, dim=d, target_id=target_id, target_params=params, seed=seed, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("gamma_scale", "del_pairs", "burnin_gen", "n_cr_gen", "n_cr", "p_snooker")}
+    ora = R.OracleSampler(algo, N, d, target_id, params, seed, **okw)
+    return eng, ora
+
+
+# ------------------------------------------------------------------ RNG layer
+def test_philox_equals_rocrand_on_device():
+    from bipymc_amd.engine import selftest_philox
+    mine, ref = selftest_philox(n=8192, seed=0x1234567890ABCDEF)
+    assert np.array_equal(mine, ref)                      # inline Philox == rocRAND device engine, bit for bit
+    # and both equal the oracle's statement of the same blocks
+    i = np.arange(8192, dtype=np.uint64)
+    subseq = np.where(i % 3 == 0, P.SUBSEQ_GLOBAL, i * np.uint64(2654435761))
+    blk = ((i * np.uint64(37)) << np.uint64(16)) | (i % np.uint64(120))
+    exp = P.block(0x1234567890ABCDEF, subseq, blk)
+    assert np.array_equal(mine, exp)
+
+
+@pytest.mark.parametrize("N", [4, 5, 10, 64, 1000, 8192, 65536])
+def test_shuffle_and_flip_bit_exact(N):
+    eng = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=99)
+    for t in (0, 1, 17, 70000):
+        order, inv, flip = eng.debug_perm(t, True, 0.5)
+        exp = P.shuffle_idx(99, t, N)
+        assert np.array_equal(order, exp)
+        assert np.array_equal(inv, P.perm_inv(np.arange(N), N, P.shuffle_keys(99, t)))
+        assert flip == P.flip_draw(99, t, 0.5)
+    order, inv, _ = eng.debug_perm(3, False, 0.5)
+    assert np.array_equal(order, np.arange(N)) and np.array_equal(inv, np.arange(N))
+
+
+# ------------------------------------------------------------------ targets
+def test_targets_against_reference_known_answers(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "targets_known_answers.json")))
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=100, target_id=R.TARGET_GAUSS_EQUICORR, target_params=_gauss_params(100), seed=1)
+    X = np.array([e["x"] for e in g["Gauss_100D"]])
+    ll = eng.eval_loglike(X)
+    # tolerance 1e-12 relative: O(d) closed form vs the reference's scipy evaluation
+    np.testing.assert_allclose(ll, [e["logpdf_true"] for e in g["Gauss_100D"]], rtol=1e-12)
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=16, target_id=R.TARGET_GAUSS_EQUICORR, target_params=_gauss_params(16), seed=1)
+    np.testing.assert_allclose(eng.eval_loglike(np.array([e["x"] for e in g["Gauss_16D"]])),
+                               [e["ln_like"] for e in g["Gauss_16D"]], rtol=1e-12)
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=2, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1)
+    np.testing.assert_allclose(eng.eval_loglike(np.array([e["x"] for e in g["BimodeGauss_2D"]])),
+                               [e["ln_like"] for e in g["BimodeGauss_2D"]], rtol=1e-12)
+    eng = _engine(algo=R.ALGO_DEMC, n_chains=8, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(sigma1=1.0, sigma2=1.0), seed=1)
+    np.testing.assert_allclose(eng.eval_loglike(np.array([e["x"] for e in g["Banana_2D"]])),
+                               [e["ln_like"] for e in g["Banana_2D"]], rtol=1e-12)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 16, 33, 100, 128, 130, 256, 300, 512])
+def test_gauss_target_every_kernel_shape(d):
+    """every (lanes-per-chain, dims-per-lane) instantiation, odd dims (padded rows) included"""
+    params = _gauss_params(d, rho=0.3)
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=1)
+    X = np.random.RandomState(d).normal(size=(37, d)) * np.sqrt(np.arange(d) + 1.0)
+    np.testing.assert_allclose(eng.eval_loglike(X), R.ll_gauss_equicorr(X, params), rtol=1e-13)
+
+
+@pytest.mark.parametrize("d", [2, 4, 8, 32, 100])
+def test_mixture_target_shapes(d):
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=d, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1)
+    rs = np.random.RandomState(d)
+    X = np.where(rs.uniform(size=(50, 1)) < 0.5, 0.0, 2.0) + 0.3 * rs.normal(size=(50, d))
+    np.testing.assert_allclose(eng.eval_loglike(X), R.ll_mixture_pairs(X, _mix_params()), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ init
+@pytest.mark.parametrize("d,N", [(2, 10), (100, 64), (7, 12)])
+def test_init_jitter(d, N):
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 5)
+    theta0 = np.linspace(-1, 1, d)
+    var = np.full(d, 1e-6) * (1 + np.arange(d))
+    eng.init_chains(theta0, var)
+    ora.init_jitter(theta0, var)
+    # 1e-13 relative: Box-Muller log/cos of two libms
+    np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=1e-12)
+    eng.init_chains(theta0, np.zeros(d))      # util.py:12: no noise unless all variances > 0
+    assert np.array_equal(eng.get_state(), np.tile(theta0, (N, 1)))
+
+
+# ------------------------------------------------------------------ one generation, everything
+def _collect_oracle_trace(tr, N, d, n_part):
+    out = dict(cr_idx=np.full(N, -1), d_prime=np.full(N, d), jump=np.zeros(N, int), accepted=np.zeros(N, int),
+               snooker=np.zeros(N, int), partners=np.full((N, n_part), -1), mask=np.zeros((N, d), bool),
+               alpha=np.zeros(N), ll_prop=np.zeros(N), delta=np.zeros(N))
+    for ph in ("phase0", "phase1"):
+        r = tr[ph]
+        ids = r["ids"]
+        out["jump"][ids] = r["jump"]
+        out["accepted"][ids] = r["accepted"]
+        out["alpha"][ids] = r["alpha"]
+        out["ll_prop"][ids] = r["ll_prop"]
+        out["delta"][ids] = r["delta"]
+        if "cr_idx" in r:
+            out["cr_idx"][ids] = r["cr_idx"]
+            out["d_prime"][ids] = r["d_prime"]
+            out["mask"][ids] = r["mask"]
+            P_ = r["pa"].shape[1]
+            out["partners"][ids[:, None], 2 * np.arange(P_)[None, :]] = r["pa"]
+            out["partners"][ids[:, None], 2 * np.arange(P_)[None, :] + 1] = r["pb"]
+        else:
+            out["partners"][ids, 0] = r["pa"]
+            out["partners"][ids, 1] = r["pb"]
+            if "snooker" in r:
+                out["snooker"][ids] = r["snooker"]
+                out["partners"][ids, 2] = r["iz"]
+                out["partners"][ids, 3] = r["i1"]
+                out["partners"][ids, 4] = r["i2"]
+    return out
+
+
+def _check_generation(eng, ora, N, d, dream, n_part):
+    ora.trace = []
+    X0 = ora.X.copy()
+    eng.step(1)
+    ora._generation(ora._k, *ora._run_args)
+    ora._k += 1
+    tr = eng.get_trace()
+    exp = _collect_oracle_trace(ora.trace[-1], N, d, n_part)
+    # ---- integer decisions: bit-exact
+    assert np.array_equal(tr["partners"][:, :n_part], exp["partners"])
+    assert np.array_equal(tr["jump"], exp["jump"])
+    if dream:
+        assert np.array_equal(tr["cr_idx"], exp["cr_idx"])
+        assert np.array_equal(tr["d_prime"], exp["d_prime"])
+        assert np.array_equal(tr["mask"], exp["mask"])
+    else:
+        assert np.array_equal(tr["snooker"], exp["snooker"])
+    assert np.array_equal(tr["accepted"], exp["accepted"])
+    # ---- floats: 1e-12 relative (libm + reduction order only)
+    np.testing.assert_allclose(tr["ll_prop"], exp["ll_prop"], rtol=RTOL_STEP, atol=1e-12)
+    np.testing.assert_allclose(tr["alpha"], exp["alpha"], rtol=1e-8, atol=1e-300)   # exp() of an O(100) difference
+    np.testing.assert_allclose(tr["delta"], exp["delta"], rtol=1e-10)
+    X1 = eng.get_state()
+    np.testing.assert_allclose(X1, ora.X, rtol=RTOL_STEP, atol=ATOL_STEP)
+    np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=RTOL_STEP, atol=1e-12)
+    assert not np.array_equal(X1, X0)
+    return float(np.mean(X1 == ora.X))
+
+
+def _start(eng, ora, X, **run):
+    eng.set_state(X)
+    ora.set_state(X)
+    eng.set_trace(True)
+    eng.begin_run(**run)
+    ora.local_n_accepted, ora.local_n_rejected = 0, 1
+    ora._k = 0
+    eps = run.get("epsilon", None)
+    if eps is None:
+        eps = 1e-12 if ora.algo == R.ALGO_DREAM else 1e-15
+    ora._run_args = (float(np.clip(run.get("flip", 0.5), 0, 1)), run.get("shuffle", True), float(eps),
+                     float(run.get("u_epsilon", 1e-2) if run.get("u_epsilon", None) is not None else 1e-2),
+                     run.get("gamma", None))
+
+
+@pytest.mark.parametrize("d,N,P_", [(100, 64, 3), (100, 10, 3), (2, 10, 3), (8, 32, 3), (16, 24, 1), (6, 9, 5),
+                                    (130, 16, 2), (5, 20, 3), (300, 8, 3)])
+def test_dream_generation_parity(d, N, P_):
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 1234, del_pairs=P_,
+                     burnin_gen=100, n_cr_gen=3, n_cr=3)
+    X = np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _start(eng, ora, X)
+    exact = []
+    for g in range(12):       # k = 0, 5, 10 take the gamma=1 branch; CR statistic switches on at history length 4
+        exact.append(_check_generation(eng, ora, N, d, True, 2 * P_))
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+    np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
+    np.testing.assert_allclose(st["delta_m"], ora.cr.delta_m, rtol=1e-9)
+    np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+    assert ora.cr.n_cr_updates.sum() > 0
+    print("fraction of state entries bit-identical to the oracle per generation:", exact)
+
+
+def test_dream_mixture_generation_parity():
+    N, d = 40, 8
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, _mix_params(), 77, burnin_gen=4, n_cr_gen=2)
+    rs = np.random.RandomState(3)
+    X = np.where(rs.uniform(size=(N, 1)) < 0.5, 0.0, 2.0) + 0.3 * rs.normal(size=(N, d))
+    _start(eng, ora, X)
+    for g in range(8):          # adaptation stops after generation 4 (burnin_gen)
+        _check_generation(eng, ora, N, d, True, 6)
+    np.testing.assert_allclose(eng.stats()["p_cr"], ora.cr.p_cr, rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,p_snk", [(8, 0.0), (64, 0.0), (64, 0.3), (1001, 0.1)])
+def test_demc_banana_generation_parity(N, p_snk):
+    eng, ora = _pair(R.ALGO_DEMC, N, 2, R.TARGET_BANANA_2D, R.banana_params(), 4321, p_snooker=p_snk)
+    rs = np.random.RandomState(5)
+    X = rs.normal(size=(N, 2)) * np.array([1.1, 1.1]) + np.array([0.0, 1.2])
+    _start(eng, ora, X)
+    for g in range(11):         # k = 0 and 10 take the gamma = 1 branch
+        _check_generation(eng, ora, N, 2, False, 5 if p_snk > 0 else 2)
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted
+
+
+def test_demc_gauss_with_options():
+    """run_mcmc kwargs: flip, shuffle, epsilon, gamma (demc.py:73-75,161-162)"""
+    N, d = 30, 16
+    eng, ora = _pair(R.ALGO_DEMC, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 8)
+    X = np.random.RandomState(1).normal(size=(N, d))
+    _start(eng, ora, X, flip=1.0, shuffle=False, epsilon=1e-6, gamma=0.4)
+    for g in range(3):
+        _check_generation(eng, ora, N, d, False, 2)
+    _start(eng, ora, X, flip=0.0, shuffle=True, epsilon=0.0)
+    for g in range(3):
+        _check_generation(eng, ora, N, d, False, 2)
+
+
+# ------------------------------------------------------------------ history, results
+def test_history_rows_and_super_chain_order():
+    N, d, G = 12, 6, 9
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 3, burnin_gen=0)
+    X = np.random.RandomState(2).normal(size=(N, d))
+    eng.set_state(X); ora.set_state(X)
+    eng.begin_run(); eng.step(G); ora.run(G)
+    H = eng.get_history()
+    assert H.shape == (G + 1, N, d)
+    assert np.array_equal(H[0], X)                             # row 0 = initial state (chain.py:29)
+    assert np.array_equal(H[-1], eng.get_state())              # last row = current_pos (chain.py:122-124)
+    np.testing.assert_allclose(H, ora.history_array(), rtol=1e-10, atol=1e-14)
+    llh = eng.get_loglike_history()
+    np.testing.assert_allclose(llh, np.stack(ora.ll_history), rtol=1e-10, atol=1e-12)
+    # second run_mcmc call continues the history, k restarts (demc.py:78): gamma jump at k = 0 again
+    eng.begin_run(); eng.step(2); ora.run(2)
+    assert eng.history_rows() == G + 3
+    np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-9, atol=1e-13)
+    st = eng.stats()
+    assert st["k_gen"] == 2 and st["t_abs"] == G + 2
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+
+
+def test_cr_adaptation_resumes_after_gap():
+    """burn-in gating restarts with k on every run_mcmc (demc.py:78, dream.py:92): the Welford
+    moments must be rebuilt from the stored history when adaptation resumes."""
+    N, d = 16, 4
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 21, burnin_gen=3, n_cr_gen=2)
+    X = np.random.RandomState(4).normal(size=(N, d))
+    eng.set_state(X); ora.set_state(X)
+    for _ in range(2):
+        eng.begin_run(); eng.step(7); ora.run(7)       # 3 adapting generations, 4 without, twice
+        st = eng.stats()
+        np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-8)
+    np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-9, atol=1e-13)
+
+
+def test_no_history_mode():
+    N, d = 16, 4
+    eng = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=_gauss_params(d),
+                  seed=2, keep_history=False)
+    ora = R.OracleSampler(R.ALGO_DEMC, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 2)
+    X = np.random.RandomState(4).normal(size=(N, d))
+    eng.set_state(X); ora.set_state(X)
+    eng.begin_run(); eng.step(5); ora.run(5)
+    assert eng.history_rows() == 1
+    np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-10, atol=1e-14)
+
+
+def test_errors_are_reported_not_thrown():
+    from bipymc_amd._lib import BpmError
+    with pytest.raises(BpmError):
+        _engine(algo=R.ALGO_DEMC, n_chains=3, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=1)
+    with pytest.raises(BpmError):
+        _engine(algo=R.ALGO_DEMC, n_chains=8, dim=3, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=1)
+    eng = _engine(algo=R.ALGO_DEMC, n_chains=8, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=1)
+    with pytest.raises(BpmError, match="not initilized"):
+        eng.begin_run()
+    eng.init_chains(np.zeros(2), 1e-6)
+    with pytest.raises(BpmError):
+        eng.step(1)                 # begin_run first
+    with pytest.raises(BpmError):
+        eng.get_history(0, 5)
