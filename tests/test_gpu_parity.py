@@ -171,7 +171,7 @@ def _check_generation(eng, ora, N, d, dream, n_part):
     X1 = eng.get_state()
     np.testing.assert_allclose(X1, ora.X, rtol=RTOL_STEP, atol=ATOL_STEP)
     np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=RTOL_STEP, atol=1e-12)
-    assert not np.array_equal(X1, X0)
+    assert np.array_equal(X1, X0) == (not exp["accepted"].any())
     return float(np.mean(X1 == ora.X))
 
 
