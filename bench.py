@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- chain-updates/s of the DREAM hot path on the 100-D Gaussian (BASELINE.json config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one generation = every chain updated once (two half-generation kernel launches,
+plus, for N > 1, the RCCL all-gather of the state after each).  N = 1: DREAM, 100-D
+equicorrelated Gaussian, n_chains = 8192, del_pairs = 3 (BASELINE configs[1]).  N > 1: weak
+scaling, 8192 chains per GPU sharded by contiguous global-id blocks (configs[3] at N = 8), one
+process per GPU launched by torch.distributed.run.
+
+Timed region = steady state after burn-in (CR adaptation finished), history append included,
+inputs resident in HBM; bracketed by barrier + synchronize on both sides, max over ranks.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CHAINS_PER_GPU = 8192
+DIM = 100
+DEL_PAIRS = 3
+BURNIN_GEN = 200
+N_CR_GEN = 50
+# algorithmic bytes per chain-update, f64, steady state, history kept:
+# 8*d*(1 own read + 2P partner reads + 1 state write + 1 history append) + 16 (cached ln_like r/w)
+BYTES_PER_UPDATE = 8 * DIM * (2 * DEL_PAIRS + 3) + 16          # 7216
+HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (NumPy restatement of the reference algorithm, oracle/sampler_ref.py) timed on
+    this host on a bounded sample of the same workload: N=8192, d=100, steady state."""
+    from oracle import sampler_ref as R
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(DIM) + 1.0))
+    ora = R.OracleSampler(R.ALGO_DREAM, CHAINS_PER_GPU, DIM, R.TARGET_GAUSS_EQUICORR, params, 42,
+                          del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN)
+    X = np.random.RandomState(0).normal(size=(CHAINS_PER_GPU, DIM)) * np.sqrt(np.arange(DIM) + 1.0)
+    ora.set_state(X)
+    ora.run(1)                                                  # warm-up
+    t0 = time.perf_counter()
+    gens = 0
+    while True:
+        ora.run(1)
+        gens += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or gens >= 200:
+            break
+    return dict(value=CHAINS_PER_GPU * gens / el, unit="chain-updates/s", cores=1, kind="port",
+                sample="%d generations of DREAM d=100 n_chains=8192 (oracle/sampler_ref.py, NumPy, 1 process) in %.1f s; "
+                       "host has %d cores" % (gens, el, os.cpu_count() or 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-moments", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+
+    import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils.d100_gauss import Gauss_100D
+
+    n_chains = CHAINS_PER_GPU * world
+    target = Gauss_100D(rho=0.5, dim=DIM)
+    tid, tparams, _ = target._bpm_target_spec()
+    uid = None
+    if world > 1:
+        box = [HipEngine.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    eng = HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42,
+                    device=local_rank, rank=rank, world_size=world, nccl_uid=uid,
+                    del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
+    # over-dispersed start theta_0 + N(0, diag(i+1)): the default 1e-3 jitter needs
+    # thousands of generations to inflate to the target's scale
+    X0 = np.random.RandomState(1234).normal(size=(n_chains, DIM)) * np.sqrt(np.arange(DIM) + 1.0)
+    eng.set_state(X0)
+    total_gens = BURNIN_GEN + args.warmup + args.steps + 64
+    eng.reserve_history(1 + total_gens)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    eng.begin_run()
+    # ---- burn-in with CR adaptation: timed separately, never part of `value`
+    fence()
+    t0 = time.perf_counter()
+    eng.step(BURNIN_GEN)
+    fence()
+    burn_s = time.perf_counter() - t0
+    # ---- warm-up
+    eng.step(args.warmup)
+    fence()
+    # ---- timed region: exactly K generations
+    t0 = time.perf_counter()
+    eng.step(args.steps)
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    value = n_chains * args.steps / el
+
+    # ---- dominant kernel: per-launch duration from HIP event pairs on the sampler's stream
+    k_ms, n_launch = eng.step_profiled(32)
+    k_avg_ms = k_ms / n_launch
+    units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
+    achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9
+    fence()
+
+    extra = {}
+    if not args.no_moments:
+        # parity gate reported with the number: posterior moments of the post-burn-in rows vs the
+        # analytic ones (mean 0, var_i = i+1), from the on-device reduction over this rank's rows
+        n_burn = (1 + BURNIN_GEN + args.warmup) * n_chains
+        cnt, s1, s2, sh = eng.reduce_moments(n_burn)
+        if dist is not None:
+            pack = torch.tensor(np.concatenate([[cnt], s1, s2]), dtype=torch.float64, device="cuda")
+            dist.all_reduce(pack)
+            pack = pack.cpu().numpy()
+            cnt, s1, s2 = pack[0], pack[1:1 + DIM], pack[1 + DIM:]
+        mean = sh + s1 / cnt
+        var = s2 / cnt - (s1 / cnt) ** 2
+        sig2 = np.arange(DIM) + 1.0
+        st = eng.stats()
+        acc = st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
+        extra = dict(max_abs_mean_over_sigma=float(np.max(np.abs(mean) / np.sqrt(sig2))),
+                     var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)),
+                     var_ratio_mean=float(np.mean(var / sig2)), rows=int(cnt),
+                     acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
+
+    if rank == 0:
+        out = {
+            "metric": "chain-updates/sec", "value": value, "unit": "chain-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "DREAM, 100-D equicorrelated Gaussian (tests/test_100dgauss.py target), "
+                                   "n_chains=%d (%d per GPU), del_pairs=3, n_cr=3, steady state after %d burn-in "
+                                   "generations, history appended every generation" % (n_chains, CHAINS_PER_GPU, BURNIN_GEN),
+                       "n_chains": n_chains, "dim": DIM, "parallelism": "chains sharded x%d" % world,
+                       "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "phase_fused_kernel<GAUSS,64,2>", "bytes_per_unit": BYTES_PER_UPDATE,
+                         "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
+                         "launches_timed": n_launch},
+            "posterior": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,10 @@ SIGNATURES = {
     "bpm_begin_run": (C.c_int, [_H, _P(BpmRunOpts)]),
     "bpm_step": (C.c_int, [_H, C.c_int64]),
     "bpm_step_timed": (C.c_int, [_H, C.c_int64, _P(C.c_float)]),
+    "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
     "bpm_synchronize": (C.c_int, [_H]),
+    "bpm_set_history": (C.c_int, [_H, C.c_int64, _dp, _dp]),
+    "bpm_reduce_moments": (C.c_int, [_H, C.c_int64, _dp, _dp, _dp, _P(C.c_int64)]),
     "bpm_propose": (C.c_int, [_H, _dp, _ip, _ip]),
     "bpm_commit": (C.c_int, [_H, _dp]),
     "bpm_get_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),

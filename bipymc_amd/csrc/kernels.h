@@ -73,7 +73,8 @@ struct PhaseArgs {
     double* w_m2;          // [n_local * ld]
     const double* tparams; // target parameter block
     const double* cr_state;  // p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
-    unsigned long long* counters;  // accepted, rejected, nan
+    unsigned long long* counters;  // [2] = NaN Metropolis ratios (rare; the only atomic)
+    uint32_t* acc_count;   // [n_local] accepted updates of each local chain in this run (one writer per chain)
     double* prop_buf;      // host-callback path: [n_local * ld] proposals by work item
     double* aux_buf;       // host-callback path: [n_local * 2] (log_corr, ll_prop)
     int32_t* ids_buf;      // host-callback path: [n_local] global id by work item (-1 = inactive)
@@ -429,13 +430,11 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     alpha = fmax(0.0, alpha);                            // np.clip(np.min((1, .)), 0, 1); NaN stays NaN in NumPy
     const bool accepted = !is_nan && (u01_53(h1.x, h1.y) < alpha);
 
-    const unsigned long long lead = __ballot(active && q == 0);
-    const unsigned long long acc = __ballot(active && q == 0 && accepted);
-    const unsigned long long nn = __ballot(active && q == 0 && is_nan);
-    if (threadIdx.x == 0) {
-        atomicAdd(&a.counters[0], (unsigned long long)__popcll(acc));
-        atomicAdd(&a.counters[1], (unsigned long long)(__popcll(lead) - __popcll(acc)));
-        if (nn) atomicAdd(&a.counters[2], (unsigned long long)__popcll(nn));
+    // accept bookkeeping without same-address atomics (8192 of them serialise at ~12 ns each):
+    // every chain owns one counter, the host sums them (demc.py:143-150)
+    if (active && q == 0) {
+        if (accepted) a.acc_count[li] += 1u;
+        if (is_nan) atomicAdd(&a.counters[2], 1ull);
     }
     if (!active) return;
     double nv[DPL];
@@ -660,32 +659,50 @@ __global__ __launch_bounds__(WAVE) void eval_ll_kernel(const double* X, uint32_t
     if (active && q == 0) out[w] = ll;
 }
 
-// per-dimension sum / centred second moment over history rows (param_est, demc.py:235-248)
-__global__ void moments_sum_kernel(const double* hist, uint64_t row_stride, uint32_t n_local, uint32_t ld,
-                                   uint32_t dim, uint64_t g_lo, uint64_t g_hi, uint32_t first_chain_of_g_lo,
-                                   const double* shift, double* out_sum, double* out_sq) {
-    // one block per dimension; rows = (g, i) with g in [g_lo, g_hi), i >= first_chain_of_g_lo when g == g_lo
-    const uint32_t j = blockIdx.x;
-    if (j >= dim) return;
-    __shared__ double s_a[256], s_b[256];
-    const double sh = shift ? shift[j] : 0.0;
-    double sa = 0.0, sb = 0.0;
-    const uint64_t total = (g_hi - g_lo) * (uint64_t)n_local;
-    for (uint64_t r = threadIdx.x; r < total; r += blockDim.x) {
-        const uint64_t g = g_lo + r / n_local;
-        const uint32_t i = (uint32_t)(r % n_local);
-        if (g == g_lo && i < first_chain_of_g_lo) continue;
-        const double v = hist[g * row_stride + (uint64_t)i * ld + j] - sh;
-        sa += v;
-        sb += v * v;
-    }
-    s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+// param_est (demc.py:235-248) on the device: per-dimension sum and sum of squares (about `shift`)
+// over the flat history rows [m_lo, m_hi) of the (rows x ld) matrix H.  Deterministic two-stage
+// reduction: per-block partials, then a fixed-order sum over blocks.
+constexpr int MOM_THREADS = 256;
+__global__ __launch_bounds__(MOM_THREADS) void moments_partial_kernel(const double* H, uint64_t m_lo, uint64_t m_hi,
+                                                                    uint32_t ld, const double* shift, double* part) {
+    __shared__ double s_a[MOM_THREADS], s_b[MOM_THREADS];
+    const uint32_t cpb = ld <= MOM_THREADS ? ld : MOM_THREADS;   // columns per pass
+    const uint32_t rpi = MOM_THREADS / cpb;                      // rows per iteration
+    const uint64_t M = m_hi - m_lo;
+    const uint64_t rpb = (M + gridDim.x - 1) / gridDim.x;
+    const uint64_t b0 = m_lo + (uint64_t)blockIdx.x * rpb;
+    const uint64_t b1 = b0 + rpb < m_hi ? b0 + rpb : m_hi;
+    for (uint32_t c0 = 0; c0 < ld; c0 += cpb) {
+        const uint32_t j = c0 + threadIdx.x % cpb, r = threadIdx.x / cpb;
+        double sa = 0.0, sb = 0.0;
+        if (r < rpi && j < ld) {
+            const double sh = shift[j];
+            for (uint64_t m = b0 + r; m < b1; m += rpi) {
+                const double v = H[m * ld + j] - sh;
+                sa += v;
+                sb += v * v;
+            }
+        }
+        s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
+        __syncthreads();
+        if (r == 0 && j < ld) {
+            for (uint32_t rr = 1; rr < rpi; ++rr) { sa += s_a[rr * cpb + threadIdx.x]; sb += s_b[rr * cpb + threadIdx.x]; }
+            part[((uint64_t)blockIdx.x * 2 + 0) * ld + j] = sa;
+            part[((uint64_t)blockIdx.x * 2 + 1) * ld + j] = sb;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out_sum[j] = s_a[0]; out_sq[j] = s_b[0]; }
+}
+__global__ void moments_final_kernel(const double* part, uint32_t nblocks, uint32_t ld, double* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    double sa = 0.0, sb = 0.0;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        sa += part[((uint64_t)b * 2 + 0) * ld + j];
+        sb += part[((uint64_t)b * 2 + 1) * ld + j];
+    }
+    out[j] = sa;
+    out[ld + j] = sb;
 }
 
 }  // namespace bpm

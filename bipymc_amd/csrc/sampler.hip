@@ -146,7 +146,9 @@ struct bpm_sampler {
     int64_t w_rows = 0;        // history rows folded into the Welford moments
     double* tparams = nullptr;
     double* cr_state = nullptr;            // p_cr | delta_m | n_cr_updates (MAX_CR each)
-    unsigned long long* counters = nullptr;  // device: accepted, rejected, nan
+    unsigned long long* counters = nullptr;  // device: [2] = NaN ratios
+    uint32_t* acc_count = nullptr;           // device: accepted updates per local chain, this run
+    int64_t gens_this_run_local = 0;
     double* prop_buf = nullptr;
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
@@ -161,6 +163,7 @@ struct bpm_sampler {
     bool run_open = false;
     int64_t k_gen = 0, t_abs = 0;
     int phase = 0;               // host-callback: next half generation to propose (0/1)
+    int64_t phase_a_updates = 0; // host-callback: local chains already updated in an open generation
     bool proposed = false;
     bool state_set = false;
     int64_t n_outlier_resets = 0;
@@ -255,16 +258,16 @@ extern "C" int bpm_get_unique_id(char out[BPM_UID_BYTES]) {
 
 extern "C" int bpm_destroy(bpm_handle_t s) {
     if (!s) return 0;
-    hipSetDevice(s->cfg.device);
-    if (s->stream) hipStreamSynchronize(s->stream);
+    (void)hipSetDevice(s->cfg.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters,
+    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (s->ev0) hipEventDestroy(s->ev0);
-    if (s->ev1) hipEventDestroy(s->ev1);
-    if (s->stream) hipStreamDestroy(s->stream);
+        if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return 0;
 }
@@ -347,6 +350,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipStreamSynchronize(s->stream));
     }
     CKD(dev_alloc(&s->counters, 4));
+    CKD(dev_alloc(&s->acc_count, s->n_local));
+    HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
     s->scratch_doubles = 4 * (size_t)s->ld + 64;
     CKD(dev_alloc(&s->scratch, s->scratch_doubles));
@@ -453,8 +458,8 @@ extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
     s->opts = d;
     s->k_gen = 0;                                                                    // demc.py:78
     s->phase = 0;
-    unsigned long long init[4] = {0ull, 1ull, 0ull, 0ull};                            // demc.py:67-68
-    HIPCK(hipMemcpyAsync(s->counters, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
+    HIPCK(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));     // demc.py:67
     HIPCK(hipStreamSynchronize(s->stream));
     s->run_open = true;
     return 0;
@@ -506,6 +511,7 @@ static int prepare_generation(bpm_sampler* s) {
         a.tparams = s->tparams;
         a.cr_state = s->cr_state;
         a.counters = s->counters;
+        a.acc_count = s->acc_count;
         a.prop_buf = s->prop_buf;
         a.aux_buf = s->aux_buf;
         a.ids_buf = s->ids_buf;
@@ -594,6 +600,125 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms)
     return 0;
 }
 
+
+// Same generations as bpm_step, with a HIP event pair on the sampler's stream around every
+// update-kernel launch: returns the summed kernel time and the number of launches, i.e. the
+// per-launch duration bench.py prices the roofline with (rocprofv3 --kernel-trace gives the same
+// figure offline).
+extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->run_open) return fail("bpm_step_profiled: call bpm_begin_run first");
+    if (s->cfg.target_id == BPM_TARGET_HOST_CALLBACK) return fail("bpm_step_profiled: device targets only");
+    if (n_gens <= 0 || n_gens > 4096) return fail("bpm_step_profiled: 1 <= n_gens <= 4096");
+    if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    std::vector<hipEvent_t> ev((size_t)n_gens * 4);
+    for (auto& e : ev) HIPCK(hipEventCreate(&e));
+    PhaseLaunch fn = nullptr;
+    switch (s->cfg.target_id) {
+        case BPM_TARGET_GAUSS_EQUICORR: fn = g_fused_gauss[s->shape.idx]; break;
+        case BPM_TARGET_MIXTURE_PAIRS: fn = g_fused_mixture[s->shape.idx]; break;
+        default: fn = launch_fused<TARGET_BANANA, 1, 2>; break;
+    }
+    for (int64_t g = 0; g < n_gens; ++g) {
+        CK(prepare_generation(s));
+        for (int ph = 0; ph < 2; ++ph) {
+            HIPCK(hipEventRecord(ev[(size_t)g * 4 + 2 * ph], s->stream));
+            if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
+            HIPCK(hipEventRecord(ev[(size_t)g * 4 + 2 * ph + 1], s->stream));
+            CK(allgather_state(s));
+        }
+        HIPCK(hipGetLastError());
+        CK(finish_generation(s));
+    }
+    HIPCK(hipStreamSynchronize(s->stream));
+    double tot = 0.0;
+    for (int64_t i = 0; i < 2 * n_gens; ++i) {
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]));
+        tot += ms;
+    }
+    for (auto& e : ev) HIPCK(hipEventDestroy(e));
+    if (kernel_ms_sum) *kernel_ms_sum = tot;
+    if (n_launches) *n_launches = 2 * n_gens;
+    return 0;
+}
+
+// Warm start (demc.py:46-51,217-233): install `rows` history rows of this rank's chains
+// (hist_local: rows x n_local x dim) and the full current state X (N x dim, = last row of every chain).
+extern "C" int bpm_set_history(bpm_handle_t s, int64_t rows, const double* hist_local, const double* X) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (rows < 1 || !hist_local || !X) return fail("bpm_set_history: bad argument");
+    if (!s->cfg.keep_history && rows > 1) return fail("bpm_set_history: sampler keeps no history");
+    CK(bpm_set_state(s, X));
+    if (rows > 1) {
+        CK(ensure_history(s, rows));
+        HIPCK(hipMemsetAsync(s->hist, 0, (size_t)rows * s->n_local * s->ld * sizeof(double), s->stream));
+        HIPCK(hipMemcpy2DAsync(s->hist, s->ld * sizeof(double), hist_local, s->dim * sizeof(double), s->dim * sizeof(double),
+                               (size_t)rows * s->n_local, hipMemcpyHostToDevice, s->stream));
+        // ln_like of the old rows is not stored in the reference's checkpoint: recompute (device targets) or NaN
+        if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) {
+            const uint32_t n = (uint32_t)((size_t)rows * s->n_local);
+            switch (s->cfg.target_id) {
+                case BPM_TARGET_GAUSS_EQUICORR: g_eval_gauss[s->shape.idx](s->hist, n, s->ld, s->dim, s->tparams, s->llhist, s->stream); break;
+                case BPM_TARGET_MIXTURE_PAIRS: g_eval_mixture[s->shape.idx](s->hist, n, s->ld, s->dim, s->tparams, s->llhist, s->stream); break;
+                default: launch_eval<TARGET_BANANA, 1, 2>(s->hist, n, s->ld, s->dim, s->tparams, s->llhist, s->stream); break;
+            }
+            HIPCK(hipGetLastError());
+        } else {
+            std::vector<double> nanv((size_t)(rows - 1) * s->n_local, std::nan(""));
+            HIPCK(hipMemcpyAsync(s->llhist, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+            HIPCK(hipStreamSynchronize(s->stream));
+            HIPCK(hipMemcpyAsync(s->llhist + (size_t)(rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        }
+        s->hist_rows = rows;
+        s->rows_logical = rows;
+        s->w_rows = 0;      // moments are rebuilt from the rows when adaptation next needs them
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    return 0;
+}
+
+// param_est (demc.py:235-248) without moving the history: raw moments of this rank's part of the
+// super chain (row g*N + i = chain i at generation g) for rows >= n_burn:
+// count, sum_j (x - shift_j), sum_j (x - shift_j)^2, shift_j (= chain 0's current state, identical
+// on every rank).  Ranks combine the three and finish mean / std(ddof=0) on the host.
+extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, double* sumsq, double* shift,
+                                  int64_t* count) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!sum || !sumsq || !shift || !count) return fail("bpm_reduce_moments: null argument");
+    if (n_burn < 0) n_burn = 0;
+    const int64_t g0 = n_burn / s->N;
+    int64_t first = n_burn % s->N - (int64_t)s->lo;      // first local chain of generation g0 that counts
+    first = std::max<int64_t>(0, std::min<int64_t>(first, s->n_local));
+    const uint64_t m_lo = (uint64_t)std::min<int64_t>(g0, s->hist_rows) * s->n_local + (g0 < s->hist_rows ? (uint64_t)first : 0);
+    const uint64_t m_hi = (uint64_t)s->hist_rows * s->n_local;
+    std::vector<double> h(3 * (size_t)s->ld, 0.0);
+    HIPCK(hipMemcpyAsync(h.data() + 2 * s->ld, s->G, s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    *count = (int64_t)(m_hi > m_lo ? m_hi - m_lo : 0);
+    if (m_hi > m_lo) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(2048, (m_hi - m_lo + 63) / 64);
+        double* part = nullptr;
+        double* out = nullptr;
+        CK(dev_alloc(&part, (size_t)nb * 2 * s->ld));
+        CK(dev_alloc(&out, 2 * (size_t)s->ld));
+        hipLaunchKernelGGL(moments_partial_kernel, dim3(nb), dim3(MOM_THREADS), 0, s->stream, s->hist, m_lo, m_hi, s->ld,
+                           s->G, part);
+        hipLaunchKernelGGL(moments_final_kernel, dim3((s->ld + 63) / 64), dim3(64), 0, s->stream, part, nb, s->ld, out);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(h.data(), out, 2 * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIPCK(hipStreamSynchronize(s->stream));
+        HIPCK(hipFree(part));
+        HIPCK(hipFree(out));
+    } else {
+        HIPCK(hipStreamSynchronize(s->stream));
+    }
+    for (uint32_t j = 0; j < s->dim; ++j) { sum[j] = h[j]; sumsq[j] = h[s->ld + j]; shift[j] = h[2 * s->ld + j]; }
+    return 0;
+}
+
 extern "C" int bpm_synchronize(bpm_handle_t s) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -655,6 +780,7 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
     s->proposed = false;
     if (s->phase == 0) {
         s->phase = 1;
+        s->phase_a_updates = (int64_t)n;
     } else {
         s->phase = 0;
         CK(finish_generation(s));
@@ -698,12 +824,18 @@ extern "C" int bpm_get_stats(bpm_handle_t s, bpm_stats_t* out) {
     if (!out) return fail("bpm_get_stats: null argument");
     unsigned long long c[4];
     double cr[3 * MAX_CR];
+    std::vector<uint32_t> acc(s->n_local);
     HIPCK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipMemcpyAsync(cr, s->cr_state, sizeof(cr), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(acc.data(), s->acc_count, s->n_local * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     std::memset(out, 0, sizeof(*out));
-    out->local_n_accepted = (int64_t)c[0];
-    out->local_n_rejected = (int64_t)c[1];
+    int64_t n_acc = 0;
+    for (uint32_t v : acc) n_acc += v;
+    // every local chain is updated exactly once per generation (it is in exactly one of the two pools)
+    const int64_t n_upd = s->k_gen * (int64_t)s->n_local + (s->phase == 1 ? s->phase_a_updates : 0);
+    out->local_n_accepted = n_acc;                       // demc.py:67,190
+    out->local_n_rejected = 1 + n_upd - n_acc;           // demc.py:68,193: starts at 1
     out->n_nan_alpha = (int64_t)c[2];
     out->k_gen = s->k_gen;
     out->t_abs = s->t_abs;
@@ -750,7 +882,7 @@ extern "C" int bpm_eval_loglike(bpm_handle_t s, const double* X, int32_t n, doub
         case BPM_TARGET_GAUSS_EQUICORR: g_eval_gauss[s->shape.idx](dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
         case BPM_TARGET_MIXTURE_PAIRS: g_eval_mixture[s->shape.idx](dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
         case BPM_TARGET_BANANA_2D: launch_eval<TARGET_BANANA, 1, 2>(dX, n, s->ld, s->dim, s->tparams, dO, s->stream); break;
-        default: hipFree(dX); hipFree(dO); return fail("bpm_eval_loglike: host-callback target has no device ln_like");
+        default: (void)hipFree(dX); (void)hipFree(dO); return fail("bpm_eval_loglike: host-callback target has no device ln_like");
     }
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(out, dO, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));

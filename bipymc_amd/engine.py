@@ -93,6 +93,13 @@ class HipEngine(object):
         L.check(self.lib.bpm_get_state(self._h, _dptr(X)))
         return X
 
+    def set_history(self, hist_local, X):
+        hist_local = np.ascontiguousarray(hist_local, dtype=np.float64)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert hist_local.ndim == 3 and hist_local.shape[1:] == (self.n_local, self.dim)
+        assert X.shape == (self.n_chains, self.dim)
+        L.check(self.lib.bpm_set_history(self._h, hist_local.shape[0], _dptr(hist_local), _dptr(X)))
+
     def set_loglike(self, ll_local):
         ll = np.ascontiguousarray(ll_local, dtype=np.float64)
         assert ll.shape == (self.n_local,)
@@ -120,6 +127,13 @@ class HipEngine(object):
         ms = C.c_float(0.0)
         L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms)))
         return float(ms.value)
+
+    def step_profiled(self, n_gens):
+        """-> (summed update-kernel time in ms, number of launches)"""
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        L.check(self.lib.bpm_step_profiled(self._h, int(n_gens), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def synchronize(self):
         L.check(self.lib.bpm_synchronize(self._h))
@@ -166,6 +180,13 @@ class HipEngine(object):
         out = np.empty((max(0, g_hi - g_lo), self.n_local), dtype=np.float64)
         L.check(self.lib.bpm_get_loglike_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
         return out
+
+    def reduce_moments(self, n_burn=0):
+        """-> (count, S1, S2, shift): raw moments of the local super-chain rows >= n_burn."""
+        s1 = np.empty(self.dim); s2 = np.empty(self.dim); sh = np.empty(self.dim)
+        n = C.c_int64(0)
+        L.check(self.lib.bpm_reduce_moments(self._h, int(n_burn), _dptr(s1), _dptr(s2), _dptr(sh), C.byref(n)))
+        return int(n.value), s1, s2, sh
 
     def set_adapt_state(self, p_cr=None, delta_m=None, n_cr_updates=None, t_abs=-1):
         keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None

@@ -120,6 +120,9 @@ int bpm_init_chains(bpm_handle_t h, const double* theta_0, const double* varepsi
 /* Set the (N, dim) state matrix in global-id order (warm start, demc.py:46-51).  History := [X]. */
 int bpm_set_state(bpm_handle_t h, const double* X);
 int bpm_get_state(bpm_handle_t h, double* X);
+/* Warm start with full histories (demc.py:46-51,217-233; chain.py:82-93): hist_local is
+ * (rows, n_local, dim) for this rank's chains, X the (N, dim) current state of all chains. */
+int bpm_set_history(bpm_handle_t h, int64_t rows, const double* hist_local, const double* X);
 /* cached ln_like of the current state: all N values (host-callback targets must set the local ones). */
 int bpm_set_loglike(bpm_handle_t h, const double* ll_local); /* n_local values */
 int bpm_get_loglike(bpm_handle_t h, double* ll_local);
@@ -130,6 +133,9 @@ int bpm_begin_run(bpm_handle_t h, const bpm_run_opts_t* opts);
 int bpm_step(bpm_handle_t h, int64_t n_gens);
 /* same, bracketed by HIP events on the sampler's stream; returns elapsed device time. */
 int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms);
+/* same again with a HIP event pair around every update-kernel launch: summed kernel time and launch
+ * count (bench.py prices the roofline with it). n_gens <= 4096. */
+int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);
 int bpm_synchronize(bpm_handle_t h);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
@@ -144,6 +150,11 @@ int bpm_commit(bpm_handle_t h, const double* ll_prop);
 int bpm_get_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);
 int bpm_get_loglike_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);
 int bpm_reserve_history(bpm_handle_t h, int64_t total_rows);
+/* param_est (demc.py:235-248) without moving the history: for this rank's rows of the interleaved
+ * super chain (row g*N + i = chain i at generation g) with row index >= n_burn, returns count,
+ * sum_j (x - shift_j), sum_j (x - shift_j)^2 and shift_j (length dim each; shift is identical on every
+ * rank).  mean_j = shift_j + S1/n, var_j = S2/n - (S1/n)^2 after summing S1, S2, n over ranks. */
+int bpm_reduce_moments(bpm_handle_t h, int64_t n_burn, double* sum, double* sumsq, double* shift, int64_t* count);
 int bpm_get_stats(bpm_handle_t h, bpm_stats_t* out);
 /* checkpoint what the reference forgets: p_cr, delta_m, n_cr_updates, t_abs */
 int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_m, const double* n_cr_updates,
