@@ -45,10 +45,13 @@ struct Layout {
     uint32_t ld;       // row stride in doubles (dim rounded up to even: rows stay 16-byte aligned)
     uint32_t dim;
     uint32_t world;
+    uint32_t magic;    // floor(2^32 / n_local) + 1 (c < 2^31)
 };
 
 __device__ __forceinline__ void split_id(const Layout& L, uint32_t c, uint32_t& r, uint32_t& i) {
-    r = (L.world == 1) ? 0u : c / L.n_local;
+    // r = c / n_local without a hardware divide: magic = floor(2^32 / n_local) + 1 over-estimates by at most one
+    r = __umulhi(c, L.magic);
+    r -= (r * L.n_local > c) ? 1u : 0u;
     i = c - r * L.n_local;
 }
 __device__ __forceinline__ double* row_ptr(const Layout& L, uint32_t c) {
@@ -203,6 +206,7 @@ struct Work {
     double delta;      // CR statistic (dream.py:130)
     double log_corr;   // snooker Jacobian term
     double gamma;
+    uint32_t acc_hi, acc_lo;   // words of the accept uniform (HDR1)
     int cr_idx, d_prime, jump, snk;
     uint32_t maskbits;
 };
@@ -227,76 +231,122 @@ __device__ __forceinline__ void store_row(double* row, int q, uint32_t ld, const
     }
 }
 
+// Two standard normals from two words in float32 on the hardware transcendental units
+// (v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32; the trig units take revolutions, so
+// cos(2 pi u2) needs no multiply and no range reduction).  Used for the per-generation jitter
+// e_n ~ N(0, eps^2), eps ~ 1e-12: float32 resolution is ~1e-19 absolute, below the state's ulp.
+__device__ __forceinline__ void box_muller_pair_f32(uint32_t w1, uint32_t w2, double& n0, double& n1) {
+    const float u1 = ((float)w1 + 1.0f) * 2.3283064365386963e-10f;
+    const float u2 = (float)w2 * 2.3283064365386963e-10f;
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(u1));
+    n0 = (double)(r * __builtin_amdgcn_cosf(u2));
+    n1 = (double)(r * __builtin_amdgcn_sinf(u2));
+}
+
+// Partner chains of chain c (pool positions -> global ids through the generation's bijection).
+// FAST (one wavefront per chain, compile-time pair count): c is wavefront-uniform, so the pair
+// draws and the Feistel walks run on the scalar unit and the ids live in SGPRs.  Otherwise the
+// lanes of the subgroup resolve them in parallel and hand them over through LDS.
+template <int LPC, int NPART_CT>
+struct Partners {
+    uint32_t r[NPART_CT > 0 ? NPART_CT : 1];
+    const uint32_t* lds;
+    __device__ __forceinline__ uint32_t get(int i) const { return NPART_CT > 0 ? r[i] : lds[i]; }
+};
+
+__device__ __forceinline__ uint32_t partner_pos(const PhaseArgs& a, uint32_t c, uint32_t idx, uint32_t n_pair_idx) {
+    if (idx < n_pair_idx) {
+        const uint32_t p = idx >> 1;
+        const u32x4 wb = chain_block(a.seed, c, a.t, SLOT_PAIR0 + (p >> 1));
+        uint32_t ia, ib;
+        distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
+        return (idx & 1) ? ib : ia;
+    }
+    const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
+    uint32_t iz, i1, i2;
+    distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
+    const uint32_t s = idx - n_pair_idx;
+    return s == 0 ? iz : (s == 1 ? i1 : i2);
+}
+
 // Build the proposal of chain c (dream.py:43-93 / demc.py:161-182).
-template <int LPC, int DPL>
+// ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
+template <int ALGO, int LPC, int DPL, int NP>
 __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
                                               uint32_t* s_part, Work<DPL>& wk) {
+    constexpr bool DREAM = ALGO == ALGO_DREAM;
+#ifndef BPM_SCALAR_PARTNERS
+#define BPM_SCALAR_PARTNERS 0   // measured: 19.8 us/generation with lane-parallel partners vs 25.9 all-scalar (cfg2)
+#endif
+    constexpr bool FAST = (LPC == WAVE) && (NP > 0) && (BPM_SCALAR_PARTNERS != 0);
     const uint32_t dim = a.L.dim, ld = a.L.ld;
-    const bool dream = a.algo == ALGO_DREAM;
+    const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
+    wk.acc_hi = h1.x; wk.acc_lo = h1.y;
 
-    // ---- partner chains: lanes of the subgroup resolve them in parallel, hand over through LDS
-    const bool snk_possible = !dream && a.p_snooker > 0.0 && a.M >= 3;
-    const uint32_t npart = 2 * a.P + (snk_possible ? 3u : 0u);
-    for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC) {
-        uint32_t pos;
-        if (idx < 2 * a.P) {
-            const uint32_t p = idx >> 1;
-            const u32x4 wb = chain_block(a.seed, c, a.t, SLOT_PAIR0 + (p >> 1));
-            uint32_t ia, ib;
-            distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
-            pos = (idx & 1) ? ib : ia;
-        } else {
-            const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
-            uint32_t iz, i1, i2;
-            distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
-            const uint32_t s = idx - 2 * a.P;
-            pos = s == 0 ? iz : (s == 1 ? i1 : i2);
-        }
-        s_part[cw * MAX_PARTNERS + idx] = perm_fwd(a.pool_off + pos, a.pk);
+    const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
+    const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
+    Partners<LPC, FAST ? 2 * NP : 0> part;
+    part.lds = s_part + cw * MAX_PARTNERS;
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) part.r[i] = perm_fwd(a.pool_off + partner_pos(a, c, (uint32_t)i, 2u * NP), a.pk);
     }
-    __syncthreads();
-    const uint32_t* part = s_part + cw * MAX_PARTNERS;
+    if (!FAST || snk_possible) {
+#pragma unroll 1
+        for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
+            s_part[cw * MAX_PARTNERS + idx] = perm_fwd(a.pool_off + partner_pos(a, c, idx, 2 * P), a.pk);
+        __syncthreads();
+    }
 
-    // ---- own row and per-dimension draws
+    // ---- own row and per-pair draws: one Philox block per coordinate pair
     load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
     double eps_n[DPL], eps_u[DPL];
     uint32_t maskbits = 0;
     wk.cr_idx = -1; wk.d_prime = (int)dim; wk.jump = 0; wk.snk = 0; wk.delta = 0.0; wk.log_corr = 0.0;
-    double cr = 1.0;
-    if (dream) {
+    uint32_t thr = 65536u;
+    if (DREAM) {
         // cr ~ Categorical(CR, p_cr)  (dream.py:51)
         const double uc = u01_32(h0.x);
         double cum = 0.0;
         int idx = (int)a.n_cr - 1;
         bool found = false;
+#pragma unroll 1
         for (int m = 0; m < (int)a.n_cr; ++m) {          // first m with uc < cumsum(p_cr)[m]
             cum += a.cr_state[m];
             if (!found && uc < cum) { idx = m; found = true; }
         }
         wk.cr_idx = idx;
-        cr = (double)(idx + 1) / (double)a.n_cr;     // dream.py:113
+        const double cr = (double)(idx + 1) / (double)a.n_cr;     // dream.py:113
+        thr = (uint32_t)floor(cr * 65536.0);                       // k 2^-16 <= cr  <=>  k <= thr
     }
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < DPL / 2; ++u) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t j = 2u * (uint32_t)(q + u * LPC) + e;
-            const int s = 2 * u + e;
-            eps_n[s] = 0.0; eps_u[s] = 0.0;
-            if (j < dim) {
-                const u32x4 wj = chain_block(a.seed, c, a.t, SLOT_DIM0 + j);
-                if (a.epsilon > 0.0) eps_n[s] = a.epsilon * box_muller(wj.z, wj.w);       // util.py:5-16
-                if (dream) {
-                    if (a.u_epsilon > 0.0) eps_u[s] = -a.u_epsilon + (2.0 * a.u_epsilon) * u01_32(wj.y);  // util.py:18-28
-                    if (u01_32(wj.x) <= cr) { maskbits |= 1u << s; ++cnt; }               // dream.py:52-53
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        const uint32_t j0 = 2u * pi;
+        eps_n[2 * u] = 0.0; eps_n[2 * u + 1] = 0.0; eps_u[2 * u] = 0.0; eps_u[2 * u + 1] = 0.0;
+        if (j0 < dim) {
+            const u32x4 wj = chain_block(a.seed, c, a.t, SLOT_DIM0 + pi);
+            const bool two = j0 + 1 < dim;
+            if (a.epsilon > 0.0) {                                   // util.py:5-16
+                double n0, n1;
+                box_muller_pair_f32(wj.z, wj.w, n0, n1);
+                eps_n[2 * u] = a.epsilon * n0;
+                if (two) eps_n[2 * u + 1] = a.epsilon * n1;
+            }
+            if (DREAM) {
+                if (a.u_epsilon > 0.0) {                             // util.py:18-28
+                    eps_u[2 * u] = -a.u_epsilon + (2.0 * a.u_epsilon) * (((double)(wj.y >> 16) + 0.5) * 1.52587890625e-05);
+                    if (two) eps_u[2 * u + 1] = -a.u_epsilon + (2.0 * a.u_epsilon) * (((double)(wj.y & 0xFFFFu) + 0.5) * 1.52587890625e-05);
                 }
+                if ((wj.x >> 16) <= thr) { maskbits |= 1u << (2 * u); ++cnt; }              // dream.py:52-53
+                if (two && (wj.x & 0xFFFFu) <= thr) { maskbits |= 1u << (2 * u + 1); ++cnt; }
             }
         }
     }
-    if (dream) {
+    if (DREAM) {
         cnt = gsum_i<LPC>(cnt);
         if (cnt == 0) {                                // dream.py:55-57: force one dimension
             const uint32_t f = mulhi32(h0.y, dim);
@@ -311,22 +361,38 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     }
     wk.maskbits = maskbits;
 
-    if (dream) {
+    if (DREAM) {
         // gamma (dream.py:61,77-80)
-        const double gamma_base = a.gamma_scale * 2.38 / sqrt(2.0 * (double)a.P * (double)cnt);
+        const double gamma_base = a.gamma_scale * 2.38 / sqrt(2.0 * (double)P * (double)cnt);
         double gamma = gamma_base;
         if (a.k % 5 == 0 && !(u01_32(h0.z) < 0.2)) { gamma = 1.0; wk.jump = 1; }
         wk.gamma = gamma;
         // sum over pairs of (A_p - B_p)  (dream.py:65-68,85-86), p = 0 first
         double sum[DPL];
+        if (NP > 0) {
+            double ra[NP > 0 ? NP : 1][DPL], rb[NP > 0 ? NP : 1][DPL];
 #pragma unroll
-        for (int s = 0; s < DPL; ++s) sum[s] = 0.0;
-        for (uint32_t p = 0; p < a.P; ++p) {
-            double ra[DPL], rb[DPL];
-            load_row<LPC, DPL>(row_ptr(a.L, part[2 * p]), q, ld, ra);
-            load_row<LPC, DPL>(row_ptr(a.L, part[2 * p + 1]), q, ld, rb);
+            for (int p = 0; p < NP; ++p) {             // all 2 NP row loads in flight together
+                load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p)), q, ld, ra[p]);
+                load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p + 1)), q, ld, rb[p]);
+            }
 #pragma unroll
-            for (int s = 0; s < DPL; ++s) sum[s] = (p == 0) ? (ra[s] - rb[s]) : (sum[s] + (ra[s] - rb[s]));
+            for (int s = 0; s < DPL; ++s) {
+                sum[s] = ra[0][s] - rb[0][s];
+#pragma unroll
+                for (int p = 1; p < NP; ++p) sum[s] = sum[s] + (ra[p][s] - rb[p][s]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) sum[s] = 0.0;
+#pragma unroll 1
+            for (uint32_t p = 0; p < P; ++p) {
+                double ra[DPL], rb[DPL];
+                load_row<LPC, DPL>(row_ptr(a.L, part.lds[2 * p]), q, ld, ra);
+                load_row<LPC, DPL>(row_ptr(a.L, part.lds[2 * p + 1]), q, ld, rb);
+#pragma unroll
+                for (int s = 0; s < DPL; ++s) sum[s] = (p == 0) ? (ra[s] - rb[s]) : (sum[s] + (ra[s] - rb[s]));
+            }
         }
         // proposal (dream.py:85-89)
 #pragma unroll
@@ -358,8 +424,10 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (a.k % 10 == 0 && !(u01_32(h0.z) < 0.1)) { gamma = 1.0; wk.jump = 1; }
         wk.gamma = gamma;
         double ra[DPL], rb[DPL];
-        load_row<LPC, DPL>(row_ptr(a.L, part[0]), q, ld, ra);
-        load_row<LPC, DPL>(row_ptr(a.L, part[1]), q, ld, rb);
+        const uint32_t ca = (FAST && !snk_possible) ? part.get(0) : part.lds[0];
+        const uint32_t cb = (FAST && !snk_possible) ? part.get(1) : part.lds[1];
+        load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
+        load_row<LPC, DPL>(row_ptr(a.L, cb), q, ld, rb);
 #pragma unroll
         for (int s = 0; s < DPL; ++s) {
             double pv = gamma * (ra[s] - rb[s]);
@@ -370,9 +438,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (snk_possible && u01_32(h0.w) < a.p_snooker) {
             // snooker update (ter Braak & Vrugt 2008) -- extension, absent from the reference
             double rz[DPL], r1[DPL], r2[DPL];
-            load_row<LPC, DPL>(row_ptr(a.L, part[2]), q, ld, rz);
-            load_row<LPC, DPL>(row_ptr(a.L, part[3]), q, ld, r1);
-            load_row<LPC, DPL>(row_ptr(a.L, part[4]), q, ld, r2);
+            load_row<LPC, DPL>(row_ptr(a.L, part.lds[2]), q, ld, rz);
+            load_row<LPC, DPL>(row_ptr(a.L, part.lds[3]), q, ld, r1);
+            load_row<LPC, DPL>(row_ptr(a.L, part.lds[4]), q, ld, r2);
             double n2 = 0.0, dot = 0.0;
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -402,41 +470,47 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             }
         }
     }
-    if (a.trace_i32 && active && q == 0) {
-        int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
-        tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
-        for (uint32_t i = 0; i < MAX_PARTNERS; ++i) tr[5 + i] = i < npart ? (int32_t)part[i] : -1;
-    }
-    if (a.trace_mask && active) {
+    if (a.trace_i32 && active) {
+        if (q == 0) {
+            int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
+            tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
+            if (FAST) {
 #pragma unroll
-        for (int s = 0; s < DPL; ++s) {
-            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
-            if (j < dim) a.trace_mask[(uint64_t)(c - a.lo) * dim + j] = (uint8_t)((maskbits >> s) & 1u);
+                for (int i = 0; i < 2 * NP; ++i) tr[5 + i] = (int32_t)part.get(i);
+            }
+#pragma unroll 1
+            for (uint32_t i = (FAST && !snk_possible) ? npart : 0u; i < MAX_PARTNERS; ++i)
+                tr[5 + i] = i < npart ? (int32_t)part.lds[i] : -1;
+        }
+        if (a.trace_mask) {
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) {
+                const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+                if (j < dim) a.trace_mask[(uint64_t)(c - a.lo) * dim + j] = (uint8_t)((maskbits >> s) & 1u);
+            }
         }
     }
 }
 
 // Metropolis test (samplers.py:328-336), append (chain.py:51-54), Welford moments, CR outputs.
-template <int LPC, int DPL>
+template <int ALGO, int LPC, int DPL>
 __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bool active, int q,
                                               const Work<DPL>& wk, double ll_prop) {
-    const uint32_t ld = a.L.ld, dim = a.L.dim;
+    const uint32_t ld = a.L.ld;
     const uint32_t li = c - a.lo;
-    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
     const double ll_cur = a.ll[li];
     double alpha = exp((ll_prop + wk.log_corr) - ll_cur);
     const bool is_nan = alpha != alpha;
     alpha = fmin(1.0, alpha);
     alpha = fmax(0.0, alpha);                            // np.clip(np.min((1, .)), 0, 1); NaN stays NaN in NumPy
-    const bool accepted = !is_nan && (u01_53(h1.x, h1.y) < alpha);
-
+    const bool accepted = !is_nan && (u01_53(wk.acc_hi, wk.acc_lo) < alpha);
+    if (!active) return;
     // accept bookkeeping without same-address atomics (8192 of them serialise at ~12 ns each):
     // every chain owns one counter, the host sums them (demc.py:143-150)
-    if (active && q == 0) {
+    if (q == 0) {
         if (accepted) a.acc_count[li] += 1u;
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
     }
-    if (!active) return;
     double nv[DPL];
 #pragma unroll
     for (int s = 0; s < DPL; ++s) nv[s] = accepted ? wk.p[s] : wk.x[s];
@@ -447,7 +521,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     }
     if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint64_t)li * ld, q, ld, nv);
     if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
-    if (a.algo == ALGO_DREAM) {
+    if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
             double mean[DPL], m2[DPL];
@@ -474,7 +548,6 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
         tf[0] = alpha; tf[1] = ll_prop; tf[2] = wk.delta; tf[3] = wk.gamma;
     }
-    (void)dim;
 }
 
 // Which chain does this subgroup update?  mode 0: work item = position in shuffle order (all items
@@ -491,40 +564,42 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
     return active;
 }
 
-template <int TARGET, int LPC, int DPL>
+template <int ALGO, int TARGET, int LPC, int DPL, int NP>
 __global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
     __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
-    const int cw = lane / LPC, q = lane % LPC;
+    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
     const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
     uint32_t c;
     const bool active = resolve_chain(a, w, c);
     if (LPC == WAVE && !active) return;          // whole wavefront idle
+    if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     Work<DPL> wk;
-    make_proposal<LPC, DPL>(a, c, active, q, cw, s_part, wk);
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk);
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, a.tparams);
-    finish_update<LPC, DPL>(a, c, active, q, wk, ll_prop);
+    finish_update<ALGO, LPC, DPL>(a, c, active, q, wk, ll_prop);
 }
 
 // Host-callback ln_like_fn: proposals out ...
-template <int LPC, int DPL>
+template <int ALGO, int LPC, int DPL>
 __global__ __launch_bounds__(WAVE) void phase_propose_kernel(const PhaseArgs a) {
     __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
-    const int cw = lane / LPC, q = lane % LPC;
+    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
     const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
     uint32_t c;
     const bool active = resolve_chain(a, w, c);
     if (w < a.n_items && q == 0) a.ids_buf[w] = active ? (int32_t)c : -1;
     if (LPC == WAVE && !active) return;
+    if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);
     Work<DPL> wk;
-    make_proposal<LPC, DPL>(a, c, active, q, cw, s_part, wk);
+    make_proposal<ALGO, LPC, DPL, 0>(a, c, active, q, cw, s_part, wk);
     if (!active) return;
     store_row<LPC, DPL>(a.prop_buf + (uint64_t)w * a.L.ld, q, a.L.ld, wk.p);
     if (q == 0) {
         a.aux_buf[2 * (uint64_t)w] = wk.log_corr;
         // CR statistic travels through the exchange slots directly
-        if (a.algo == ALGO_DREAM) {
+        if (ALGO == ALGO_DREAM) {
             const bool gated = a.adapt_on && a.cr_gate;
             *delta_ptr(a.L, c) = gated ? wk.delta : 0.0;
             *cridx_ptr(a.L, c) = gated ? (double)wk.cr_idx : -1.0;
@@ -533,10 +608,10 @@ __global__ __launch_bounds__(WAVE) void phase_propose_kernel(const PhaseArgs a) 
 }
 
 // ... and ln_like values back in (aux_buf[2w+1]).
-template <int LPC, int DPL>
+template <int ALGO, int LPC, int DPL>
 __global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
     const int lane = threadIdx.x;
-    const int cw = lane / LPC, q = lane % LPC;
+    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
     const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
     bool active = w < a.n_items;
     int32_t id = active ? a.ids_buf[w] : -1;
@@ -548,15 +623,17 @@ __global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
     load_row<LPC, DPL>(a.prop_buf + (uint64_t)(active ? w : 0u) * a.L.ld, q, a.L.ld, wk.p);
     wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
+    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
+    wk.acc_hi = h1.x; wk.acc_lo = h1.y;
     wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0;
     // finish_update rewrites the CR slots: carry the values written by the propose kernel
-    if (a.algo == ALGO_DREAM && active) {
+    if (ALGO == ALGO_DREAM && active) {
         wk.delta = *delta_ptr(a.L, c);
         wk.cr_idx = (int)*cridx_ptr(a.L, c);
     }
     PhaseArgs b = a;
-    if (a.algo == ALGO_DREAM) b.cr_gate = (wk.cr_idx >= 0) ? 1u : 0u;
-    finish_update<LPC, DPL>(b, c, active, q, wk, ll_prop);
+    if (ALGO == ALGO_DREAM) b.cr_gate = (wk.cr_idx >= 0) ? 1u : 0u;
+    finish_update<ALGO, LPC, DPL>(b, c, active, q, wk, ll_prop);
 }
 
 // ---------------------------------------------------------------------------------
@@ -650,7 +727,7 @@ template <int TARGET, int LPC, int DPL>
 __global__ __launch_bounds__(WAVE) void eval_ll_kernel(const double* X, uint32_t n, uint32_t ld, uint32_t dim,
                                                       const double* tparams, double* out) {
     const int lane = threadIdx.x;
-    const int cw = lane / LPC, q = lane % LPC;
+    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
     const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
     const bool active = w < n;
     double v[DPL];

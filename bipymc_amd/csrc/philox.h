@@ -28,7 +28,7 @@ constexpr uint32_t SLOT_HDR0 = 0;   // (cr select, forced dim, gamma select, sno
 constexpr uint32_t SLOT_HDR1 = 1;   // (accept hi, accept lo, snooker gamma, spare)
 constexpr uint32_t SLOT_PAIR0 = 2;  // two pairs per block: (ia, ib, ia', ib')
 constexpr uint32_t SLOT_SNK = 7;    // (iz, i1, i2, spare)
-constexpr uint32_t SLOT_DIM0 = 8;   // per-dimension block j: (mask z, eps_u, bm1, bm2)
+constexpr uint32_t SLOT_DIM0 = 8;   // per coordinate pair pi: (z16|z16, e16|e16, bm1, bm2); init jitter: per coordinate
 constexpr int MAX_PAIRS = 10;
 constexpr uint64_t SUBSEQ_GLOBAL = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t SLOT_G_FLIP = 0;
@@ -53,8 +53,9 @@ BPM_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;   // one 32x32->64 multiply each
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
@@ -152,6 +153,7 @@ BPM_HD uint32_t feistel_inv(uint32_t y, const PermKey& pk) {
 BPM_HD uint32_t perm_fwd(uint32_t x, const PermKey& pk) {
     if (!pk.on) return x;
     x = feistel_fwd(x, pk);
+#pragma unroll 1
     while (x >= pk.n) x = feistel_fwd(x, pk);
     return x;
 }
@@ -159,6 +161,7 @@ BPM_HD uint32_t perm_fwd(uint32_t x, const PermKey& pk) {
 BPM_HD uint32_t perm_inv(uint32_t y, const PermKey& pk) {
     if (!pk.on) return y;
     y = feistel_inv(y, pk);
+#pragma unroll 1
     while (y >= pk.n) y = feistel_inv(y, pk);
     return y;
 }

@@ -81,17 +81,17 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
     const uint32_t cpw = WAVE / lpc;
     return (n_items + cpw - 1) / cpw;
 }
-template <int T, int LPC, int DPL>
+template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_fused_kernel<T, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
 }
-template <int LPC, int DPL>
+template <int ALGO, int LPC, int DPL>
 static void launch_propose(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_propose_kernel<LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
 }
-template <int LPC, int DPL>
+template <int ALGO, int LPC, int DPL>
 static void launch_commit(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_commit_kernel<LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_commit_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
 }
 template <int T, int LPC, int DPL>
 static void launch_eval(const double* X, uint32_t n, uint32_t ld, uint32_t dim, const double* tp, double* out,
@@ -118,10 +118,17 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
     {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
      FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>}
 #define COMMA ,
-static PhaseLaunch g_fused_gauss[6] = SHAPE_TABLE(launch_fused, TARGET_GAUSS COMMA);
-static PhaseLaunch g_fused_mixture[6] = SHAPE_TABLE(launch_fused, TARGET_MIXTURE COMMA);
-static PhaseLaunch g_propose[6] = SHAPE_TABLE(launch_propose, );
-static PhaseLaunch g_commit[6] = SHAPE_TABLE(launch_commit, );
+// update-kernel variants: [DE-MC (1 pair) | DREAM del_pairs = 3 (compile-time) | DREAM any del_pairs][shape]
+static PhaseLaunch g_fused_gauss[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
+                                          SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
+                                          SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
+static PhaseLaunch g_fused_mixture[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
+                                            SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
+                                            SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
+static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
+                                        launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
+static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+static PhaseLaunch g_commit[2][6] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
 static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
 static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
 
@@ -171,6 +178,17 @@ struct bpm_sampler {
     PhaseArgs cur_args[2];
     bool gen_adapt_on = false;
 };
+
+
+static PhaseLaunch pick_fused(const bpm_sampler* s) {
+    const int v = s->cfg.algo == BPM_ALGO_DEMC ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
+    switch (s->cfg.target_id) {
+        case BPM_TARGET_GAUSS_EQUICORR: return g_fused_gauss[v][s->shape.idx];
+        case BPM_TARGET_MIXTURE_PAIRS: return g_fused_mixture[v][s->shape.idx];
+        case BPM_TARGET_BANANA_2D: return g_fused_banana[v];
+        default: return nullptr;
+    }
+}
 
 static int check_handle(bpm_handle_t h) {
     if (!h) return fail("null handle");
@@ -332,6 +350,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
     s->L.blk = (uint64_t)s->n_local * (s->ld + 2);
+    s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
     s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
     const size_t row_d = (size_t)s->n_local * s->ld;
     CKD(dev_alloc(&s->G, (size_t)s->world * s->L.blk));
@@ -561,13 +580,8 @@ static int finish_generation(bpm_sampler* s) {
 
 static int run_generation_fused(bpm_sampler* s) {
     CK(prepare_generation(s));
-    PhaseLaunch fn = nullptr;
-    switch (s->cfg.target_id) {
-        case BPM_TARGET_GAUSS_EQUICORR: fn = g_fused_gauss[s->shape.idx]; break;
-        case BPM_TARGET_MIXTURE_PAIRS: fn = g_fused_mixture[s->shape.idx]; break;
-        case BPM_TARGET_BANANA_2D: fn = launch_fused<TARGET_BANANA, 1, 2>; break;
-        default: return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
-    }
+    PhaseLaunch fn = pick_fused(s);
+    if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
     for (int ph = 0; ph < 2; ++ph) {
         if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
         CK(allgather_state(s));
@@ -614,12 +628,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     std::vector<hipEvent_t> ev((size_t)n_gens * 4);
     for (auto& e : ev) HIPCK(hipEventCreate(&e));
-    PhaseLaunch fn = nullptr;
-    switch (s->cfg.target_id) {
-        case BPM_TARGET_GAUSS_EQUICORR: fn = g_fused_gauss[s->shape.idx]; break;
-        case BPM_TARGET_MIXTURE_PAIRS: fn = g_fused_mixture[s->shape.idx]; break;
-        default: fn = launch_fused<TARGET_BANANA, 1, 2>; break;
-    }
+    PhaseLaunch fn = pick_fused(s);
     for (int64_t g = 0; g < n_gens; ++g) {
         CK(prepare_generation(s));
         for (int ph = 0; ph < 2; ++ph) {
@@ -736,7 +745,7 @@ extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, i
     if (s->phase == 0) CK(prepare_generation(s));
     const PhaseArgs& a = s->cur_args[s->phase];
     HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
-    if (a.n_items > 0) g_propose[s->shape.idx](a, s->stream);
+    if (a.n_items > 0) g_propose[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
     std::vector<int32_t> ids(s->n_local);
     std::vector<double> props((size_t)s->n_local * s->ld);
@@ -773,7 +782,7 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
         aux[2 * (size_t)w + 1] = ll_prop[n++];
     }
     HIPCK(hipMemcpyAsync(s->aux_buf, aux.data(), aux.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    if (a.n_items > 0) g_commit[s->shape.idx](a, s->stream);
+    if (a.n_items > 0) g_commit[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
     CK(allgather_state(s));
     HIPCK(hipStreamSynchronize(s->stream));

@@ -428,8 +428,18 @@ class OracleSampler(object):
         ll_cur = self.ll[ids]
         h0 = P.chain_block(seed, ids, t, P.SLOT_HDR0)
         h1 = P.chain_block(seed, ids, t, P.SLOT_HDR1)
-        wd = P.chain_block(seed, ids[:, None], t, P.SLOT_DIM0 + np.arange(d)[None, :])   # (n, d, 4)
-        eps_n = epsilon * P.box_muller(wd[..., 2], wd[..., 3]) if epsilon > 0 else np.zeros((n, d))
+        npairs = (d + 1) // 2
+        wd = P.chain_block(seed, ids[:, None], t, P.SLOT_DIM0 + np.arange(npairs)[None, :])   # (n, npairs, 4)
+
+        def interleave(first, second):
+            """(n, npairs) x 2 -> (n, d): coordinates 2pi, 2pi+1"""
+            return np.stack([first, second], axis=-1).reshape(n, 2 * npairs)[:, :d]
+
+        if epsilon > 0:
+            n0, n1 = P.box_muller_pair_f32(wd[..., 2], wd[..., 3])
+            eps_n = epsilon * interleave(n0, n1)
+        else:
+            eps_n = np.zeros((n, d))
         out = dict(ids=ids)
         log_corr = np.zeros(n)
         if self.algo == ALGO_DREAM:
@@ -438,9 +448,9 @@ class OracleSampler(object):
             cum = np.cumsum(self.cr.p_cr)     # sequential running sum, as the kernel does
             cr_idx = np.minimum((uc[:, None] >= cum[None, :]).sum(axis=1), self.n_cr - 1)
             cr = self.cr.CR[cr_idx]
-            z = P.u01_32(wd[..., 0])
+            zk = interleave(*P.split16(wd[..., 0]))                      # 16-bit uniforms k * 2^-16
             forced = P.mulhi(h0[:, 1], d)
-            mask = z <= cr[:, None]
+            mask = zk <= P.mask_threshold(cr)[:, None]                   # == (k * 2^-16 <= cr), dream.py:53
             none = ~mask.any(axis=1)
             mask[none, forced[none]] = True
             d_prime = mask.sum(axis=1)
@@ -456,7 +466,10 @@ class OracleSampler(object):
             else:
                 jump = np.zeros(n, dtype=bool)
                 gamma = gamma_base
-            eps_u = (-u_epsilon + (2.0 * u_epsilon) * P.u01_32(wd[..., 1])) if u_epsilon > 0 else np.zeros((n, d))
+            if u_epsilon > 0:                                            # util.py:18-28
+                eps_u = -u_epsilon + (2.0 * u_epsilon) * P.u_sym16(interleave(*P.split16(wd[..., 1])))
+            else:
+                eps_u = np.zeros((n, d))
             A = self.X[pool_ids[pa]]             # (n, P, d)
             B = self.X[pool_ids[pb]]
             prop = dream_proposal(cur, A, B, gamma, eps_u, eps_n, mask)
