@@ -129,7 +129,6 @@ class DeMcMpi(object):
         self.am_chains = [McmcChain(self, int(c), i) for i, c in enumerate(self.rank_chain_ids)]
         self._hist_cache = None
         self._hist_cache_rows = -1
-        self._warm_prefix = None
         if not self.uses_device_target:
             X = self._engine.get_state()
             lo = self.comm.rank * self.n_local
@@ -148,10 +147,7 @@ class DeMcMpi(object):
     def _local_history(self):
         rows = self._engine.history_rows()
         if self._hist_cache is None or rows != self._hist_cache_rows:
-            h = self._engine.get_history(0, rows)
-            if self._warm_prefix is not None:
-                h = np.concatenate([self._warm_prefix, h[1:]], axis=0)
-            self._hist_cache = h
+            self._hist_cache = self._engine.get_history(0, rows)
             self._hist_cache_rows = rows
         return self._hist_cache
 
@@ -294,10 +290,9 @@ class DeMcMpi(object):
         if not h5_file:
             h5_file = self.h5_file
         hist, adapt = checkpoint.read(h5_file, self.n_chains, self.dim)   # (T, N, d)
-        self._engine.set_state(hist[-1])
-        self._after_state_reset()
         lo = self.comm.rank * self.n_local
-        self._warm_prefix = hist[:, lo:lo + self.n_local, :].copy()
+        self._engine.set_history(hist[:, lo:lo + self.n_local, :], hist[-1])
+        self._after_state_reset()
         self._restore_adapt_state(adapt)
         self.comm.Barrier()
 

@@ -1,0 +1,190 @@
+"""The drop-in surface on the GPU: the reference's own test scenarios (tests/test_dblgauss.py,
+tests/test_banana.py, tests/test_100dgauss.py) driven through bipymc_amd.DeMcMpi / DreamMpi, the
+host-callback ln_like_fn path, checkpoints, and size-independent properties at BASELINE sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg1_dream_bimodal_reference_scenario(golden_dir):
+    """BASELINE config 1 / tests/test_dblgauss.py:135-140,43-69: DREAM n_chains=10, n=100000, n_burn=40000."""
+    from bipymc_amd import DreamMpi
+    from bipymc_amd.utils import dblgauss_rv
+    np.random.seed(42)
+    target = dblgauss_rv.BimodeGauss_2D()
+    s = DreamMpi(target.ln_like, np.zeros(2), n_chains=10, mpi_comm=None, n_cr_gen=50, burnin_gen=2000)
+    assert s.uses_device_target
+    s.run_mcmc(100000)
+    theta_est, sig_est, chain = s.param_est(n_burn=40000)
+    theta_full, _, full_chain = s.param_est(n_burn=0)
+    assert full_chain.shape == (100000, 2) and chain.shape == (60000, 2)
+    # the reference's assertion (test_dblgauss.py:67-69)
+    assert abs(theta_est[0] - 1.5) <= 0.1 and abs(theta_est[1] - 1.5) <= 0.1
+    # exact per-axis std is sqrt(0.8125) = 0.9014; 10 chains, 6000 generations: 5 %
+    assert abs(sig_est[0] - 0.9014) < 0.05 and abs(sig_est[1] - 0.9014) < 0.05
+    assert 0.05 < s.acceptance_fraction < 0.6
+    # statistical anchor recorded from the genuine reference (same config, shorter run): same regime
+    ref = json.load(open(os.path.join(golden_dir, "e2e_anchor_cfg1.json")))
+    assert abs(s.acceptance_fraction - ref["acceptance_fraction"]) < 0.08
+    assert s.p_cr.shape == (3,) and abs(s.p_cr.sum() - 1.0) < 1e-12
+    assert s.n_accepted + s.n_rejected == 9999 * 10 + 1
+
+
+def test_demc_bimodal_and_banana_reference_scenarios():
+    """tests/test_dblgauss.py:130-133 (DE-MC n_chains=20) and tests/test_banana.py:43-72,118-121."""
+    from bipymc_amd import DeMcMpi
+    from bipymc_amd.utils import banana_rv, dblgauss_rv
+    np.random.seed(42)
+    s = DeMcMpi(dblgauss_rv.BimodeGauss_2D().ln_like, np.zeros(2), n_chains=20)
+    s.run_mcmc(100000)
+    theta_est, _, _ = s.param_est(n_burn=40000)
+    assert abs(theta_est[0] - 1.5) <= 0.1 and abs(theta_est[1] - 1.5) <= 0.1
+    banana = banana_rv.Banana_2D(sigma1=1, sigma2=1)
+    s = DeMcMpi(banana.ln_like, np.array([0.0, 0.0]), n_chains=20)
+    s.run_mcmc(100000)
+    _, _, chain = s.param_est(n_burn=20000)
+    y1, y2 = chain[:, 0], chain[:, 1]
+    # fraction of samples above the pdf levels 0.18 / 0.018; analytic values 0.5070 / 0.9507
+    f1 = np.count_nonzero(banana.check_prob_lvl(y1, y2, 0.18)) / y1.size
+    f2 = np.count_nonzero(banana.check_prob_lvl(y1, y2, 0.018)) / y1.size
+    assert abs(f1 - 0.5070) <= 0.05 and abs(f2 - 0.9507) <= 0.05      # reference tolerance (test_banana.py:71-72)
+
+
+def test_100d_gauss_reference_scenario():
+    """tests/test_100dgauss.py:100-110: DE-MC n_chains=200 and DREAM n_chains=100, n=500000, n_burn=200000."""
+    from bipymc_amd import DeMcMpi, DreamMpi
+    from bipymc_amd.utils import d100_gauss
+    np.random.seed(42)
+    gauss = d100_gauss.Gauss_100D()
+    for mk in (lambda: DeMcMpi(gauss.ln_like, np.zeros(100), n_chains=200),
+               lambda: DreamMpi(gauss.ln_like, np.zeros(100), n_chains=100, n_cr_gen=50, burnin_gen=2000)):
+        s = mk()
+        s.run_mcmc(500000)
+        theta_est, sig_est, chain = s.param_est(n_burn=200000)
+        assert abs(theta_est[0]) <= 0.2 and abs(theta_est[1]) <= 0.2            # test_100dgauss.py:67-69
+        assert chain.shape[0] == 300000
+
+
+def test_host_callback_equals_device_target():
+    """An arbitrary Python ln_like_fn (samplers.py:36-43) takes the propose/commit path; with the same
+    target it must reproduce the fused device path (same draws, ln_like equal to rounding)."""
+    from bipymc_amd import DeMcMpi, DreamMpi
+    from bipymc_amd.utils import banana_rv, d100_gauss
+    g = d100_gauss.Gauss_100D(rho=0.5, dim=10)
+    calls = []
+
+    def py_ll(theta, offset=0.0):
+        assert isinstance(theta, np.ndarray) and theta.shape == (10,) and theta.dtype == np.float64
+        calls.append(1)
+        return float(g.ln_like(theta)) + offset
+
+    a = DreamMpi(g.ln_like, np.ones(10), n_chains=16, n_cr_gen=3, burnin_gen=10, seed=5)
+    b = DreamMpi(py_ll, np.ones(10), n_chains=16, n_cr_gen=3, burnin_gen=10, seed=5, ln_kwargs={"offset": 0.0})
+    assert a.uses_device_target and not b.uses_device_target
+    a.run_mcmc(16 * 31)
+    b.run_mcmc(16 * 31)
+    assert len(calls) == 16 + 16 * 30                       # once per chain at init, once per chain update
+    np.testing.assert_allclose(b.param_est(0)[2], a.param_est(0)[2], rtol=1e-9, atol=1e-12)
+    assert b.n_accepted == a.n_accepted
+    np.testing.assert_allclose(b.p_cr, a.p_cr, rtol=1e-9)
+    # DE-MC with snooker and an odd dimension through the host path
+    t3 = lambda th: -0.5 * float(np.sum(th ** 2))
+    c = DeMcMpi(t3, np.zeros(3), n_chains=12, seed=9, p_snooker=0.2)
+    c.run_mcmc(12 * 2001)
+    m, sd, _ = c.param_est(12 * 500)
+    assert np.all(np.abs(m) < 0.15) and np.all(np.abs(sd - 1.0) < 0.15)
+    # priors returning -inf (examples/ex_para_fit.py:45-55): proposals outside the support are rejected
+    def bounded(th):
+        return -np.inf if np.any(np.abs(th) > 1.0) else 0.0
+    d = DeMcMpi(bounded, np.zeros(2), varepsilon=1e-2, n_chains=16, seed=3)
+    d.run_mcmc(16 * 801)
+    ch = d.param_est(16 * 200)[2]
+    assert np.all(np.abs(ch) <= 1.0) and abs(ch.std() - 1 / np.sqrt(3)) < 0.05
+
+
+def test_nan_ratio_raises_like_numpy():
+    """both ln_like values -inf -> alpha NaN -> the reference's np.random.choice raises ValueError (samplers.py:336)"""
+    from bipymc_amd import DeMcMpi
+    s = DeMcMpi(lambda th: -np.inf, np.zeros(2), n_chains=8, seed=1)
+    with pytest.raises(ValueError):
+        s.run_mcmc(8 * 3)
+
+
+def test_checkpoint_warm_start_gpu(tmp_path):
+    from bipymc_amd import DreamMpi
+    from bipymc_amd.utils import dblgauss_rv
+    t = dblgauss_rv.BimodeGauss_2D()
+    f = str(tmp_path / "ck.npz")
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, seed=5, h5_file=f, checkpoint=4)
+    s.run_mcmc(8 * 13)
+    full = s.param_est(0)[2]
+    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, seed=5, h5_file=f, warm_start=True)
+    assert np.array_equal(s2.param_est(0)[2], full)
+    np.testing.assert_allclose(s2.p_cr, s.p_cr)
+    s2.run_mcmc(8 * 6)                     # adaptation resumes: Welford moments rebuilt from the loaded rows
+    assert s2.param_est(0)[2].shape == (8 * 18, 2)
+    assert np.array_equal(s2.param_est(0)[2][:8 * 13], full)
+
+
+def test_device_moments_equal_host_param_est():
+    from bipymc_amd import DreamMpi
+    from bipymc_amd.utils import d100_gauss
+    g = d100_gauss.Gauss_100D(rho=0.5, dim=7)
+    s = DreamMpi(g.ln_like, np.zeros(7), n_chains=24, seed=2, burnin_gen=20, n_cr_gen=5)
+    s.run_mcmc(24 * 60)
+    for n_burn in (0, 24 * 10, 24 * 10 + 5, 24 * 59 + 23):
+        mean, std, chain = s.param_est(n_burn)
+        cnt, s1, s2, sh = s._engine.reduce_moments(n_burn)
+        assert cnt == chain.shape[0]
+        np.testing.assert_allclose(sh + s1 / cnt, mean, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(np.sqrt(s2 / cnt - (s1 / cnt) ** 2), std, rtol=1e-9)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5_local"])
+def test_full_size_properties(cfg):
+    """BASELINE full sizes, checked through size-independent properties: determinism (same seed ->
+    same bits), history/state consistency, accept bookkeeping, finite log-likes, and movement."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    if cfg == "cfg2":
+        tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
+        kw = dict(algo=L.ALGO_DREAM, n_chains=8192, dim=d, burnin_gen=10, n_cr_gen=3)
+        x0 = np.random.RandomState(0).normal(size=(8192, d)) * np.sqrt(np.arange(d) + 1.0)
+        gens = 20
+    elif cfg == "cfg3":
+        tid, tp, d = banana_rv.Banana_2D()._bpm_target_spec()
+        kw = dict(algo=L.ALGO_DEMC, n_chains=65536, dim=d, p_snooker=0.1)
+        x0 = np.random.RandomState(0).normal(size=(65536, d)) + np.array([0, 1.0])
+        gens = 30
+    else:
+        tid, tp, d = mixture_nd.BimodeGauss_ND(8)._bpm_target_spec()
+        kw = dict(algo=L.ALGO_DREAM, n_chains=32768, dim=d, burnin_gen=10, n_cr_gen=3)
+        rs = np.random.RandomState(0)
+        x0 = np.where(rs.uniform(size=(32768, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(32768, d))
+        gens = 30
+    outs = []
+    for rep in range(2):
+        e = HipEngine(target_id=tid, target_params=tp, seed=77, **kw)
+        e.set_state(x0)
+        e.begin_run()
+        e.step(gens)
+        st = e.stats()
+        H = e.get_history(gens - 1, gens + 1)
+        X = e.get_state()
+        assert np.array_equal(H[-1], X)                                     # last history row = current state
+        moved = np.any(H[-1] != H[-2], axis=1)
+        assert st["local_n_accepted"] + st["local_n_rejected"] == gens * kw["n_chains"] + 1
+        assert 0.02 < st["local_n_accepted"] / (gens * kw["n_chains"]) < 0.9
+        assert 0 < moved.sum() < kw["n_chains"]
+        ll = e.get_loglike()
+        assert np.all(np.isfinite(ll))
+        np.testing.assert_allclose(ll, e.eval_loglike(X), rtol=1e-12, atol=1e-9)   # cache == fresh evaluation
+        outs.append((X, st["local_n_accepted"], st["p_cr"]))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]     # bitwise reproducible
+    assert np.array_equal(outs[0][2], outs[1][2])
