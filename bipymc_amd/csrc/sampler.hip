@@ -379,8 +379,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         CKD(dev_alloc(&s->aux_buf, 2 * (size_t)s->n_local));
         CKD(dev_alloc(&s->ids_buf, s->n_local));
     }
-    if (s->world > 1) {
-        if (!cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
+    if (s->world > 1 && !cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
+    if (cfg->nccl_uid) {      // world_size == 1 with a uid: a one-rank communicator (exercises the RCCL path on one GPU)
         CKD(load_rccl());
         ncclUniqueId id;
         std::memcpy(&id, cfg->nccl_uid, BPM_UID_BYTES);
@@ -485,7 +485,7 @@ extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
 }
 
 static int allgather_state(bpm_sampler* s) {
-    if (s->world == 1) return 0;
+    if (!s->comm) return 0;
     NCCLCK(g_rccl.AllGather(s->G + (uint64_t)s->rank * s->L.blk, s->G, (size_t)s->L.blk, ncclDouble, s->comm, s->stream));
     return 0;
 }

@@ -188,3 +188,23 @@ def test_full_size_properties(cfg):
         e.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]     # bitwise reproducible
     assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_rccl_one_rank_communicator():
+    """RCCL is loaded on demand; a one-rank communicator runs the in-place all-gather after each half
+    generation on the sampler's stream and must not change any result."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D(dim=20)._bpm_target_spec()
+    x0 = np.random.RandomState(0).normal(size=(64, d))
+    res = []
+    for uid in (None, HipEngine.unique_id()):
+        e = HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=3, nccl_uid=uid,
+                      burnin_gen=5, n_cr_gen=2)
+        e.set_state(x0)
+        e.begin_run()
+        e.step(12)
+        res.append((e.get_state(), e.stats()["p_cr"]))
+        e.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
