@@ -60,12 +60,14 @@ def cpu_baseline(seconds_budget=20.0):
 
 
 def main():
+    global CHAINS_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
+    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU, help="experiments only; the default is the BASELINE workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,6 +88,7 @@ def main():
     from bipymc_amd.engine import HipEngine
     from bipymc_amd.utils.d100_gauss import Gauss_100D
 
+    CHAINS_PER_GPU = args.chains_per_gpu
     n_chains = CHAINS_PER_GPU * world
     target = Gauss_100D(rho=0.5, dim=DIM)
     tid, tparams, _ = target._bpm_target_spec()

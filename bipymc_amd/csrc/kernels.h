@@ -85,6 +85,10 @@ struct PhaseArgs {
     double* trace_f64;     // [n_local * TRACE_F64]
     uint8_t* trace_mask;   // [n_local * dim]
     PermKey pk;
+    const uint32_t* perm_tab;   // [N] shuffle order of this generation, position -> chain id (nullptr: evaluate the bijection)
+    const uint32_t* inv_tab;    // [N] its inverse, chain id -> position
+    const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
+    uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
@@ -100,16 +104,50 @@ struct PhaseArgs {
     double gamma_scale, gamma_demc, epsilon, u_epsilon, p_snooker;
 };
 
+// Sum over the LPC lanes of a chain subgroup, result in every lane of the subgroup.
+// Cross-lane moves are DPP (no LDS traffic, ~8 cycles each instead of a ds_bpermute round trip):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror give the sum of each row of
+// 16 lanes; a full wavefront then combines its four row sums through v_readlane (scalar operands).
+// Must be called with all 64 lanes active (it is: subgroups never diverge around a reduction).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 template <int LPC>
 __device__ __forceinline__ double gsum(double v) {
-#pragma unroll
-    for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    static_assert(LPC == 1 || LPC == 4 || LPC == 16 || LPC == 32 || LPC == 64, "subgroup sizes");
+    if (LPC >= 4) {
+        v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    }
+    if (LPC >= 16) {
+        v += dpp_f64<0x141>(v);    // row_half_mirror
+        v += dpp_f64<0x140>(v);    // row_mirror
+    }
+    if (LPC == 32) v += __shfl_xor(v, 16);
+    if (LPC == 64) v = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
     return v;
 }
 template <int LPC>
 __device__ __forceinline__ int gsum_i(int v) {
-#pragma unroll
-    for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (LPC >= 4) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    }
+    if (LPC >= 16) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    }
+    if (LPC == 32) v += __shfl_xor(v, 16);
+    if (LPC == 64)
+        v = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+            (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
     return v;
 }
 
@@ -206,7 +244,8 @@ struct Work {
     double delta;      // CR statistic (dream.py:130)
     double log_corr;   // snooker Jacobian term
     double gamma;
-    uint32_t acc_hi, acc_lo;   // words of the accept uniform (HDR1)
+    uint32_t acc_hi, acc_lo;   // words of the accept uniform
+    double ll_cur;             // cached ln_like of the current state, fetched early
     int cr_idx, d_prime, jump, snk;
     uint32_t maskbits;
 };
@@ -269,6 +308,13 @@ __device__ __forceinline__ uint32_t partner_pos(const PhaseArgs& a, uint32_t c, 
     return s == 0 ? iz : (s == 1 ? i1 : i2);
 }
 
+__device__ __forceinline__ uint32_t pos_to_chain(const PhaseArgs& a, uint32_t pos) {
+    return a.perm_tab ? a.perm_tab[pos] : perm_fwd(pos, a.pk);
+}
+__device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c) {
+    return a.inv_tab ? a.inv_tab[c] : perm_inv(c, a.pk);
+}
+
 // Build the proposal of chain c (dream.py:43-93 / demc.py:161-182).
 // ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
 template <int ALGO, int LPC, int DPL, int NP>
@@ -281,45 +327,58 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     constexpr bool FAST = (LPC == WAVE) && (NP > 0) && (BPM_SCALAR_PARTNERS != 0);
     const uint32_t dim = a.L.dim, ld = a.L.ld;
     const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;
+    // state-dependent loads first: they overlap with all the draw arithmetic below
+    load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
+    wk.ll_cur = a.ll[c - a.lo];
+    // one header block: (select16|gamma16, forced dim [DREAM] / snooker gamma [DE-MC], accept hi, accept lo)
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
-    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
-    wk.acc_hi = h1.x; wk.acc_lo = h1.y;
+    wk.acc_hi = h0.z; wk.acc_lo = h0.w;
+    const double u_sel = (double)(h0.x >> 16) * 1.52587890625e-05;      // CR select (DREAM) / snooker select (DE-MC)
+    const double u_gam = (double)(h0.x & 0xFFFFu) * 1.52587890625e-05;  // gamma = 1 jump select
 
     const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
     const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
-    Partners<LPC, FAST ? 2 * NP : 0> part;
+    // RL: one wavefront per chain and a compile-time pair count: lanes 0..2NP-1 resolve one partner
+    // each (pair draw + Feistel walk in parallel), v_readlane hands the ids over as scalars: no LDS,
+    // no barrier, and the partner row addresses are scalar arithmetic.
+    constexpr bool RL = (LPC == WAVE) && (NP > 0) && !FAST;
+    Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
     part.lds = s_part + cw * MAX_PARTNERS;
     if (FAST) {
 #pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) part.r[i] = perm_fwd(a.pool_off + partner_pos(a, c, (uint32_t)i, 2u * NP), a.pk);
+        for (int i = 0; i < 2 * NP; ++i) part.r[i] = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)i, 2u * NP));
     }
-    if (!FAST || snk_possible) {
+    if (RL) {
+        uint32_t mine = 0;
+        if (q < 2 * NP) mine = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)q, 2u * NP));
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+    }
+    if (!(FAST || RL) || snk_possible) {
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
-            s_part[cw * MAX_PARTNERS + idx] = perm_fwd(a.pool_off + partner_pos(a, c, idx, 2 * P), a.pk);
+            s_part[cw * MAX_PARTNERS + idx] = pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
         __syncthreads();
     }
 
-    // ---- own row and per-pair draws: one Philox block per coordinate pair
-    load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
+    // ---- per-pair draws: one Philox block per coordinate pair
     double eps_n[DPL], eps_u[DPL];
     uint32_t maskbits = 0;
     wk.cr_idx = -1; wk.d_prime = (int)dim; wk.jump = 0; wk.snk = 0; wk.delta = 0.0; wk.log_corr = 0.0;
     uint32_t thr = 65536u;
     if (DREAM) {
         // cr ~ Categorical(CR, p_cr)  (dream.py:51)
-        const double uc = u01_32(h0.x);
+        const double uc = u_sel;
         double cum = 0.0;
         int idx = (int)a.n_cr - 1;
         bool found = false;
 #pragma unroll 1
         for (int m = 0; m < (int)a.n_cr; ++m) {          // first m with uc < cumsum(p_cr)[m]
             cum += a.cr_state[m];
-            if (!found && uc < cum) { idx = m; found = true; }
+            if (!found && uc < cum) { idx = m; thr = a.thr[m]; found = true; }   // k 2^-16 <= CR_m  <=>  k <= thr[m]
         }
+        if (!found) thr = a.thr[a.n_cr - 1];
         wk.cr_idx = idx;
-        const double cr = (double)(idx + 1) / (double)a.n_cr;     // dream.py:113
-        thr = (uint32_t)floor(cr * 65536.0);                       // k 2^-16 <= cr  <=>  k <= thr
     }
     int cnt = 0;
 #pragma unroll
@@ -347,7 +406,13 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         }
     }
     if (DREAM) {
-        cnt = gsum_i<LPC>(cnt);
+        if (LPC == WAVE) {
+            cnt = 0;
+#pragma unroll
+            for (int sb = 0; sb < DPL; ++sb) cnt += (int)__popcll(__ballot((maskbits >> sb) & 1u));
+        } else {
+            cnt = gsum_i<LPC>(cnt);
+        }
         if (cnt == 0) {                                // dream.py:55-57: force one dimension
             const uint32_t f = mulhi32(h0.y, dim);
 #pragma unroll
@@ -363,9 +428,8 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 
     if (DREAM) {
         // gamma (dream.py:61,77-80)
-        const double gamma_base = a.gamma_scale * 2.38 / sqrt(2.0 * (double)P * (double)cnt);
-        double gamma = gamma_base;
-        if (a.k % 5 == 0 && !(u01_32(h0.z) < 0.2)) { gamma = 1.0; wk.jump = 1; }
+        double gamma = a.gamma_tab[cnt];            // gamma_scale * 2.38 / sqrt(2 P d')
+        if (a.k % 5 == 0 && !(u_gam < 0.2)) { gamma = 1.0; wk.jump = 1; }
         wk.gamma = gamma;
         // sum over pairs of (A_p - B_p)  (dream.py:65-68,85-86), p = 0 first
         double sum[DPL];
@@ -421,11 +485,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     } else {
         // DE-MC (demc.py:161-182)
         double gamma = a.gamma_demc;
-        if (a.k % 10 == 0 && !(u01_32(h0.z) < 0.1)) { gamma = 1.0; wk.jump = 1; }
+        if (a.k % 10 == 0 && !(u_gam < 0.1)) { gamma = 1.0; wk.jump = 1; }
         wk.gamma = gamma;
         double ra[DPL], rb[DPL];
-        const uint32_t ca = (FAST && !snk_possible) ? part.get(0) : part.lds[0];
-        const uint32_t cb = (FAST && !snk_possible) ? part.get(1) : part.lds[1];
+        const uint32_t ca = ((FAST || RL) && !snk_possible) ? part.get(0) : part.lds[0];
+        const uint32_t cb = ((FAST || RL) && !snk_possible) ? part.get(1) : part.lds[1];
         load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
         load_row<LPC, DPL>(row_ptr(a.L, cb), q, ld, rb);
 #pragma unroll
@@ -435,7 +499,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             pv = pv + eps_n[s];
             wk.p[s] = pv;
         }
-        if (snk_possible && u01_32(h0.w) < a.p_snooker) {
+        if (snk_possible && u_sel < a.p_snooker) {
             // snooker update (ter Braak & Vrugt 2008) -- extension, absent from the reference
             double rz[DPL], r1[DPL], r2[DPL];
             load_row<LPC, DPL>(row_ptr(a.L, part.lds[2]), q, ld, rz);
@@ -451,7 +515,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             n2 = gsum<LPC>(n2);
             dot = gsum<LPC>(dot);
             if (n2 > 0.0) {
-                const double gs = (1.2 + u01_32(h1.z)) * (dot / n2);
+                const double gs = (1.2 + u01_32(h0.y)) * (dot / n2);
                 double n2p = 0.0;
 #pragma unroll
                 for (int s = 0; s < DPL; ++s) {
@@ -474,12 +538,12 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (q == 0) {
             int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
             tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
-            if (FAST) {
+            if (FAST || RL) {
 #pragma unroll
                 for (int i = 0; i < 2 * NP; ++i) tr[5 + i] = (int32_t)part.get(i);
             }
 #pragma unroll 1
-            for (uint32_t i = (FAST && !snk_possible) ? npart : 0u; i < MAX_PARTNERS; ++i)
+            for (uint32_t i = ((FAST || RL) && !snk_possible) ? npart : 0u; i < MAX_PARTNERS; ++i)
                 tr[5 + i] = i < npart ? (int32_t)part.lds[i] : -1;
         }
         if (a.trace_mask) {
@@ -498,7 +562,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                                               const Work<DPL>& wk, double ll_prop) {
     const uint32_t ld = a.L.ld;
     const uint32_t li = c - a.lo;
-    const double ll_cur = a.ll[li];
+    const double ll_cur = wk.ll_cur;
     double alpha = exp((ll_prop + wk.log_corr) - ll_cur);
     const bool is_nan = alpha != alpha;
     alpha = fmin(1.0, alpha);
@@ -555,10 +619,10 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
 __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, uint32_t& c) {
     bool active = w < a.n_items;
     if (a.mode == 0) {
-        c = perm_fwd(a.upd_off + (active ? w : 0u), a.pk);
+        c = pos_to_chain(a, a.upd_off + (active ? w : 0u));
     } else {
         c = a.lo + (active ? w : 0u);
-        const uint32_t pos = perm_inv(c, a.pk);
+        const uint32_t pos = chain_to_pos(a, c);
         active = active && (pos - a.upd_off) < a.n_upd;
     }
     return active;
@@ -622,9 +686,10 @@ __global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
     load_row<LPC, DPL>(row_ptr(a.L, c), q, a.L.ld, wk.x);
     load_row<LPC, DPL>(a.prop_buf + (uint64_t)(active ? w : 0u) * a.L.ld, q, a.L.ld, wk.p);
     wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
+    wk.ll_cur = a.ll[c - a.lo];
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
-    const u32x4 h1 = chain_block(a.seed, c, a.t, SLOT_HDR1);
-    wk.acc_hi = h1.x; wk.acc_lo = h1.y;
+    const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
+    wk.acc_hi = h0.z; wk.acc_lo = h0.w;
     wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0;
     // finish_update rewrites the CR slots: carry the values written by the propose kernel
     if (ALGO == ALGO_DREAM && active) {
@@ -686,6 +751,22 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
             for (uint32_t m = 0; m < n_cr; ++m) p_cr[m] = p_cr[m] / s;                              // dream.py:140
         }
     }
+}
+
+// Shuffle orders of K consecutive generations in one launch: tab[g*N + k] = pi_g(k), inv[g*N + pi_g(k)] = k.
+// The update kernels then look partners up (one 4-byte load) instead of walking the Feistel network
+// (~100 instructions per id, and the kernels are instruction-issue bound).
+constexpr int PERM_CHUNK = 64;
+struct PermKeys {
+    PermKey k[PERM_CHUNK];
+};
+__global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t N, uint32_t* tab, uint32_t* inv) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)n_gens * N) return;
+    const uint32_t g = (uint32_t)(e / N), k = (uint32_t)(e % N);
+    const uint32_t c = perm_fwd(k, keys.k[g]);
+    tab[e] = c;
+    inv[(uint64_t)g * N + c] = k;
 }
 
 // Welford moments of every local chain's history rows [0, rows) recomputed from the history

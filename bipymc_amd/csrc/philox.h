@@ -24,8 +24,7 @@ namespace bpm {
 
 // ---- draw layout (keep equal to oracle/philox_ref.py) ----------------------
 constexpr int SLOT_BITS = 16;
-constexpr uint32_t SLOT_HDR0 = 0;   // (cr select, forced dim, gamma select, snooker select)
-constexpr uint32_t SLOT_HDR1 = 1;   // (accept hi, accept lo, snooker gamma, spare)
+constexpr uint32_t SLOT_HDR0 = 0;   // (select16|gamma16, forced dim [DREAM] / snooker gamma [DE-MC], accept hi, accept lo)
 constexpr uint32_t SLOT_PAIR0 = 2;  // two pairs per block: (ia, ib, ia', ib')
 constexpr uint32_t SLOT_SNK = 7;    // (iz, i1, i2, spare)
 constexpr uint32_t SLOT_DIM0 = 8;   // per coordinate pair pi: (z16|z16, e16|e16, bm1, bm2); init jitter: per coordinate

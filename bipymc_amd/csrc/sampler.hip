@@ -108,7 +108,13 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
     if (np <= 1) sh = {1, 2, 0};
     else if (np <= 4) sh = {4, 2, 1};
     else if (np <= 16) sh = {16, 2, 2};
-    else if (np <= 64) sh = {64, 2, 3};
+    else if (np <= 64) {
+        sh = {64, 2, 3};
+        // experiment: several chains per wavefront amortise the per-chain control work
+        const char* e = getenv("BPM_SHAPE");
+        if (e && !strcmp(e, "32x4")) sh = {32, 4, 6};
+        if (e && !strcmp(e, "16x8")) sh = {16, 8, 7};
+    }
     else if (np <= 128) sh = {64, 4, 4};
     else if (np <= 256) sh = {64, 8, 5};
     else return false;
@@ -116,21 +122,21 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
 }
 #define SHAPE_TABLE(FN, ...)                                                                     \
     {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
-     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>}
+     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>, FN<__VA_ARGS__ 32, 4>, FN<__VA_ARGS__ 16, 8>}
 #define COMMA ,
 // update-kernel variants: [DE-MC (1 pair) | DREAM del_pairs = 3 (compile-time) | DREAM any del_pairs][shape]
-static PhaseLaunch g_fused_gauss[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
+static PhaseLaunch g_fused_gauss[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
-static PhaseLaunch g_fused_mixture[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
+static PhaseLaunch g_fused_mixture[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
 static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
                                         launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
-static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
-static PhaseLaunch g_commit[2][6] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
-static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
-static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
+static PhaseLaunch g_propose[2][8] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+static PhaseLaunch g_commit[2][8] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
+static EvalLaunch g_eval_gauss[8] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
+static EvalLaunch g_eval_mixture[8] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
 
 // ---- the sampler ------------------------------------------------------------------------
 struct bpm_sampler {
@@ -163,6 +169,12 @@ struct bpm_sampler {
     double* trace_f64 = nullptr;
     uint8_t* trace_mask = nullptr;
     double* scratch = nullptr;   // small device scratch (theta0, var, moments)
+    uint32_t* perm_tab = nullptr;   // [PERM_CHUNK * N] shuffle orders of the generations [tab_t0, tab_t0 + tab_K)
+    uint32_t* inv_tab = nullptr;
+    int64_t tab_t0 = -1;
+    int tab_K = 0;
+    int tab_shuffle = -1;
+    double* gamma_tab = nullptr;    // [dim + 1]
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
     // run state
@@ -280,7 +292,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -372,6 +384,16 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc(&s->acc_count, s->n_local));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
+    CKD(dev_alloc(&s->perm_tab, (size_t)PERM_CHUNK * s->N));
+    CKD(dev_alloc(&s->inv_tab, (size_t)PERM_CHUNK * s->N));
+    CKD(dev_alloc(&s->gamma_tab, (size_t)s->dim + 1));
+    {
+        std::vector<double> gt(s->dim + 1, 0.0);      // dream.py:61, same operation order as the reference
+        for (uint32_t dp = 1; dp <= s->dim; ++dp)
+            gt[dp] = s->cfg.gamma_scale * 2.38 / std::sqrt(2. * (double)s->cfg.del_pairs * (double)dp);
+        HIPCKD(hipMemcpyAsync(s->gamma_tab, gt.data(), gt.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIPCKD(hipStreamSynchronize(s->stream));
+    }
     s->scratch_doubles = 4 * (size_t)s->ld + 64;
     CKD(dev_alloc(&s->scratch, s->scratch_doubles));
     if (tid == BPM_TARGET_HOST_CALLBACK) {
@@ -490,11 +512,30 @@ static int allgather_state(bpm_sampler* s) {
     return 0;
 }
 
+// Shuffle orders for the generations [t, t + n_ahead) (at most PERM_CHUNK) in one launch.
+static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
+    const int shuffle = s->opts.shuffle != 0 ? 1 : 0;
+    if (s->tab_shuffle == shuffle && t >= s->tab_t0 && t < s->tab_t0 + s->tab_K) return 0;
+    const int K = (int)std::max<int64_t>(1, std::min<int64_t>(PERM_CHUNK, n_ahead));
+    PermKeys keys;
+    for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t + g), s->N, shuffle != 0);
+    for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
+    const uint64_t n = (uint64_t)K * s->N;
+    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, keys, (uint32_t)K, s->N,
+                       s->perm_tab, s->inv_tab);
+    HIPCK(hipGetLastError());
+    s->tab_t0 = t;
+    s->tab_K = K;
+    s->tab_shuffle = shuffle;
+    return 0;
+}
+
 // Everything of one generation that is decided on the host: flip, shuffle key, group ranges
 // (demc.py:81-86,95-100), gating flags (dream.py:92,123), history row.
-static int prepare_generation(bpm_sampler* s) {
+static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     const bool dream = s->cfg.algo == BPM_ALGO_DREAM;
     const uint64_t t = (uint64_t)s->t_abs;
+    CK(ensure_perm_table(s, s->t_abs, n_ahead));
     const bool flip = flip_draw(s->cfg.seed, t, s->opts.flip);
     const PermKey pk = make_perm_key(s->cfg.seed, t, s->N, s->opts.shuffle != 0);
     const uint32_t n_first = (s->N + 1) / 2, n_second = s->N - n_first;    // np.array_split: first gets ceil
@@ -538,6 +579,13 @@ static int prepare_generation(bpm_sampler* s) {
         a.trace_f64 = s->trace_f64;
         a.trace_mask = s->trace_mask;
         a.pk = pk;
+        a.perm_tab = s->perm_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
+        a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
+        { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
+          if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
+        a.gamma_tab = s->gamma_tab;
+        for (int m = 0; m < s->cfg.n_cr && m < MAX_CR; ++m)
+            a.thr[m] = (uint32_t)std::floor(((double)(m + 1) / (double)s->cfg.n_cr) * 65536.0);   // dream.py:113
         a.seed = s->cfg.seed;
         a.t = t;
         a.k = (uint32_t)s->k_gen;
@@ -578,8 +626,8 @@ static int finish_generation(bpm_sampler* s) {
     return 0;
 }
 
-static int run_generation_fused(bpm_sampler* s) {
-    CK(prepare_generation(s));
+static int run_generation_fused(bpm_sampler* s, int64_t n_ahead) {
+    CK(prepare_generation(s, n_ahead));
     PhaseLaunch fn = pick_fused(s);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
     for (int ph = 0; ph < 2; ++ph) {
@@ -596,7 +644,7 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
-    for (int64_t g = 0; g < n_gens; ++g) CK(run_generation_fused(s));
+    for (int64_t g = 0; g < n_gens; ++g) CK(run_generation_fused(s, n_gens - g));
     return 0;
 }
 
@@ -630,7 +678,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     for (auto& e : ev) HIPCK(hipEventCreate(&e));
     PhaseLaunch fn = pick_fused(s);
     for (int64_t g = 0; g < n_gens; ++g) {
-        CK(prepare_generation(s));
+        CK(prepare_generation(s, n_gens - g));
         for (int ph = 0; ph < 2; ++ph) {
             HIPCK(hipEventRecord(ev[(size_t)g * 4 + 2 * ph], s->stream));
             if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
@@ -742,7 +790,7 @@ extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, i
     if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail("bpm_propose: sampler has a device target; use bpm_step");
     if (s->proposed) return fail("bpm_propose: previous proposals not committed");
     if (!out_prop || !out_ids || !n_out) return fail("bpm_propose: null argument");
-    if (s->phase == 0) CK(prepare_generation(s));
+    if (s->phase == 0) CK(prepare_generation(s, 1));
     const PhaseArgs& a = s->cur_args[s->phase];
     HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
     if (a.n_items > 0) g_propose[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);

@@ -426,8 +426,11 @@ class OracleSampler(object):
         M = pool_ids.size
         cur = self.X[ids]
         ll_cur = self.ll[ids]
+        # one header block per chain update: (select16|gamma16, forced dim / snooker gamma, accept hi, accept lo)
         h0 = P.chain_block(seed, ids, t, P.SLOT_HDR0)
-        h1 = P.chain_block(seed, ids, t, P.SLOT_HDR1)
+        sel_hi, sel_lo = P.split16(h0[:, 0])
+        u_sel = sel_hi * 2.0 ** -16          # DREAM: CR select; DE-MC: snooker select
+        u_gam = sel_lo * 2.0 ** -16          # gamma = 1 jump select
         npairs = (d + 1) // 2
         wd = P.chain_block(seed, ids[:, None], t, P.SLOT_DIM0 + np.arange(npairs)[None, :])   # (n, npairs, 4)
 
@@ -444,7 +447,7 @@ class OracleSampler(object):
         log_corr = np.zeros(n)
         if self.algo == ALGO_DREAM:
             # CR index ~ Categorical(p_cr)   dream.py:51
-            uc = P.u01_32(h0[:, 0])
+            uc = u_sel
             cum = np.cumsum(self.cr.p_cr)     # sequential running sum, as the kernel does
             cr_idx = np.minimum((uc[:, None] >= cum[None, :]).sum(axis=1), self.n_cr - 1)
             cr = self.cr.CR[cr_idx]
@@ -461,7 +464,7 @@ class OracleSampler(object):
                 wp = P.chain_block(seed, ids, t, P.SLOT_PAIR0 + p // 2)
                 pa[:, p], pb[:, p] = P.distinct_pair(wp[:, 2 * (p % 2)], wp[:, 2 * (p % 2) + 1], M)
             if k % 5 == 0:                       # dream.py:77-80
-                jump = ~(P.u01_32(h0[:, 2]) < 0.2)
+                jump = ~(u_gam < 0.2)
                 gamma = np.where(jump, 1.0, gamma_base)
             else:
                 jump = np.zeros(n, dtype=bool)
@@ -487,7 +490,7 @@ class OracleSampler(object):
             wp = P.chain_block(seed, ids, t, P.SLOT_PAIR0)
             ia, ib = P.distinct_pair(wp[:, 0], wp[:, 1], M)
             if k % 10 == 0:                      # demc.py:174-177
-                jump = ~(P.u01_32(h0[:, 2]) < 0.1)
+                jump = ~(u_gam < 0.1)
                 gamma = np.where(jump, 1.0, gamma_base)
             else:
                 jump = np.zeros(n, dtype=bool)
@@ -495,10 +498,10 @@ class OracleSampler(object):
             prop = demc_proposal(cur, self.X[pool_ids[ia]], self.X[pool_ids[ib]], gamma, eps_n)
             snk = np.zeros(n, dtype=bool)
             if self.p_snooker > 0 and M >= 3:
-                snk = P.u01_32(h0[:, 3]) < self.p_snooker
+                snk = u_sel < self.p_snooker
                 ws = P.chain_block(seed, ids, t, P.SLOT_SNK)
                 iz, i1, i2 = snooker_third(ws[:, 0], ws[:, 1], ws[:, 2], M)
-                gamma_s = 1.2 + P.u01_32(h1[:, 2])
+                gamma_s = 1.2 + P.u01_32(h0[:, 1])
                 zz = self.X[pool_ids[iz]]
                 with np.errstate(divide="ignore", invalid="ignore"):
                     sprop, n2 = snooker_proposal(cur, zz, self.X[pool_ids[i1]], self.X[pool_ids[i2]], gamma_s, eps_n)
@@ -513,7 +516,7 @@ class OracleSampler(object):
             cr_idx_eff = np.full(n, -1, dtype=np.int64)
         ll_prop = self._ll(prop)
         alpha = mut_prop_ratio(ll_cur, ll_prop + log_corr)
-        ua = P.u01_53(h1[:, 0], h1[:, 1])
+        ua = P.u01_53(h0[:, 2], h0[:, 3])
         accepted = metropolis_accept(alpha, ua)
         new_state = np.where(accepted[:, None], prop, cur)
         new_ll = np.where(accepted, ll_prop, ll_cur)
