@@ -79,7 +79,10 @@ def main():
 
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
     dist = None
-    if world > 1:
+    # BPM_FORCE_DIST=1 takes the multi-process path with a single rank (process group + one-rank RCCL
+    # communicator): the only way to rehearse it on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("BPM_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -93,7 +96,7 @@ def main():
     target = Gauss_100D(rho=0.5, dim=DIM)
     tid, tparams, _ = target._bpm_target_spec()
     uid = None
-    if world > 1:
+    if use_dist:
         box = [HipEngine.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]

@@ -769,6 +769,36 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
     inv[(uint64_t)g * N + c] = k;
 }
 
+// Outlier-chain reset (Vrugt et al. 2009, DREAM; NOT in the reference -- extension).
+// omega_i = mean ln_like of chain i over the history rows [r0, rows).
+__global__ void omega_kernel(const double* llhist, uint32_t n_local, uint32_t r0, uint32_t rows, double* omega) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local) return;
+    double acc = 0.0;
+    for (uint32_t g = r0; g < rows; ++g) acc += llhist[(uint64_t)g * n_local + i];
+    omega[i] = acc / (double)(rows - r0);
+}
+// Every rank copies the best chain's state over each outlier chain in its replica of the state matrix;
+// the owner of an outlier also fixes its ln_like cache and the last history row (= current state).
+__global__ void outlier_reset_kernel(Layout L, uint32_t lo, const int32_t* ids, uint32_t n_out, uint32_t best, double* ll,
+                                     double ll_best, double* hist_last, double* llhist_last) {
+    const uint32_t o = blockIdx.x;
+    if (o >= n_out) return;
+    const uint32_t c = (uint32_t)ids[o];
+    const double* src = row_ptr(L, best);
+    double* dst = row_ptr(L, c);
+    const bool mine = c >= lo && c < lo + L.n_local;
+    for (uint32_t j = threadIdx.x; j < L.ld; j += blockDim.x) {
+        const double v = src[j];
+        dst[j] = v;
+        if (mine && hist_last) hist_last[(uint64_t)(c - lo) * L.ld + j] = v;
+    }
+    if (mine && threadIdx.x == 0) {
+        ll[c - lo] = ll_best;
+        if (llhist_last) llhist_last[c - lo] = ll_best;
+    }
+}
+
 // Welford moments of every local chain's history rows [0, rows) recomputed from the history
 // buffer (only needed when adaptation resumes after generations run without it).
 __global__ void welford_rebuild_kernel(const double* hist, uint64_t row_stride, uint64_t n_elem, uint32_t rows,

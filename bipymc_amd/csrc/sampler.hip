@@ -612,6 +612,67 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     return 0;
 }
 
+// np.percentile(v, q) with the default linear interpolation (NumPy's _lerp), v sorted ascending
+static double percentile_sorted(const std::vector<double>& v, double q) {
+    const double pos = q / 100.0 * (double)(v.size() - 1);
+    const size_t lo = (size_t)std::floor(pos);
+    const size_t hi = std::min(lo + 1, v.size() - 1);
+    const double t = pos - (double)lo, a = v[lo], b = v[hi], d = b - a;
+    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+
+// DREAM outlier-chain reset (Vrugt et al. 2009): chains whose mean ln_like over the last half of their
+// history lies below Q1 - 2 IQR (quartiles over all N chains) restart from the best chain's state.
+static int outlier_check(bpm_sampler* s) {
+    if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
+    const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
+    double* d_omega = nullptr;
+    CK(dev_alloc(&d_omega, (size_t)s->N));
+    double* mine = d_omega + (size_t)s->rank * s->n_local;
+    hipLaunchKernelGGL(omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->n_local, r0, rows, mine);
+    HIPCK(hipGetLastError());
+    if (s->comm) NCCLCK(g_rccl.AllGather(mine, d_omega, (size_t)s->n_local, ncclDouble, s->comm, s->stream));
+    std::vector<double> omega(s->N);
+    HIPCK(hipMemcpyAsync(omega.data(), d_omega, (size_t)s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    HIPCK(hipFree(d_omega));
+    std::vector<double> sorted(omega);
+    std::sort(sorted.begin(), sorted.end());
+    const double q1 = percentile_sorted(sorted, 25.0), q3 = percentile_sorted(sorted, 75.0);
+    const double cut = q1 - 2.0 * (q3 - q1);
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < s->N; ++i) if (omega[i] > omega[best]) best = i;       // first maximum
+    std::vector<int32_t> ids;
+    for (uint32_t i = 0; i < s->N; ++i) if (omega[i] < cut) ids.push_back((int32_t)i);
+    if (ids.empty()) return 0;
+    // ln_like of the best chain's current state: its owner has it cached; every rank needs the value
+    double ll_best = 0.0;
+    {
+        double* d_ll = nullptr;
+        CK(dev_alloc(&d_ll, (size_t)s->world));
+        const uint32_t owner = best / s->n_local;
+        if (owner == s->rank) HIPCK(hipMemcpyAsync(d_ll + s->rank, s->ll + (best - s->lo), sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        else HIPCK(hipMemsetAsync(d_ll + s->rank, 0, sizeof(double), s->stream));
+        if (s->comm) NCCLCK(g_rccl.AllGather(d_ll + s->rank, d_ll, 1, ncclDouble, s->comm, s->stream));
+        HIPCK(hipMemcpyAsync(&ll_best, d_ll + owner, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIPCK(hipStreamSynchronize(s->stream));
+        HIPCK(hipFree(d_ll));
+    }
+    int32_t* d_ids = nullptr;
+    CK(dev_alloc(&d_ids, ids.size()));
+    HIPCK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    double* hist_last = s->hist + (uint64_t)(s->hist_rows - 1) * s->n_local * s->ld;
+    double* llhist_last = s->llhist + (uint64_t)(s->hist_rows - 1) * s->n_local;
+    hipLaunchKernelGGL(outlier_reset_kernel, dim3((unsigned)ids.size()), dim3(64), 0, s->stream, s->L, s->lo, d_ids,
+                       (uint32_t)ids.size(), best, s->ll, ll_best, hist_last, llhist_last);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(s->stream));
+    HIPCK(hipFree(d_ids));
+    s->n_outlier_resets += (int64_t)ids.size();
+    s->w_rows = 0;       // the last history row of the reset chains changed: moments are rebuilt on demand
+    return 0;
+}
+
 static int finish_generation(bpm_sampler* s) {
     if (s->gen_adapt_on) {
         hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
@@ -623,6 +684,9 @@ static int finish_generation(bpm_sampler* s) {
     s->rows_logical += 1;
     s->k_gen += 1;      // demc.py:134
     s->t_abs += 1;
+    if (s->cfg.algo == BPM_ALGO_DREAM && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen &&
+        s->k_gen % s->cfg.outlier_every == 0)
+        CK(outlier_check(s));
     return 0;
 }
 

@@ -304,7 +304,7 @@ class OracleSampler(object):
     def __init__(self, algo, n_chains, dim, target_id, target_params, seed,
                  rank=0, world=1, allgather=None, ll_fn=None,
                  gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
-                 p_snooker=0.0):
+                 p_snooker=0.0, outlier_every=0):
         assert n_chains >= 4                       # samplers.py:249
         assert n_chains % world == 0
         assert 1 <= del_pairs <= P.MAX_PAIRS
@@ -320,6 +320,8 @@ class OracleSampler(object):
         self.gamma_scale, self.P = float(gamma_scale), int(del_pairs)
         self.burnin_gen, self.n_cr_gen, self.n_cr = int(burnin_gen), int(n_cr_gen), int(n_cr)
         self.p_snooker = float(p_snooker)
+        self.outlier_every = int(outlier_every)
+        self.n_outlier_resets = 0
         self.cr = CrState(self.n_cr)
         self.X = np.zeros((self.N, self.d))
         self.ll = np.zeros(self.N)
@@ -419,6 +421,40 @@ class OracleSampler(object):
             tr["p_cr"] = self.cr.p_cr.copy()
             self.trace.append(tr)
         self.t += 1
+        if (self.algo == ALGO_DREAM and self.outlier_every > 0 and (k + 1) < self.burnin_gen
+                and (k + 1) % self.outlier_every == 0):
+            self._outlier_check()
+
+    def _outlier_check(self):
+        """DREAM outlier-chain reset (Vrugt et al. 2009; NOT in the reference, parity unpinned): chains whose
+        mean ln_like over the last half of their history is below Q1 - 2 IQR restart from the best chain."""
+        rows = len(self.ll_history)
+        omega = np.zeros(self.n_local)
+        for g in range(rows // 2, rows):            # sequential accumulation, as the kernel does
+            omega = omega + self.ll_history[g]
+        omega = omega / float(rows - rows // 2)
+        ll_all = self.ll[self.lo:self.hi].copy()
+        if self.world > 1:
+            omega = self.allgather(omega.reshape(-1, 1)).reshape(-1)
+            ll_all = self.allgather(ll_all.reshape(-1, 1)).reshape(-1)
+        else:
+            ll_all = self.ll.copy()
+        q1, q3 = np.percentile(omega, [25.0, 75.0])
+        cut = q1 - 2.0 * (q3 - q1)
+        best = int(np.argmax(omega))
+        out = np.nonzero(omega < cut)[0]
+        if out.size == 0:
+            return
+        self.X[out] = self.X[best]
+        for c in out:
+            if self.lo <= c < self.hi:
+                self.ll[c] = ll_all[best]
+                self.history[-1][c - self.lo] = self.X[best]
+                self.ll_history[-1][c - self.lo] = ll_all[best]
+        self.n_outlier_resets += int(out.size)
+        self.w_count = 0
+        self.w_mean[:] = 0
+        self.w_m2[:] = 0
 
     def _update(self, k, t, ids, pool_ids, epsilon, u_epsilon, gamma_kw, adapt_on, hist_len):
         seed, d = self.seed, self.d

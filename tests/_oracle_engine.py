@@ -25,7 +25,8 @@ class OracleEngine(object):
                 dist.all_gather(out, t)
                 return torch.cat(out, dim=0).numpy()
         kw = dict(gamma_scale=gamma_scale, burnin_gen=burnin_gen, n_cr_gen=n_cr_gen, n_cr=n_cr if algo == R.ALGO_DREAM else 1,
-                  del_pairs=del_pairs if algo == R.ALGO_DREAM else 1, p_snooker=p_snooker)
+                  del_pairs=del_pairs if algo == R.ALGO_DREAM else 1, p_snooker=p_snooker,
+                  outlier_every=outlier_every)
         self.s = R.OracleSampler(algo, n_chains, dim, target_id, target_params, seed, rank=rank, world=world_size,
                                  allgather=allgather, ll_fn=ll_fn, **kw)
         self._k = 0
@@ -80,7 +81,7 @@ class OracleEngine(object):
     def stats(self):
         return dict(local_n_accepted=self.s.local_n_accepted, local_n_rejected=self.s.local_n_rejected,
                     n_nan_alpha=self.s.n_nan, k_gen=self._k, t_abs=self.s.t, history_rows=len(self.s.history),
-                    n_outlier_resets=0, p_cr=self.s.cr.p_cr.copy(), delta_m=self.s.cr.delta_m.copy(),
+                    n_outlier_resets=self.s.n_outlier_resets, p_cr=self.s.cr.p_cr.copy(), delta_m=self.s.cr.delta_m.copy(),
                     n_cr_updates=self.s.cr.n_cr_updates.copy())
 
     def history_rows(self):

@@ -33,7 +33,7 @@ def _mix_params():
 def _pair(algo, N, d, target_id, params, seed, **kw):
     """(HipEngine, OracleSampler) with identical configuration."""
     eng = _engine(algo=algo, n_chains=N, dim=d, target_id=target_id, target_params=params, seed=seed, **kw)
-    okw = {k: v for k, v in kw.items() if k in ("gamma_scale", "del_pairs", "burnin_gen", "n_cr_gen", "n_cr", "p_snooker")}
+    okw = {k: v for k, v in kw.items() if k in ("gamma_scale", "del_pairs", "burnin_gen", "n_cr_gen", "n_cr", "p_snooker", "outlier_every")}
     ora = R.OracleSampler(algo, N, d, target_id, params, seed, **okw)
     return eng, ora
 
@@ -310,3 +310,25 @@ def test_errors_are_reported_not_thrown():
         eng.step(1)                 # begin_run first
     with pytest.raises(BpmError):
         eng.get_history(0, 5)
+
+
+def test_outlier_chain_reset_matches_oracle():
+    """DREAM outlier-chain reset (extension; absent from the reference): chains parked far in the tails are
+    detected by the IQR rule on their mean ln_like and restart from the best chain; engine == oracle."""
+    N, d = 32, 8
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, _mix_params(), 3, burnin_gen=200, n_cr_gen=10,
+                     outlier_every=20)
+    rs = np.random.RandomState(0)
+    X = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
+    X[5] = 30.0
+    X[17] = -25.0
+    eng.set_state(X); ora.set_state(X)
+    eng.begin_run(); eng.step(100); ora.run(100)
+    st = eng.stats()
+    assert st["n_outlier_resets"] == ora.n_outlier_resets >= 2
+    np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=1e-8, atol=1e-9)
+    H = eng.get_history()
+    assert np.array_equal(H[-1], eng.get_state())
+    np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-7)
+    assert np.all(eng.get_loglike() > -50)          # nobody is left in the tails
