@@ -163,28 +163,38 @@ __device__ __forceinline__ double box_muller(uint32_t w1, uint32_t w2) {
 // ---------------------------------------------------------------------------------
 template <int TARGET, int LPC, int DPL>
 struct Target;
+// Every target splits into load() -- fetch its constants, called first thing in the kernel so the misses
+// overlap with the draw arithmetic -- and eval() on registers only.
 
 // utils/d100_gauss.py:14-35, equicorrelated Gaussian in O(d):
 // ll = c0 - 0.5 (a S2 - b S1^2), z = y / sigma.  params [rho, c0, a, b, 1/sigma...]
 template <int LPC, int DPL>
 struct Target<TARGET_GAUSS, LPC, DPL> {
-    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
+    struct Consts { double is[DPL]; double c0, a, b; };
+    static __device__ __forceinline__ Consts load(int q, uint32_t dim, const double* tp) {
+        Consts k;
+        k.c0 = tp[1]; k.a = tp[2]; k.b = tp[3];
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) {
+            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+            k.is[s] = j < dim ? tp[4 + j] : 0.0;
+        }
+        return k;
+    }
+    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const Consts& k) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int u = 0; u < DPL / 2; ++u) {
-            const uint32_t j = 2u * (uint32_t)(q + u * LPC);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (j + e < dim) {
-                    const double z = v[2 * u + e] * tp[4 + j + e];
-                    s1 += z;
-                    s2 += z * z;
-                }
+        for (int s = 0; s < DPL; ++s) {
+            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
+            if (j < dim) {
+                const double z = v[s] * k.is[s];
+                s1 += z;
+                s2 += z * z;
             }
         }
         s1 = gsum<LPC>(s1);
         s2 = gsum<LPC>(s2);
-        return tp[1] - 0.5 * (tp[2] * s2 - tp[3] * s1 * s1);
+        return k.c0 - 0.5 * (k.a * s2 - k.b * s1 * s1);
     }
 };
 
@@ -192,7 +202,14 @@ struct Target<TARGET_GAUSS, LPC, DPL> {
 // params [lw1, lw2, (mx, my, 1/sx, 1/sy, rho, 1/(1-rho^2), ln_norm) x 2]
 template <int LPC, int DPL>
 struct Target<TARGET_MIXTURE, LPC, DPL> {
-    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
+    struct Consts { double p[16]; };
+    static __device__ __forceinline__ Consts load(int, uint32_t, const double* tp) {
+        Consts k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) k.p[i] = tp[i];
+        return k;
+    }
+    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const Consts& k) {
         double q0 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int u = 0; u < DPL / 2; ++u) {
@@ -200,7 +217,7 @@ struct Target<TARGET_MIXTURE, LPC, DPL> {
             if (j + 1 < dim) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double* p = tp + 2 + 7 * c;
+                    const double* p = k.p + 2 + 7 * c;
                     const double a = (v[2 * u] - p[0]) * p[2];
                     const double b = (v[2 * u + 1] - p[1]) * p[3];
                     const double qq = (a * a - 2.0 * p[4] * a * b + b * b) * p[5];
@@ -211,8 +228,8 @@ struct Target<TARGET_MIXTURE, LPC, DPL> {
         q0 = gsum<LPC>(q0);
         q1 = gsum<LPC>(q1);
         const double npairs = (double)(dim / 2);
-        const double c0 = tp[0] + npairs * tp[8] - 0.5 * q0;
-        const double c1 = tp[1] + npairs * tp[15] - 0.5 * q1;
+        const double c0 = k.p[0] + npairs * k.p[8] - 0.5 * q0;
+        const double c1 = k.p[1] + npairs * k.p[15] - 0.5 * q1;
         const double m = fmax(c0, c1);
         return m + log(exp(c0 - m) + exp(c1 - m));
     }
@@ -221,19 +238,21 @@ struct Target<TARGET_MIXTURE, LPC, DPL> {
 // utils/banana_rv.py:26-37; params [mu1, mu2, 1/s1, 1/s2, rho, 1/(1-rho^2), ln_norm, a, b]; d = 2, LPC = 1
 template <int LPC, int DPL>
 struct Target<TARGET_BANANA, LPC, DPL> {
-    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const double* tp) {
-        const double a = tp[7], b = tp[8];
+    struct Consts { double p[9]; };
+    static __device__ __forceinline__ Consts load(int, uint32_t, const double* tp) {
+        Consts k;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k.p[i] = tp[i];
+        return k;
+    }
+    static __device__ __forceinline__ double eval(const double* v, int, uint32_t, const Consts& k) {
+        const double a = k.p[7], b = k.p[8];
         const double x1 = v[0] / a;
         const double x2 = (v[1] - b * (x1 * x1 + a * a)) * a;
-        const double u = (x1 - tp[0]) * tp[2];
-        const double w = (x2 - tp[1]) * tp[3];
-        return tp[6] - 0.5 * (u * u - 2.0 * tp[4] * u * w + w * w) * tp[5];
+        const double u = (x1 - k.p[0]) * k.p[2];
+        const double w = (x2 - k.p[1]) * k.p[3];
+        return k.p[6] - 0.5 * (u * u - 2.0 * k.p[4] * u * w + w * w) * k.p[5];
     }
-};
-
-template <int LPC, int DPL>
-struct Target<TARGET_HOST, LPC, DPL> {
-    static __device__ __forceinline__ double eval(const double*, int, uint32_t, const double*) { return 0.0; }
 };
 
 // ---------------------------------------------------------------------------------
@@ -246,6 +265,7 @@ struct Work {
     double gamma;
     uint32_t acc_hi, acc_lo;   // words of the accept uniform
     double ll_cur;             // cached ln_like of the current state, fetched early
+    uint32_t acc_prev;         // this chain's accept counter, fetched early
     int cr_idx, d_prime, jump, snk;
     uint32_t maskbits;
 };
@@ -330,30 +350,71 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     // state-dependent loads first: they overlap with all the draw arithmetic below
     load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
     wk.ll_cur = a.ll[c - a.lo];
-    // one header block: (select16|gamma16, forced dim [DREAM] / snooker gamma [DE-MC], accept hi, accept lo)
-    const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
+    wk.acc_prev = a.acc_count[c - a.lo];
+    double pcr[MAX_CR];                        // p_cr (uniform pointer: one scalar load of the whole block)
+    if (DREAM) {
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) pcr[m] = a.cr_state[m];
+    }
+    // gamma table held across the wavefront's lanes: the lookup by d' is then a v_readlane, not a dependent load
+    double gtab[DPL];
+    if (DREAM && LPC == WAVE) {
+#pragma unroll
+        for (int u = 0; u < DPL; ++u) gtab[u] = ((uint32_t)(q + u * WAVE) <= dim) ? a.gamma_tab[q + u * WAVE] : 0.0;
+    }
+    const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
+    const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
+    // RL: one wavefront per chain and a compile-time pair count: the partner ids are resolved by lanes in
+    // parallel and handed over as scalars through v_readlane: no LDS, no barrier, scalar row addresses.
+    constexpr bool RL = (LPC == WAVE) && (NP > 0) && !FAST;
+    // MERGED (RL, one coordinate pair per lane, enough idle lanes): ONE Philox evaluation per lane serves
+    // everything -- lanes [0, npairs) draw their coordinate pair's block, lanes [npairs, npairs + 2NP) the
+    // pair-selection blocks, lane npairs + 2NP the chain's header block -- instead of three separate
+    // evaluations (one of them a 110-instruction scalar one) per wavefront.
+    const uint32_t npairs = (dim + 1u) >> 1;
+    const bool merged = RL && DPL == 2 && (npairs + 2u * (uint32_t)NP + 1u <= (uint32_t)WAVE);
+    u32x4 wpair[DPL / 2];
+    u32x4 h0;
+    Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
+    part.lds = s_part + cw * MAX_PARTNERS;
+    if (merged) {
+        const uint32_t uq = (uint32_t)q, hdr_lane = npairs + 2u * (uint32_t)NP;
+        const uint32_t pidx = uq - npairs;                       // partner index for lanes [npairs, hdr_lane)
+        const uint32_t slot = uq < npairs ? SLOT_DIM0 + uq : (uq < hdr_lane ? SLOT_PAIR0 + (pidx >> 2) : SLOT_HDR0);
+        const u32x4 wb = chain_block(a.seed, c, a.t, slot);
+        wpair[0] = wb;
+        h0.x = (uint32_t)__builtin_amdgcn_readlane((int)wb.x, hdr_lane);
+        h0.y = (uint32_t)__builtin_amdgcn_readlane((int)wb.y, hdr_lane);
+        h0.z = (uint32_t)__builtin_amdgcn_readlane((int)wb.z, hdr_lane);
+        h0.w = (uint32_t)__builtin_amdgcn_readlane((int)wb.w, hdr_lane);
+        uint32_t mine = 0;
+        if (uq >= npairs && uq < hdr_lane) {
+            const uint32_t p = pidx >> 1;
+            uint32_t ia, ib;
+            distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
+            mine = pos_to_chain(a, a.pool_off + ((pidx & 1) ? ib : ia));
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, npairs + i);
+    } else {
+        // one header block: (select16|gamma16, forced dim [DREAM] / snooker gamma [DE-MC], accept hi, accept lo)
+        h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
+#pragma unroll
+        for (int u = 0; u < DPL / 2; ++u) wpair[u] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)(q + u * LPC));
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < 2 * NP; ++i) part.r[i] = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)i, 2u * NP));
+        }
+        if (RL) {
+            uint32_t mine = 0;
+            if (q < 2 * NP) mine = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)q, 2u * NP));
+#pragma unroll
+            for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+        }
+    }
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
     const double u_sel = (double)(h0.x >> 16) * 1.52587890625e-05;      // CR select (DREAM) / snooker select (DE-MC)
     const double u_gam = (double)(h0.x & 0xFFFFu) * 1.52587890625e-05;  // gamma = 1 jump select
-
-    const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
-    const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
-    // RL: one wavefront per chain and a compile-time pair count: lanes 0..2NP-1 resolve one partner
-    // each (pair draw + Feistel walk in parallel), v_readlane hands the ids over as scalars: no LDS,
-    // no barrier, and the partner row addresses are scalar arithmetic.
-    constexpr bool RL = (LPC == WAVE) && (NP > 0) && !FAST;
-    Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
-    part.lds = s_part + cw * MAX_PARTNERS;
-    if (FAST) {
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) part.r[i] = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)i, 2u * NP));
-    }
-    if (RL) {
-        uint32_t mine = 0;
-        if (q < 2 * NP) mine = pos_to_chain(a, a.pool_off + partner_pos(a, c, (uint32_t)q, 2u * NP));
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
-    }
     if (!(FAST || RL) || snk_possible) {
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
@@ -372,10 +433,12 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         double cum = 0.0;
         int idx = (int)a.n_cr - 1;
         bool found = false;
-#pragma unroll 1
-        for (int m = 0; m < (int)a.n_cr; ++m) {          // first m with uc < cumsum(p_cr)[m]
-            cum += a.cr_state[m];
-            if (!found && uc < cum) { idx = m; thr = a.thr[m]; found = true; }   // k 2^-16 <= CR_m  <=>  k <= thr[m]
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) {               // first m with uc < cumsum(p_cr)[m]
+            if (m < (int)a.n_cr) {
+                cum += pcr[m];
+                if (!found && uc < cum) { idx = m; thr = a.thr[m]; found = true; }   // k 2^-16 <= CR_m  <=>  k <= thr[m]
+            }
         }
         if (!found) thr = a.thr[a.n_cr - 1];
         wk.cr_idx = idx;
@@ -387,7 +450,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         const uint32_t j0 = 2u * pi;
         eps_n[2 * u] = 0.0; eps_n[2 * u + 1] = 0.0; eps_u[2 * u] = 0.0; eps_u[2 * u + 1] = 0.0;
         if (j0 < dim) {
-            const u32x4 wj = chain_block(a.seed, c, a.t, SLOT_DIM0 + pi);
+            const u32x4 wj = wpair[u];
             const bool two = j0 + 1 < dim;
             if (a.epsilon > 0.0) {                                   // util.py:5-16
                 double n0, n1;
@@ -428,7 +491,15 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 
     if (DREAM) {
         // gamma (dream.py:61,77-80)
-        double gamma = a.gamma_tab[cnt];            // gamma_scale * 2.38 / sqrt(2 P d')
+        double gamma;                               // gamma_scale * 2.38 / sqrt(2 P d')
+        if (LPC == WAVE && (uint32_t)cnt < (uint32_t)(WAVE * DPL)) {
+            double gsel = gtab[0];
+#pragma unroll
+            for (int u = 1; u < DPL; ++u) gsel = ((cnt >> 6) == u) ? gtab[u] : gsel;
+            gamma = readlane_f64(gsel, cnt & 63);
+        } else {
+            gamma = a.gamma_tab[cnt];
+        }
         if (a.k % 5 == 0 && !(u_gam < 0.2)) { gamma = 1.0; wk.jump = 1; }
         wk.gamma = gamma;
         // sum over pairs of (A_p - B_p)  (dream.py:65-68,85-86), p = 0 first
@@ -572,7 +643,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     // accept bookkeeping without same-address atomics (8192 of them serialise at ~12 ns each):
     // every chain owns one counter, the host sums them (demc.py:143-150)
     if (q == 0) {
-        if (accepted) a.acc_count[li] += 1u;
+        if (accepted) a.acc_count[li] = wk.acc_prev + 1u;
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
     }
     double nv[DPL];
@@ -638,9 +709,10 @@ __global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
     const bool active = resolve_chain(a, w, c);
     if (LPC == WAVE && !active) return;          // whole wavefront idle
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
+    const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
     make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk);
-    const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, a.tparams);
+    const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     finish_update<ALGO, LPC, DPL>(a, c, active, q, wk, ll_prop);
 }
 
@@ -687,6 +759,7 @@ __global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
     load_row<LPC, DPL>(a.prop_buf + (uint64_t)(active ? w : 0u) * a.L.ld, q, a.L.ld, wk.p);
     wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
     wk.ll_cur = a.ll[c - a.lo];
+    wk.acc_prev = a.acc_count[c - a.lo];
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
@@ -843,7 +916,7 @@ __global__ __launch_bounds__(WAVE) void eval_ll_kernel(const double* X, uint32_t
     const bool active = w < n;
     double v[DPL];
     load_row<LPC, DPL>(X + (uint64_t)(active ? w : 0u) * ld, q, ld, v);
-    const double ll = Target<TARGET, LPC, DPL>::eval(v, q, dim, tparams);
+    const double ll = Target<TARGET, LPC, DPL>::eval(v, q, dim, Target<TARGET, LPC, DPL>::load(q, dim, tparams));
     if (active && q == 0) out[w] = ll;
 }
 
