@@ -24,6 +24,21 @@
 
 #include "philox.h"
 
+// Diagnostic build only (-DBPM_STAMPS): s_memtime stamps along one wavefront's critical path, written to
+// PhaseArgs::stamps (8 x u64 per work item).  Never compiled into the product library.
+#ifdef BPM_STAMPS
+#define BPM_STAMP(i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long _t;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        bpm_stamp[i] = _t;                                                                    \
+    } while (0)
+#else
+#define BPM_STAMP(i) do { } while (0)
+#endif
+
 namespace bpm {
 
 constexpr int ALGO_DEMC = 0, ALGO_DREAM = 1;
@@ -89,6 +104,7 @@ struct PhaseArgs {
     const uint32_t* inv_tab;    // [N] its inverse, chain id -> position
     const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
+    unsigned long long* stamps;  // diagnostic build only
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
@@ -339,7 +355,7 @@ __device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c)
 // ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
 template <int ALGO, int LPC, int DPL, int NP>
 __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
-                                              uint32_t* s_part, Work<DPL>& wk) {
+                                              uint32_t* s_part, Work<DPL>& wk, unsigned long long* bpm_stamp = nullptr) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
 #ifndef BPM_SCALAR_PARTNERS
 #define BPM_SCALAR_PARTNERS 0   // measured: 19.8 us/generation with lane-parallel partners vs 25.9 all-scalar (cfg2)
@@ -387,6 +403,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         h0.y = (uint32_t)__builtin_amdgcn_readlane((int)wb.y, hdr_lane);
         h0.z = (uint32_t)__builtin_amdgcn_readlane((int)wb.z, hdr_lane);
         h0.w = (uint32_t)__builtin_amdgcn_readlane((int)wb.w, hdr_lane);
+        BPM_STAMP(2);
         uint32_t mine = 0;
         if (uq >= npairs && uq < hdr_lane) {
             const uint32_t p = pidx >> 1;
@@ -412,6 +429,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
         }
     }
+    BPM_STAMP(3);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
     const double u_sel = (double)(h0.x >> 16) * 1.52587890625e-05;      // CR select (DREAM) / snooker select (DE-MC)
     const double u_gam = (double)(h0.x & 0xFFFFu) * 1.52587890625e-05;  // gamma = 1 jump select
@@ -421,6 +439,19 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             s_part[cw * MAX_PARTNERS + idx] = pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
         __syncthreads();
     }
+
+    // partner rows requested as soon as their ids exist: their L2/MALL latency overlaps with the mask,
+    // jitter and gamma arithmetic below
+    constexpr int NPX = NP > 0 ? NP : 1;
+    double ra[NPX][DPL], rb[NPX][DPL];
+    if (DREAM && NP > 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {             // all 2 NP row loads in flight together
+            load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p)), q, ld, ra[p]);
+            load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p + 1)), q, ld, rb[p]);
+        }
+    }
+    BPM_STAMP(7);
 
     // ---- per-pair draws: one Philox block per coordinate pair
     double eps_n[DPL], eps_u[DPL];
@@ -505,12 +536,6 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         // sum over pairs of (A_p - B_p)  (dream.py:65-68,85-86), p = 0 first
         double sum[DPL];
         if (NP > 0) {
-            double ra[NP > 0 ? NP : 1][DPL], rb[NP > 0 ? NP : 1][DPL];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {             // all 2 NP row loads in flight together
-                load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p)), q, ld, ra[p]);
-                load_row<LPC, DPL>(row_ptr(a.L, part.get(2 * p + 1)), q, ld, rb[p]);
-            }
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
                 sum[s] = ra[0][s] - rb[0][s];
@@ -535,6 +560,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             const double jump = (1.0 + eps_u[s]) * gamma * sum[s] + eps_n[s];
             wk.p[s] = ((maskbits >> s) & 1u) ? (jump + wk.x[s]) : wk.x[s];
         }
+        BPM_STAMP(4);
         // CR statistic (dream.py:92-93,119-130): BEFORE the accept test, from the proposed jump
         if (a.adapt_on && a.cr_gate) {
             const uint32_t li = c - a.lo;
@@ -705,15 +731,29 @@ __global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
     const int lane = threadIdx.x;
     const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
     const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+#ifdef BPM_STAMPS
+    unsigned long long bpm_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    BPM_STAMP(0);
+#endif
     uint32_t c;
     const bool active = resolve_chain(a, w, c);
     if (LPC == WAVE && !active) return;          // whole wavefront idle
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
+#ifdef BPM_STAMPS
+    bpm_stamp[1] = 0; BPM_STAMP(1);
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, bpm_stamp);
+#else
     make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk);
+#endif
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
+    BPM_STAMP(5);
     finish_update<ALGO, LPC, DPL>(a, c, active, q, wk, ll_prop);
+    BPM_STAMP(6);
+#ifdef BPM_STAMPS
+    if (a.stamps && lane == 0) for (int i = 0; i < 8; ++i) a.stamps[(uint64_t)w * 8 + i] = bpm_stamp[i];
+#endif
 }
 
 // Host-callback ln_like_fn: proposals out ...

@@ -175,6 +175,7 @@ struct bpm_sampler {
     int tab_K = 0;
     int tab_shuffle = -1;
     double* gamma_tab = nullptr;    // [dim + 1]
+    unsigned long long* stamps = nullptr;   // diagnostic build (-DBPM_STAMPS) only
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
     // run state
@@ -584,6 +585,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
           if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
         a.gamma_tab = s->gamma_tab;
+        a.stamps = s->stamps;
         for (int m = 0; m < s->cfg.n_cr && m < MAX_CR; ++m)
             a.thr[m] = (uint32_t)std::floor(((double)(m + 1) / (double)s->cfg.n_cr) * 65536.0);   // dream.py:113
         a.seed = s->cfg.seed;
@@ -1075,3 +1077,19 @@ extern "C" int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uin
     }
     return 0;
 }
+
+#ifdef BPM_STAMPS
+// diagnostic build only: per-work-item s_memtime stamps of the LAST launched phase kernel
+extern "C" int bpm_debug_stamps(bpm_handle_t s, unsigned long long* out, int64_t n_items) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->stamps) {
+        HIPCK(hipMalloc(reinterpret_cast<void**>(&s->stamps), (size_t)s->n_local * 8 * sizeof(unsigned long long)));
+        HIPCK(hipMemset(s->stamps, 0, (size_t)s->n_local * 8 * sizeof(unsigned long long)));
+        return 0;
+    }
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (out) HIPCK(hipMemcpy(out, s->stamps, (size_t)n_items * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostic (never part of the product): per-wavefront s_memtime timeline of the update kernel, from a
+library built with -DBPM_STAMPS (build_variants/libbipymc_stamps.so).  Shares, not absolute times."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bipymc_amd import _lib as L          # noqa: E402
+L.LIB_PATH = os.path.join(ROOT, "build_variants", "libbipymc_stamps.so")
+from bipymc_amd.engine import HipEngine   # noqa: E402
+from bipymc_amd.utils import d100_gauss   # noqa: E402
+
+tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
+for N in (1024, 8192, 65536):
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=1, burnin_gen=0)
+    lib = e.lib
+    lib.bpm_debug_stamps.restype = C.c_int
+    lib.bpm_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    e.set_state(np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0))
+    L.check(lib.bpm_debug_stamps(e._h, None, 0))        # allocate
+    e.begin_run()
+    e.step(30)
+    n = N // 2
+    out = np.zeros((n, 8), dtype=np.uint64)
+    L.check(lib.bpm_debug_stamps(e._h, out.ctypes.data_as(C.c_void_p), n))
+    t = out.astype(np.float64)
+    ok = t[:, 6] > 0
+    t = t[ok]
+    t0 = t[:, 0].min()
+    names = ["entry", "c known", "philox+header", "partner ids", "proposal (rows in)", "ll reduced", "end"]
+    print("N=%d  waves=%d  (s_memtime ticks = shader cycles; 100 MHz realtime not used)" % (N, t.shape[0]))
+    print("   wave start spread: median %.0f  p99 %.0f cycles after first" % (np.median(t[:, 0] - t0), np.percentile(t[:, 0] - t0, 99)))
+    prev = t[:, 0]
+    for i in range(1, 7):
+        dt = t[:, i] - prev
+        print("   %-20s median %7.0f  p90 %7.0f cycles" % (names[i], np.median(dt), np.percentile(dt, 90)))
+        prev = t[:, i]
+    life = t[:, 6] - t[:, 0]
+    print("   wave lifetime        median %7.0f  p90 %7.0f ; kernel span %.0f cycles" % (np.median(life), np.percentile(life, 90), t[:, 6].max() - t0))
+    e.close()
