@@ -597,8 +597,12 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.n_upd = ph == 0 ? a_n : b_n;
         a.pool_off = ph == 0 ? b_off : a_off;
         a.M = ph == 0 ? b_n : a_n;
-        a.mode = s->world == 1 ? 0u : 1u;
-        a.n_items = s->world == 1 ? a.n_upd : s->n_local;
+        // mode 1 (work item = local chain, filtered by its position) is what world_size > 1 uses;
+        // BPM_FORCE_MODE1 selects it on one GPU so the sharded kernel path can be tested there
+        static const bool force_mode1 = getenv("BPM_FORCE_MODE1") != nullptr;
+        const bool by_chain = s->world > 1 || force_mode1;
+        a.mode = by_chain ? 1u : 0u;
+        a.n_items = by_chain ? s->n_local : a.n_upd;
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;

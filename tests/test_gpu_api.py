@@ -208,3 +208,40 @@ def test_rccl_one_rank_communicator():
         res.append((e.get_state(), e.stats()["p_cr"]))
         e.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_sharded_kernel_path_on_one_gpu():
+    """world_size > 1 launches one work item per LOCAL chain and filters by the chain's position in the
+    shuffle order (inverse table); forcing that path on one GPU must reproduce the position-ordered path
+    bit for bit, for every kernel shape."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+from bipymc_amd.utils import d100_gauss, banana_rv, mixture_nd
+out = []
+for spec, algo, N, kw in ((d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 96, dict(burnin_gen=6, n_cr_gen=2)),
+                          (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 101, dict(burnin_gen=6, n_cr_gen=2, del_pairs=2)),
+                          (banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 77, dict(p_snooker=0.2))):
+    tid, tp, d = spec
+    e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, **kw)
+    e.set_state(np.random.RandomState(0).normal(size=(N, d)) + 1.0)
+    e.begin_run(); e.step(15)
+    out.append(e.get_state()); out.append(np.array([e.stats()["local_n_accepted"]], dtype=float)); out.append(e.stats()["p_cr"])
+np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
+'''
+    import tempfile
+    res = []
+    for force in (False, True):
+        env = dict(os.environ)
+        env.pop("BPM_FORCE_MODE1", None)
+        if force:
+            env["BPM_FORCE_MODE1"] = "1"
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npy")
+            subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
+            res.append(np.load(f))
+    assert np.array_equal(res[0], res[1])
