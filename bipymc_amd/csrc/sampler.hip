@@ -178,6 +178,7 @@ struct bpm_sampler {
     unsigned long long* stamps = nullptr;   // diagnostic build (-DBPM_STAMPS) only
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
+    bool local_group = false;     // test mode: ranks are handles of ONE process, exchanged by device copies
     // run state
     bpm_run_opts_t opts{};
     bool run_open = false;
@@ -403,6 +404,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         CKD(dev_alloc(&s->ids_buf, s->n_local));
     }
     if (s->world > 1 && !cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
+    // Test mode: a uid starting with "BPMLOCAL" makes the ranks of a world handles of ONE process on one GPU;
+    // bpm_local_group_step drives them in lock-step and does the all-gather with device copies.  It runs the
+    // very kernels, layouts and host logic of a multi-GPU run (everything but RCCL) where only one GPU exists.
+    if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMLOCAL", 8) == 0) {
+        s->local_group = true;
+    } else
     if (cfg->nccl_uid) {      // world_size == 1 with a uid: a one-rank communicator (exercises the RCCL path on one GPU)
         CKD(load_rccl());
         ncclUniqueId id;
@@ -708,9 +715,46 @@ static int run_generation_fused(bpm_sampler* s, int64_t n_ahead) {
     return finish_generation(s);
 }
 
+// Lock-step driver of a local group (see bpm_create): handles[r] = rank r of R, all on one GPU.
+extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens) {
+    if (!handles || R < 1) return fail("bpm_local_group_step: bad argument");
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        CK(check_handle(s));
+        if (!s->local_group || (int)s->world != R || (int)s->rank != r) return fail("bpm_local_group_step: handles are not ranks 0..R-1 of one local group");
+        if (!s->run_open) return fail("bpm_local_group_step: call bpm_begin_run on every rank first");
+        if (s->cfg.outlier_every > 0) return fail("bpm_local_group_step: outlier detection is not emulated");
+        if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    }
+    bpm_sampler* s0 = handles[0];
+    CK(set_device(s0));
+    PhaseLaunch fn = pick_fused(s0);
+    if (!fn) return fail("bpm_local_group_step: device targets only");
+    for (int64_t g = 0; g < n_gens; ++g) {
+        for (int r = 0; r < R; ++r) CK(prepare_generation(handles[r], n_gens - g));
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int r = 0; r < R; ++r)
+                if (handles[r]->cur_args[ph].n_items > 0) fn(handles[r]->cur_args[ph], handles[r]->stream);
+            HIPCK(hipGetLastError());
+            for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
+            // the all-gather: rank r's block goes into every other rank's replica
+            for (int r = 0; r < R; ++r)
+                for (int o = 0; o < R; ++o)
+                    if (o != r)
+                        HIPCK(hipMemcpyAsync(handles[o]->G + (uint64_t)r * s0->L.blk, handles[r]->G + (uint64_t)r * s0->L.blk,
+                                             (size_t)s0->L.blk * sizeof(double), hipMemcpyDeviceToDevice, handles[r]->stream));
+            for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
+        }
+        for (int r = 0; r < R; ++r) CK(finish_generation(handles[r]));
+    }
+    for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
+    return 0;
+}
+
 extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     CK(check_handle(s));
     CK(set_device(s));
+    if (s->local_group) return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step");
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));

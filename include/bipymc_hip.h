@@ -137,6 +137,10 @@ int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms);
  * count (bench.py prices the roofline with it). n_gens <= 4096. */
 int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);
 int bpm_synchronize(bpm_handle_t h);
+/* Test hook for the world_size > 1 path on ONE GPU: create R handles with rank = 0..R-1, world_size = R and a
+ * nccl_uid that starts with "BPMLOCAL" (no RCCL involved); this call advances all of them n_gens generations
+ * in lock-step, doing the per-half-generation all-gather (demc.py:93-94,116-117) with device copies. */
+int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop

@@ -245,3 +245,55 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
             res.append(np.load(f))
     assert np.array_equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8", "demc_banana_snooker", "dream_gauss7_pairs2"])
+@pytest.mark.parametrize("R", [2, 4])
+def test_multi_rank_equals_single_rank_on_device(case, R):
+    """The world_size > 1 device path (rank blocks of the exchange buffer, per-rank history / ln_like /
+    Welford / accept counters, local-chain launch mode, CR statistics travelling in the gathered block)
+    emulated with R handles on ONE GPU (bpm_local_group_step; the RCCL all-gather replaced by device
+    copies): chain histories and p_cr must equal the single-rank run bit for bit."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    if case == "dream_gauss100":
+        spec, algo, N, kw = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 64, dict(burnin_gen=8, n_cr_gen=3)
+    elif case == "dream_mix8":
+        spec, algo, N, kw = mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 48, dict(burnin_gen=8, n_cr_gen=3)
+    elif case == "demc_banana_snooker":
+        spec, algo, N, kw = banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 40, dict(p_snooker=0.3)
+    else:
+        spec, algo, N, kw = d100_gauss.Gauss_100D(dim=7)._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=20, n_cr_gen=2, del_pairs=2)
+    tid, tp, d = spec
+    G = 14
+    x0 = np.random.RandomState(3).normal(size=(N, d)) + 0.5
+    one = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
+    one.set_state(x0)
+    one.begin_run(flip=0.4)
+    one.step(G)
+    H1 = one.get_history()                                    # (G+1, N, d)
+    st1 = one.stats()
+
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run(flip=0.4)
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    HR = np.concatenate([e.get_history() for e in ranks], axis=1)      # ranks own contiguous id blocks (demc.py:39)
+    assert HR.shape == H1.shape
+    assert np.array_equal(HR, H1)
+    for e in ranks:
+        assert np.array_equal(e.get_state(), one.get_state())          # every replica is complete and identical
+        st = e.stats()
+        np.testing.assert_array_equal(st["p_cr"], st1["p_cr"])
+        np.testing.assert_array_equal(st["n_cr_updates"], st1["n_cr_updates"])
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == st1["local_n_accepted"]
+    lls = np.concatenate([e.get_loglike() for e in ranks])
+    assert np.array_equal(lls, one.get_loglike())
+    with pytest.raises(L.BpmError):
+        ranks[0].step(1)                                               # local-group ranks are not driven individually
