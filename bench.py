@@ -36,27 +36,42 @@ BYTES_PER_UPDATE = 8 * DIM * (2 * DEL_PAIRS + 3) + 16          # 7216
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (NumPy restatement of the reference algorithm, oracle/sampler_ref.py) timed on
-    this host on a bounded sample of the same workload: N=8192, d=100, steady state."""
+def cpu_baseline(seconds_budget=15.0):
+    """The CPU oracle timed on this host on a bounded sample of the same workload (N=8192, d=100, steady
+    state): the plain-C + OpenMP restatement (oracle/csrc/dream_ref.c, checked against the NumPy oracle in
+    tests/test_oracle_c.py) on the box's CPU share, and the NumPy oracle (1 process) for reference."""
+    from oracle import dream_ref_c as CR
     from oracle import sampler_ref as R
     params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(DIM) + 1.0))
+    rs = np.random.RandomState(0)
+    X = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, 1))
+                                         + np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, DIM)))
+    threads = max(1, min(16, os.cpu_count() or 1, CR.max_threads()))      # a one-GPU box's CPU share is 16 cores
+    out = {}
+    for label, nt in (("c1", 1), ("cN", threads)):
+        Xc = X.copy()
+        ll = R.ll_gauss_equicorr(Xc, params)
+        CR.dream_run(Xc, ll, params, 42, 0, 0, 2, del_pairs=DEL_PAIRS, n_threads=nt)     # warm-up
+        gens, el, t0 = 0, 0.0, time.perf_counter()
+        while el < seconds_budget / 3 and gens < 2000:
+            CR.dream_run(Xc, ll, params, 42, 2 + gens, 2 + gens, 10, del_pairs=DEL_PAIRS, n_threads=nt)
+            gens += 10
+            el = time.perf_counter() - t0
+        out[label] = (CHAINS_PER_GPU * gens / el, gens, el)
     ora = R.OracleSampler(R.ALGO_DREAM, CHAINS_PER_GPU, DIM, R.TARGET_GAUSS_EQUICORR, params, 42,
                           del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN)
-    X = np.random.RandomState(0).normal(size=(CHAINS_PER_GPU, DIM)) * np.sqrt(np.arange(DIM) + 1.0)
     ora.set_state(X)
-    ora.run(1)                                                  # warm-up
-    t0 = time.perf_counter()
-    gens = 0
-    while True:
+    ora.run(1)
+    gens, el, t0 = 0, 0.0, time.perf_counter()
+    while el < seconds_budget / 3 and gens < 200:
         ora.run(1)
         gens += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or gens >= 200:
-            break
-    return dict(value=CHAINS_PER_GPU * gens / el, unit="chain-updates/s", cores=1, kind="port",
-                sample="%d generations of DREAM d=100 n_chains=8192 (oracle/sampler_ref.py, NumPy, 1 process) in %.1f s; "
-                       "host has %d cores" % (gens, el, os.cpu_count() or 0))
+    return dict(value=out["cN"][0], unit="chain-updates/s", cores=threads, kind="port",
+                sample="%d generations of DREAM d=100 n_chains=8192 in %.1f s with oracle/csrc/dream_ref.c on %d OpenMP threads "
+                       "(1 thread: %.3g chain-updates/s; NumPy oracle, 1 process: %.3g chain-updates/s over %d generations); "
+                       "host has %d cores" % (out["cN"][1], out["cN"][2], threads, out["c1"][0],
+                                              CHAINS_PER_GPU * gens / el, gens, os.cpu_count() or 0))
 
 
 def main():
