@@ -169,7 +169,9 @@ def _check_generation(eng, ora, N, d, dream, n_part):
     # ---- floats: 1e-12 relative (libm + reduction order only)
     np.testing.assert_allclose(tr["ll_prop"], exp["ll_prop"], rtol=RTOL_STEP, atol=max(1e-12, 1e3 * atol_state))
     np.testing.assert_allclose(tr["alpha"], exp["alpha"], rtol=1e-8, atol=1e-300)   # exp() of an O(100) difference
-    np.testing.assert_allclose(tr["delta"], exp["delta"], rtol=1e-10)
+    # delta divides by the chain's own history variance: for a chain that has barely moved this is ~1e-30 and
+    # amplifies the (1e-19 absolute) float32-jitter difference between device and oracle
+    np.testing.assert_allclose(tr["delta"], exp["delta"], rtol=1e-6)
     X1 = eng.get_state()
     np.testing.assert_allclose(X1, ora.X, rtol=RTOL_STEP, atol=atol_state)
     np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=RTOL_STEP, atol=max(1e-12, 1e3 * atol_state))
@@ -332,3 +334,28 @@ def test_outlier_chain_reset_matches_oracle():
     assert np.array_equal(H[-1], eng.get_state())
     np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-7)
     assert np.all(eng.get_loglike() > -50)          # nobody is left in the tails
+
+
+@pytest.mark.parametrize("N,d,P_,n_cr", [(4, 1, 1, 1), (5, 3, 1, 2), (4, 100, 1, 3), (7, 2, 3, 8), (23, 9, 10, 3),
+                                         (6, 512, 2, 3), (11, 511, 3, 3), (64, 114, 3, 3), (64, 116, 3, 3), (16, 128, 3, 5)])
+def test_dream_edge_shapes(N, d, P_, n_cr):
+    """smallest populations (pool of two), odd N (unequal pools), dim 1, padded odd dims, the largest dim,
+    del_pairs up to 10, n_cr 1..8, and the dims around the merged-Philox lane budget (114 / 116)."""
+    if 2 * P_ > 0 and (N // 2) < 2:
+        pytest.skip("pool too small")
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 99, del_pairs=P_, burnin_gen=6,
+                     n_cr_gen=2, n_cr=n_cr)
+    X = np.random.RandomState(1).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _start(eng, ora, X)
+    for g in range(8):
+        _check_generation(eng, ora, N, d, True, 2 * P_)
+    np.testing.assert_allclose(eng.stats()["p_cr"], ora.cr.p_cr, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,d", [(4, 1), (5, 2), (6, 3), (9, 100), (8, 300)])
+def test_demc_edge_shapes(N, d):
+    eng, ora = _pair(R.ALGO_DEMC, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 98, p_snooker=0.5)
+    X = np.random.RandomState(2).normal(size=(N, d))
+    _start(eng, ora, X)
+    for g in range(11):
+        _check_generation(eng, ora, N, d, False, 5)
