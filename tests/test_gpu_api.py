@@ -297,3 +297,19 @@ def test_multi_rank_equals_single_rank_on_device(case, R):
     assert np.array_equal(lls, one.get_loglike())
     with pytest.raises(L.BpmError):
         ranks[0].step(1)                                               # local-group ranks are not driven individually
+
+
+def test_example_line_fit_host_callback():
+    """examples/ex_para_fit.py (the reference's examples/ex_para_fit.py:39-110 scenario): a Python lnprob
+    with ln_kwargs and a -inf prior, through both drop-in classes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ex_para_fit", os.path.join(os.path.dirname(__file__), "..", "examples", "ex_para_fit.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    from bipymc_amd import DeMcMpi, DreamMpi
+    for cls in (DreamMpi, DeMcMpi):
+        s, est, sig, truth = ex.run(cls, n_chains=12, n=12 * 2501)
+        assert not s.uses_device_target
+        # posterior of 50 noisy points: the truth lies within ~3 posterior sigmas
+        assert np.all(np.abs(est - np.array(truth)) < 3.5 * sig + 0.05), (est, sig, truth)
+        assert 0.02 < s.acceptance_fraction < 0.7
