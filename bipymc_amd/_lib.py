@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbipymc_hip.so")
 
 ABI_VERSION = 1
-ALGO_DEMC, ALGO_DREAM = 0, 1
+ALGO_DEMC, ALGO_DREAM, ALGO_DEMC_SYNC = 0, 1, 2
 TARGET_HOST_CALLBACK, TARGET_GAUSS_EQUICORR, TARGET_MIXTURE_PAIRS, TARGET_BANANA_2D = 0, 1, 2, 3
 MAX_CR = 8
 UID_BYTES = 128

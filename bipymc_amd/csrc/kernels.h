@@ -105,12 +105,14 @@ struct PhaseArgs {
     const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     unsigned long long* stamps;  // diagnostic build only
+    double* x_next;             // mode 2 (synchronous DE-MC): new states go here, the state matrix stays frozen
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
     uint32_t N, lo;
     uint32_t upd_off, n_upd, pool_off, M;   // position ranges in shuffle order
-    uint32_t mode;         // 0: work item = position (world == 1); 1: work item = local chain
+    uint32_t mode;         // 0: work item = position (world == 1); 1: work item = local chain filtered by its group;
+                           // 2: synchronous DE-MC (samplers.py:261-308): every local chain, pool = all OTHER chains
     uint32_t n_items;
     uint32_t algo;
     uint32_t P, n_cr;
@@ -335,7 +337,9 @@ __device__ __forceinline__ uint32_t partner_pos(const PhaseArgs& a, uint32_t c, 
         const u32x4 wb = chain_block(a.seed, c, a.t, SLOT_PAIR0 + (p >> 1));
         uint32_t ia, ib;
         distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
-        return (idx & 1) ? ib : ia;
+        uint32_t pos = (idx & 1) ? ib : ia;
+        if (a.mode == 2) pos += (pos >= c) ? 1u : 0u;      // np.delete(range(N), i) (samplers.py:274): skip the chain itself
+        return pos;
     }
     const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
     uint32_t iz, i1, i2;
@@ -409,7 +413,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             const uint32_t p = pidx >> 1;
             uint32_t ia, ib;
             distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, a.M, ia, ib);
-            mine = pos_to_chain(a, a.pool_off + ((pidx & 1) ? ib : ia));
+            uint32_t pos = (pidx & 1) ? ib : ia;
+            if (a.mode == 2) pos += (pos >= c) ? 1u : 0u;      // synchronous DE-MC: pool = all other chains
+            mine = pos_to_chain(a, a.pool_off + pos);
         }
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, npairs + i);
@@ -582,7 +588,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     } else {
         // DE-MC (demc.py:161-182)
         double gamma = a.gamma_demc;
-        if (a.k % 10 == 0 && !(u_gam < 0.1)) { gamma = 1.0; wk.jump = 1; }
+        if (a.mode != 2 && a.k % 10 == 0 && !(u_gam < 0.1)) { gamma = 1.0; wk.jump = 1; }   // demc.py:174-177 (not in samplers.py DeMc)
         wk.gamma = gamma;
         double ra[DPL], rb[DPL];
         const uint32_t ca = ((FAST || RL) && !snk_possible) ? part.get(0) : part.lds[0];
@@ -676,7 +682,11 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
 #pragma unroll
     for (int s = 0; s < DPL; ++s) nv[s] = accepted ? wk.p[s] : wk.x[s];
     const double new_ll = accepted ? ll_prop : ll_cur;
-    if (accepted) {
+    if (a.x_next) {
+        // synchronous generation (samplers.py:300-308 delayed_accept): updates are banked, applied after the launch
+        store_row<LPC, DPL>(a.x_next + (uint64_t)li * ld, q, ld, nv);
+        if (accepted && q == 0) a.ll[li] = new_ll;
+    } else if (accepted) {
         store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
         if (q == 0) a.ll[li] = new_ll;
     }
@@ -717,6 +727,8 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
     bool active = w < a.n_items;
     if (a.mode == 0) {
         c = pos_to_chain(a, a.upd_off + (active ? w : 0u));
+    } else if (a.mode == 2) {
+        c = a.lo + (active ? w : 0u);
     } else {
         c = a.lo + (active ? w : 0u);
         const uint32_t pos = chain_to_pos(a, c);

@@ -175,6 +175,7 @@ struct bpm_sampler {
     int tab_K = 0;
     int tab_shuffle = -1;
     double* gamma_tab = nullptr;    // [dim + 1]
+    double* x_next = nullptr;       // [n_local * ld] banked updates of a synchronous DE-MC generation
     unsigned long long* stamps = nullptr;   // diagnostic build (-DBPM_STAMPS) only
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
@@ -195,7 +196,7 @@ struct bpm_sampler {
 
 
 static PhaseLaunch pick_fused(const bpm_sampler* s) {
-    const int v = s->cfg.algo == BPM_ALGO_DEMC ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
+    const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
     switch (s->cfg.target_id) {
         case BPM_TARGET_GAUSS_EQUICORR: return g_fused_gauss[v][s->shape.idx];
         case BPM_TARGET_MIXTURE_PAIRS: return g_fused_mixture[v][s->shape.idx];
@@ -294,7 +295,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->x_next, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -308,7 +309,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (!cfg || !out) return fail("bpm_create: null argument");
     *out = nullptr;
     if (cfg->abi_version != BPM_ABI_VERSION) return fail("bpm_create: ABI version mismatch");
-    if (cfg->algo != BPM_ALGO_DEMC && cfg->algo != BPM_ALGO_DREAM) return fail("bpm_create: unknown algo");
+    if (cfg->algo != BPM_ALGO_DEMC && cfg->algo != BPM_ALGO_DREAM && cfg->algo != BPM_ALGO_DEMC_SYNC) return fail("bpm_create: unknown algo");
     if (cfg->n_chains < 4) return fail("bpm_create: n_chains >= 4 required (samplers.py:249)");
     if (cfg->dim < 1) return fail("bpm_create: dim >= 1 required");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail("bpm_create: bad rank/world_size");
@@ -344,7 +345,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     else if (tid != BPM_TARGET_HOST_CALLBACK) ok = false;
     if (!ok || (np > 0 && !cfg->target_params)) { delete s; return fail("bpm_create: target id / parameter block / dim mismatch"); }
     if (np > 0) s->tparams_h.assign(cfg->target_params, cfg->target_params + np);
-    if (cfg->algo == BPM_ALGO_DEMC) { s->cfg.del_pairs = 1; s->cfg.n_cr = 1; }
+    if (cfg->algo != BPM_ALGO_DREAM) { s->cfg.del_pairs = 1; s->cfg.n_cr = 1; }
+    if (cfg->algo == BPM_ALGO_DEMC_SYNC) s->cfg.p_snooker = 0.0;
 
 #define CKD(expr)                                   \
     do {                                            \
@@ -389,6 +391,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc(&s->perm_tab, (size_t)PERM_CHUNK * s->N));
     CKD(dev_alloc(&s->inv_tab, (size_t)PERM_CHUNK * s->N));
     CKD(dev_alloc(&s->gamma_tab, (size_t)s->dim + 1));
+    if (cfg->algo == BPM_ALGO_DEMC_SYNC) CKD(dev_alloc(&s->x_next, row_d));
     {
         std::vector<double> gt(s->dim + 1, 0.0);      // dream.py:61, same operation order as the reference
         for (uint32_t dp = 1; dp <= s->dim; ++dp)
@@ -543,7 +546,8 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
 static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     const bool dream = s->cfg.algo == BPM_ALGO_DREAM;
     const uint64_t t = (uint64_t)s->t_abs;
-    CK(ensure_perm_table(s, s->t_abs, n_ahead));
+    const bool sync = s->cfg.algo == BPM_ALGO_DEMC_SYNC;
+    if (!sync) CK(ensure_perm_table(s, s->t_abs, n_ahead));
     const bool flip = flip_draw(s->cfg.seed, t, s->opts.flip);
     const PermKey pk = make_perm_key(s->cfg.seed, t, s->N, s->opts.shuffle != 0);
     const uint32_t n_first = (s->N + 1) / 2, n_second = s->N - n_first;    // np.array_split: first gets ceil
@@ -621,6 +625,14 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.epsilon = s->opts.epsilon;
         a.u_epsilon = s->opts.u_epsilon;
         a.p_snooker = s->cfg.p_snooker;
+        if (sync) {      // samplers.py:261-308: one launch, every local chain against all other chains, updates banked
+            a.algo = (uint32_t)BPM_ALGO_DEMC;
+            a.mode = 2u;
+            a.n_items = ph == 0 ? s->n_local : 0u;
+            a.perm_tab = nullptr; a.inv_tab = nullptr; a.pk.on = 0u;
+            a.upd_off = 0; a.n_upd = s->N; a.pool_off = 0; a.M = s->N - 1;
+            a.x_next = s->x_next;
+        }
     }
     return 0;
 }
@@ -707,6 +719,14 @@ static int run_generation_fused(bpm_sampler* s, int64_t n_ahead) {
     CK(prepare_generation(s, n_ahead));
     PhaseLaunch fn = pick_fused(s);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
+    if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) {
+        fn(s->cur_args[0], s->stream);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(s->G + (uint64_t)s->rank * s->L.blk, s->x_next, (size_t)s->n_local * s->ld * sizeof(double),
+                             hipMemcpyDeviceToDevice, s->stream));      // apply the banked updates
+        CK(allgather_state(s));
+        return finish_generation(s);
+    }
     for (int ph = 0; ph < 2; ++ph) {
         if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
         CK(allgather_state(s));
@@ -724,6 +744,7 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
         if (!s->local_group || (int)s->world != R || (int)s->rank != r) return fail("bpm_local_group_step: handles are not ranks 0..R-1 of one local group");
         if (!s->run_open) return fail("bpm_local_group_step: call bpm_begin_run on every rank first");
         if (s->cfg.outlier_every > 0) return fail("bpm_local_group_step: outlier detection is not emulated");
+        if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_local_group_step: synchronous DE-MC mode is not emulated");
         if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     }
     bpm_sampler* s0 = handles[0];
@@ -786,6 +807,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     CK(set_device(s));
     if (!s->run_open) return fail("bpm_step_profiled: call bpm_begin_run first");
     if (s->cfg.target_id == BPM_TARGET_HOST_CALLBACK) return fail("bpm_step_profiled: device targets only");
+    if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_profiled: not available for the synchronous DE-MC mode");
     if (n_gens <= 0 || n_gens > 4096) return fail("bpm_step_profiled: 1 <= n_gens <= 4096");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     std::vector<hipEvent_t> ev((size_t)n_gens * 4);
@@ -946,6 +968,14 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
     HIPCK(hipMemcpyAsync(s->aux_buf, aux.data(), aux.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (a.n_items > 0) g_commit[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
+    if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) {       // one propose/commit per generation: apply the banked updates
+        HIPCK(hipMemcpyAsync(s->G + (uint64_t)s->rank * s->L.blk, s->x_next, (size_t)s->n_local * s->ld * sizeof(double),
+                             hipMemcpyDeviceToDevice, s->stream));
+        CK(allgather_state(s));
+        HIPCK(hipStreamSynchronize(s->stream));
+        s->proposed = false;
+        return finish_generation(s);
+    }
     CK(allgather_state(s));
     HIPCK(hipStreamSynchronize(s->stream));
     s->proposed = false;

@@ -42,6 +42,8 @@ extern "C" {
 /* algo */
 #define BPM_ALGO_DEMC 0  /* bipymc/demc.py:153-196 */
 #define BPM_ALGO_DREAM 1 /* bipymc/dream.py:32-107 */
+#define BPM_ALGO_DEMC_SYNC 2 /* bipymc/samplers.py:237-308 serial DeMc with delayed_accept=True: all chains
+                              propose against the generation's starting states, updates banked; no a/b pools */
 
 /* target ids: which ln_like_fn is evaluated on the device */
 #define BPM_TARGET_HOST_CALLBACK 0  /* arbitrary Python ln_like_fn (samplers.py:36-43): propose/commit */

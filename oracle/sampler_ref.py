@@ -42,6 +42,7 @@ LN_2PI = math.log(2.0 * math.pi)
 
 ALGO_DEMC = 0
 ALGO_DREAM = 1
+ALGO_DEMC_SYNC = 2      # serial DeMc of samplers.py:237-308 with delayed_accept=True (banked, synchronous updates)
 
 TARGET_HOST = 0
 TARGET_GAUSS_EQUICORR = 1
@@ -382,6 +383,8 @@ class OracleSampler(object):
             self._generation(k, flip, shuffle, float(epsilon), float(u_epsilon), gamma)
 
     def _generation(self, k, flip_prob, shuffle, epsilon, u_epsilon, gamma_kw):
+        if self.algo == ALGO_DEMC_SYNC:
+            return self._generation_sync(k, epsilon, gamma_kw)
         t, N = self.t, self.N
         flip = P.flip_draw(self.seed, t, flip_prob)
         order = P.shuffle_idx(self.seed, t, N, shuffle)
@@ -455,6 +458,46 @@ class OracleSampler(object):
         self.w_count = 0
         self.w_mean[:] = 0
         self.w_m2[:] = 0
+
+    def _generation_sync(self, k, epsilon, gamma_kw):
+        """samplers.py:268-308 with delayed_accept=True: every chain proposes from the states at the start
+        of the generation, pair drawn from all OTHER chains (np.delete, :274-275), no gamma jumps, updates banked."""
+        t, N, d, seed = self.t, self.N, self.d, self.seed
+        ids = np.arange(self.lo, self.hi)
+        n = ids.size
+        h0 = P.chain_block(seed, ids, t, P.SLOT_HDR0)
+        npairs = (d + 1) // 2
+        wd = P.chain_block(seed, ids[:, None], t, P.SLOT_DIM0 + np.arange(npairs)[None, :])
+        if epsilon > 0:
+            n0, n1 = P.box_muller_pair_f32(wd[..., 2], wd[..., 3])
+            eps_n = epsilon * np.stack([n0, n1], axis=-1).reshape(n, 2 * npairs)[:, :d]
+        else:
+            eps_n = np.zeros((n, d))
+        wp = P.chain_block(seed, ids, t, P.SLOT_PAIR0)
+        ia, ib = P.distinct_pair(wp[:, 0], wp[:, 1], N - 1)
+        ia = ia + (ia >= ids)                        # positions in np.delete(range(N), i)
+        ib = ib + (ib >= ids)
+        gamma = demc_gamma_base(d, gamma_kw)
+        cur = self.X[ids]
+        prop = demc_proposal(cur, self.X[ia], self.X[ib], np.full(n, gamma), eps_n)
+        ll_prop = self._ll(prop)
+        alpha = mut_prop_ratio(self.ll[ids], ll_prop)
+        accepted = metropolis_accept(alpha, P.u01_53(h0[:, 2], h0[:, 3]))
+        new_local = np.where(accepted[:, None], prop, cur)
+        self.ll[ids] = np.where(accepted, ll_prop, self.ll[ids])
+        na = int(np.count_nonzero(accepted))
+        self.local_n_accepted += na
+        self.local_n_rejected += n - na
+        self.n_nan += int(np.count_nonzero(np.isnan(alpha)))
+        if self.world > 1:
+            self.X = self.allgather(new_local)
+        else:
+            self.X = new_local.copy()
+        if self.trace is not None:
+            self.trace.append(dict(pa=ia, pb=ib, accepted=accepted, alpha=alpha, ll_prop=ll_prop))
+        self.history.append(self.X[self.lo:self.hi].copy())
+        self.ll_history.append(self.ll[self.lo:self.hi].copy())
+        self.t += 1
 
     def _update(self, k, t, ids, pool_ids, epsilon, u_epsilon, gamma_kw, adapt_on, hist_len):
         seed, d = self.seed, self.d

@@ -313,3 +313,31 @@ def test_example_line_fit_host_callback():
         # posterior of 50 noisy points: the truth lies within ~3 posterior sigmas
         assert np.all(np.abs(est - np.array(truth)) < 3.5 * sig + 0.05), (est, sig, truth)
         assert 0.02 < s.acceptance_fraction < 0.7
+
+
+def test_serial_api_demc_class():
+    """bipymc_amd.samplers.DeMc == the reference's serial `DeMc` surface (samplers.py:237-336;
+    examples/ex_line_fit.py:77 style): run_mcmc(n, theta_0), param_est, super_chain, acceptance_fraction."""
+    from bipymc_amd.samplers import DeMc
+    from bipymc_amd.utils import banana_rv
+    np.random.seed(3)
+    banana = banana_rv.Banana_2D()
+    s = DeMc(banana.ln_like, n_chains=64)
+    s.run_mcmc(64 * 3001, np.zeros(2), varepsilon=1e-4)
+    mean, std, chain = s.param_est(n_burn=64 * 1000)
+    assert s.super_chain.shape == (64 * 3001, 2) and chain.shape == (64 * 2001, 2)
+    assert abs(mean[0]) < 0.1 and abs(mean[1] - 1.16125) < 0.1                 # SURVEY a13 analytic moments
+    assert abs(std[0] ** 2 - 1.3225) < 0.15
+    assert 0.1 < s.acceptance_fraction < 0.6
+    assert s.n_accepted + s.n_rejected == 64 * 3000 + 1                        # samplers.py:30-31: starts at 1/0
+    assert np.array_equal(s.super_chain[5::64], s.am_chains[5].chain) and np.array_equal(s.current_pos, s.am_chains[0].chain[-1])
+    # a Python callable with kwargs takes the host path; a second run re-initialises the chains (samplers.py:266-267)
+    t = DeMc(lambda th, s2=1.0: -0.5 * float(np.sum(th ** 2)) / s2, n_chains=16, ln_kwargs={"s2": 4.0})
+    t.run_mcmc(16 * 1501, np.zeros(3), varepsilon=1e-2)
+    m, sd, _ = t.param_est(16 * 500)
+    assert np.all(np.abs(m) < 0.35) and np.all(np.abs(sd - 2.0) < 0.35)
+    acc1 = t.n_accepted
+    t.run_mcmc(16 * 11, np.ones(3))
+    assert t.super_chain.shape == (16 * 11, 3) and t.n_accepted >= acc1
+    with pytest.raises(NotImplementedError):
+        t.run_mcmc(100, np.zeros(3), delayed_accept=False)

@@ -359,3 +359,33 @@ def test_demc_edge_shapes(N, d):
     _start(eng, ora, X)
     for g in range(11):
         _check_generation(eng, ora, N, d, False, 5)
+
+
+@pytest.mark.parametrize("N,d,tgt", [(8, 2, "banana"), (64, 2, "banana"), (33, 16, "gauss"), (10, 100, "gauss"), (5, 3, "gauss")])
+def test_demc_sync_mode_parity(N, d, tgt):
+    """Synchronous DE-MC (serial `DeMc` of samplers.py:237-308, delayed_accept=True): pair from all OTHER
+    chains, updates banked, no gamma jumps -- engine vs oracle, generation by generation."""
+    if tgt == "banana":
+        tid, params = R.TARGET_BANANA_2D, R.banana_params()
+    else:
+        tid, params = R.TARGET_GAUSS_EQUICORR, _gauss_params(d)
+    eng, ora = _pair(R.ALGO_DEMC_SYNC, N, d, tid, params, 31)
+    X = np.random.RandomState(6).normal(size=(N, d)) + 0.3
+    eng.set_state(X); ora.set_state(X)
+    eng.set_trace(True)
+    eng.begin_run(epsilon=1e-4, gamma=0.7, shuffle=False, flip=0.0)
+    ora.local_n_accepted, ora.local_n_rejected = 0, 1
+    for g in range(12):
+        ora.trace = []
+        eng.step(1)
+        ora._generation(g, 0.0, False, 1e-4, 1e-2, 0.7)
+        tr = eng.get_trace()
+        assert np.array_equal(tr["partners"][:, 0], ora.trace[-1]["pa"]) and np.array_equal(tr["partners"][:, 1], ora.trace[-1]["pb"])
+        assert np.all(tr["partners"][:, 0] != np.arange(N)) and np.all(tr["partners"][:, 1] != np.arange(N))
+        assert np.all(tr["partners"][:, 0] != tr["partners"][:, 1])
+        assert np.array_equal(tr["accepted"].astype(bool), ora.trace[-1]["accepted"])
+        assert not tr["jump"].any()
+        np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-12, atol=1e-9)     # epsilon = 1e-4 float32 jitter
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["history_rows"] == 13
+    np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-12, atol=1e-9)
