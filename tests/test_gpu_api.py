@@ -341,3 +341,63 @@ def test_serial_api_demc_class():
     assert t.super_chain.shape == (16 * 11, 3) and t.n_accepted >= acc1
     with pytest.raises(NotImplementedError):
         t.run_mcmc(100, np.zeros(3), delayed_accept=False)
+
+
+def test_posterior_moments_at_baseline_sizes():
+    """'Posterior moments within 1 % of reference / analytic values'  at the BASELINE sizes,
+    from the on-device moment reduction; starts are exact draws of the targets (stationary regime)."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    np.random.seed(5)
+
+    def moments(e, n_burn_rows):
+        cnt, s1, s2, sh = e.reduce_moments(n_burn_rows)
+        return sh + s1 / cnt, s2 / cnt - (s1 / cnt) ** 2
+
+    # cfg3: DE-MC, banana, N = 65536, snooker 0.1.  E = (0, 1.16125), Var = (1.3225, 1.25614) (SURVEY a13)
+    ban = banana_rv.Banana_2D()
+    tid, tp, d = ban._bpm_target_spec()
+    N = 65536
+    y1, y2 = ban.rvs(N)
+    e = HipEngine(algo=L.ALGO_DEMC, n_chains=N, dim=2, target_id=tid, target_params=tp, seed=1, p_snooker=0.1)
+    e.set_state(np.stack([y1, y2], axis=1))
+    e.begin_run(); e.step(400)
+    mean, var = moments(e, 100 * N)
+    assert abs(mean[0]) < 0.01 and abs(mean[1] - 1.16125) < 0.0117            # 1 % of the scale
+    assert abs(var[0] / 1.3225 - 1) < 0.01 and abs(var[1] / 1.25614 - 1) < 0.01
+    e.close()
+
+    # cfg2: DREAM, 100-D Gaussian, N = 8192: mean 0, var_i = i + 1
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=8192, dim=d, target_id=tid, target_params=tp, seed=2, burnin_gen=200, n_cr_gen=50)
+    e.set_state(g.rvs(8192))
+    e.begin_run(); e.step(1500)
+    mean, var = moments(e, 300 * 8192)
+    sig2 = np.arange(d) + 1.0
+    assert np.max(np.abs(mean) / np.sqrt(sig2)) < 0.03
+    assert abs(np.mean(var / sig2) - 1) < 0.01                                 # 1 % on the pooled variance
+    assert np.max(np.abs(var / sig2 - 1)) < 0.035                              # each coordinate: MC noise of the slow common mode
+    e.close()
+
+    # cfg5 (one GPU's share of the 8-D mixture, N = 32768) with CR adaptation and outlier reset on: per-axis
+    # moments inside each mode are those of the 2-D reference target: var 0.0625 around 0 and 2
+    m = mixture_nd.BimodeGauss_ND(8)
+    tid, tp, d = m._bpm_target_spec()
+    N = 32768
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=3, burnin_gen=300, n_cr_gen=50,
+                  outlier_every=50)
+    x0 = m.rvs(N)
+    x0[:7] = 40.0                                                              # a few chains parked in the far tail
+    e.set_state(x0)
+    e.begin_run(); e.step(600)
+    st = e.stats()
+    assert st["n_outlier_resets"] >= 7
+    X = e.get_state()
+    in0 = np.all(np.abs(X) < 1.6, axis=1)                                      # sigma = 0.25 per axis: 6.4 sigma boxes
+    in2 = np.all(np.abs(X - 2.0) < 1.6, axis=1) & ~in0
+    assert in0.sum() + in2.sum() == N                                          # everybody sits in one of the two modes
+    assert abs(in0.mean() - 0.25) < 0.02                                       # mode weights preserved (w = 0.25 / 0.75)
+    assert abs(X[in2].var(axis=0).mean() / 0.0625 - 1) < 0.02 and abs(X[in0].var(axis=0).mean() / 0.0625 - 1) < 0.03
+    e.close()
