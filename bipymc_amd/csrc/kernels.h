@@ -833,47 +833,75 @@ __global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
 // ---------------------------------------------------------------------------------
 constexpr int ADAPT_THREADS = 1024;
 __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state) {
-    __shared__ double s_d[ADAPT_THREADS];
-    __shared__ double s_n[ADAPT_THREADS];
+    __shared__ double s_d[ADAPT_THREADS / WAVE][MAX_CR], s_n[ADAPT_THREADS / WAVE][MAX_CR];
     __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
     const int tid = threadIdx.x;
     double acc_d[MAX_CR], acc_n[MAX_CR];
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
-    for (uint32_t c = tid; c < N; c += ADAPT_THREADS) {
-        const int idx = (int)*cridx_ptr(L, c);
-        const double dl = *delta_ptr(L, c);
+    constexpr int UNR = 8;                              // 8 independent load pairs in flight per thread
+    for (uint32_t base = tid; base < N; base += ADAPT_THREADS * UNR) {
+        int idx[UNR];
+        double dl[UNR];
 #pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) {
-            if (idx == m) { acc_d[m] += dl; acc_n[m] += 1.0; }
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t c = base + (uint32_t)u * ADAPT_THREADS;
+            idx[u] = c < N ? (int)*cridx_ptr(L, c) : -1;
+            dl[u] = c < N ? *delta_ptr(L, c) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) {
+                if (idx[u] == m) { acc_d[m] += dl[u]; acc_n[m] += 1.0; }
+            }
         }
     }
+    // fixed-order reduction: DPP sum inside each wavefront, then the 16 wavefront partials in wave order
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) {
         if (m < (int)n_cr) {                       // uniform
-            s_d[tid] = acc_d[m]; s_n[tid] = acc_n[m];
-            __syncthreads();
-            for (int o = ADAPT_THREADS / 2; o > 0; o >>= 1) {
-                if (tid < o) { s_d[tid] += s_d[tid + o]; s_n[tid] += s_n[tid + o]; }
-                __syncthreads();
-            }
-            if (tid == 0) { tot_d[m] = s_d[0]; tot_n[m] = s_n[0]; }
-            __syncthreads();
+            const double wd = gsum<WAVE>(acc_d[m]), wn = gsum<WAVE>(acc_n[m]);
+            if ((tid & (WAVE - 1)) == 0) { s_d[tid / WAVE][m] = wd; s_n[tid / WAVE][m] = wn; }
         }
     }
+    __syncthreads();
+    if (tid < (int)n_cr) {
+        double d = 0.0, n = 0.0;
+        for (int w = 0; w < ADAPT_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
+        tot_d[tid] = d; tot_n[tid] = n;
+    }
+    __syncthreads();
     if (tid == 0) {
-        double* p_cr = cr_state; double* delta_m = cr_state + MAX_CR; double* n_upd = cr_state + 2 * MAX_CR;
+        // the whole state in registers first (one burst of loads), written back once: the dependent
+        // read-modify-write chain through global memory was most of this kernel's 11 us
+        double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
         bool any = false;
-        for (uint32_t m = 0; m < n_cr; ++m) {
-            if (tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) {
+            if (m < (int)n_cr && tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
         }
         if (any) {
             uint32_t nz = 0;
-            for (uint32_t m = 0; m < n_cr; ++m) nz += n_upd[m] != 0.0 ? 1u : 0u;
-            if (nz == n_cr) for (uint32_t m = 0; m < n_cr; ++m) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && n_upd[m] != 0.0) ? 1u : 0u;
+            if (nz == n_cr) {
+#pragma unroll
+                for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
+            }
             double s = 0.0;
-            for (uint32_t m = 0; m < n_cr; ++m) s += p_cr[m];
-            for (uint32_t m = 0; m < n_cr; ++m) p_cr[m] = p_cr[m] / s;                              // dream.py:140
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) s += p_cr[m];
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) {
+                if (m < (int)n_cr) {
+                    cr_state[m] = p_cr[m] / s;                                                          // dream.py:140
+                    cr_state[MAX_CR + m] = delta_m[m];
+                    cr_state[2 * MAX_CR + m] = n_upd[m];
+                }
+            }
         }
     }
 }
@@ -990,10 +1018,16 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_partial_kernel(const doub
         double sa = 0.0, sb = 0.0;
         if (r < rpi && j < ld) {
             const double sh = shift[j];
-            for (uint64_t m = b0 + r; m < b1; m += rpi) {
-                const double v = H[m * ld + j] - sh;
-                sa += v;
-                sb += v * v;
+            constexpr int UNR = 8;                      // 8 independent row loads in flight per thread
+            for (uint64_t m = b0 + r; m < b1; m += (uint64_t)rpi * UNR) {
+                double v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const uint64_t mm = m + (uint64_t)u * rpi;
+                    v[u] = mm < b1 ? H[mm * ld + j] - sh : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { sa += v[u]; sb += v[u] * v[u]; }
             }
         }
         s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
@@ -1006,16 +1040,22 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_partial_kernel(const doub
         __syncthreads();
     }
 }
-__global__ void moments_final_kernel(const double* part, uint32_t nblocks, uint32_t ld, double* out) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld) return;
+__global__ __launch_bounds__(MOM_THREADS) void moments_final_kernel(const double* part, uint32_t nblocks, uint32_t ld, double* out) {
+    // one block per column: strided partial sums, then a fixed-order tree
+    __shared__ double s_a[MOM_THREADS], s_b[MOM_THREADS];
+    const uint32_t j = blockIdx.x;
     double sa = 0.0, sb = 0.0;
-    for (uint32_t b = 0; b < nblocks; ++b) {
+    for (uint32_t b = threadIdx.x; b < nblocks; b += MOM_THREADS) {
         sa += part[((uint64_t)b * 2 + 0) * ld + j];
         sb += part[((uint64_t)b * 2 + 1) * ld + j];
     }
-    out[j] = sa;
-    out[ld + j] = sb;
+    s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
+    __syncthreads();
+    for (int o = MOM_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_a[threadIdx.x] += s_a[threadIdx.x + o]; s_b[threadIdx.x] += s_b[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[j] = s_a[0]; out[ld + j] = s_b[0]; }
 }
 
 }  // namespace bpm

@@ -892,14 +892,14 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
     HIPCK(hipMemcpyAsync(h.data() + 2 * s->ld, s->G, s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     *count = (int64_t)(m_hi > m_lo ? m_hi - m_lo : 0);
     if (m_hi > m_lo) {
-        const uint32_t nb = (uint32_t)std::min<uint64_t>(2048, (m_hi - m_lo + 63) / 64);
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(1024, (m_hi - m_lo + 63) / 64);
         double* part = nullptr;
         double* out = nullptr;
         CK(dev_alloc(&part, (size_t)nb * 2 * s->ld));
         CK(dev_alloc(&out, 2 * (size_t)s->ld));
         hipLaunchKernelGGL(moments_partial_kernel, dim3(nb), dim3(MOM_THREADS), 0, s->stream, s->hist, m_lo, m_hi, s->ld,
                            s->G, part);
-        hipLaunchKernelGGL(moments_final_kernel, dim3((s->ld + 63) / 64), dim3(64), 0, s->stream, part, nb, s->ld, out);
+        hipLaunchKernelGGL(moments_final_kernel, dim3(s->ld), dim3(MOM_THREADS), 0, s->stream, part, nb, s->ld, out);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(h.data(), out, 2 * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         HIPCK(hipStreamSynchronize(s->stream));
