@@ -45,6 +45,11 @@ constexpr int ALGO_DEMC = 0, ALGO_DREAM = 1;
 constexpr int TARGET_HOST = 0, TARGET_GAUSS = 1, TARGET_MIXTURE = 2, TARGET_BANANA = 3;
 constexpr int STAGE_FUSED = 0, STAGE_PROPOSE = 1, STAGE_COMMIT = 2;
 constexpr int WAVE = 64;
+// Threads per workgroup of the update kernels, by lanes-per-chain: the wavefronts of a workgroup are independent
+// (no workgroup barrier anywhere), so this is purely a dispatch-granularity choice.  Measured (profiles/): one
+// wavefront per workgroup is best for one-wavefront-per-chain (d=100) and one-lane-per-chain (d=2) kernels, four
+// wavefronts for the 4-lanes-per-chain kernel (d=8: 14.8 vs 17.0 us/generation at N=32768).
+constexpr int block_for(int lpc) { return (lpc == 4 || lpc == 16) ? 256 : 64; }
 constexpr int MAX_CR = 8;
 constexpr int TRACE_I32 = 32;   // ints per chain in the debug trace
 constexpr int TRACE_F64 = 4;
@@ -443,7 +448,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
             s_part[cw * MAX_PARTNERS + idx] = pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
-        __syncthreads();
+        // a chain subgroup never spans wavefronts: LDS ops of one wavefront complete in order, so a wavefront-scope
+        // fence (compiler ordering + lgkmcnt wait) is all the hand-over needs -- no workgroup barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
     // partner rows requested as soon as their ids exist: their L2/MALL latency overlaps with the mask,
@@ -738,11 +747,11 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 }
 
 template <int ALGO, int TARGET, int LPC, int DPL, int NP>
-__global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
-    __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
+__global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(const PhaseArgs a) {
+    __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
-    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
-    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
+    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
 #ifdef BPM_STAMPS
     unsigned long long bpm_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     BPM_STAMP(0);
@@ -770,11 +779,11 @@ __global__ __launch_bounds__(WAVE) void phase_fused_kernel(const PhaseArgs a) {
 
 // Host-callback ln_like_fn: proposals out ...
 template <int ALGO, int LPC, int DPL>
-__global__ __launch_bounds__(WAVE) void phase_propose_kernel(const PhaseArgs a) {
-    __shared__ uint32_t s_part[(WAVE / LPC) * MAX_PARTNERS];
+__global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const PhaseArgs a) {
+    __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
-    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
-    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
+    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
     uint32_t c;
     const bool active = resolve_chain(a, w, c);
     if (w < a.n_items && q == 0) a.ids_buf[w] = active ? (int32_t)c : -1;
@@ -797,10 +806,10 @@ __global__ __launch_bounds__(WAVE) void phase_propose_kernel(const PhaseArgs a) 
 
 // ... and ln_like values back in (aux_buf[2w+1]).
 template <int ALGO, int LPC, int DPL>
-__global__ __launch_bounds__(WAVE) void phase_commit_kernel(const PhaseArgs a) {
+__global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const PhaseArgs a) {
     const int lane = threadIdx.x;
-    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
-    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
+    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
     bool active = w < a.n_items;
     int32_t id = active ? a.ids_buf[w] : -1;
     active = active && id >= 0;
@@ -988,11 +997,11 @@ __global__ void init_jitter_kernel(Layout L, uint32_t lo, uint64_t seed, const d
 
 // ln_like of n points (row stride ld) with the device target
 template <int TARGET, int LPC, int DPL>
-__global__ __launch_bounds__(WAVE) void eval_ll_kernel(const double* X, uint32_t n, uint32_t ld, uint32_t dim,
+__global__ __launch_bounds__(block_for(LPC)) void eval_ll_kernel(const double* X, uint32_t n, uint32_t ld, uint32_t dim,
                                                       const double* tparams, double* out) {
     const int lane = threadIdx.x;
-    const int cw = (LPC == WAVE) ? 0 : lane / LPC, q = (LPC == WAVE) ? lane : lane % LPC;
-    const uint32_t w = blockIdx.x * (WAVE / LPC) + cw;
+    const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
+    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
     const bool active = w < n;
     double v[DPL];
     load_row<LPC, DPL>(X + (uint64_t)(active ? w : 0u) * ld, q, ld, v);

@@ -78,25 +78,25 @@ typedef void (*PhaseLaunch)(const PhaseArgs&, hipStream_t);
 typedef void (*EvalLaunch)(const double*, uint32_t, uint32_t, uint32_t, const double*, double*, hipStream_t);
 
 static inline uint32_t grid_for(uint32_t n_items, int lpc) {
-    const uint32_t cpw = WAVE / lpc;
+    const uint32_t cpw = (uint32_t)(block_for(lpc) / lpc);
     return (n_items + cpw - 1) / cpw;
 }
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_propose(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_commit(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_commit_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((phase_commit_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
 template <int T, int LPC, int DPL>
 static void launch_eval(const double* X, uint32_t n, uint32_t ld, uint32_t dim, const double* tp, double* out,
                         hipStream_t s) {
-    hipLaunchKernelGGL((eval_ll_kernel<T, LPC, DPL>), dim3(grid_for(n, LPC)), dim3(WAVE), 0, s, X, n, ld, dim, tp, out);
+    hipLaunchKernelGGL((eval_ll_kernel<T, LPC, DPL>), dim3(grid_for(n, LPC)), dim3(block_for(LPC)), 0, s, X, n, ld, dim, tp, out);
 }
 
 struct Shape {
