@@ -68,23 +68,23 @@ struct Layout {
     uint32_t magic;    // floor(2^32 / n_local) + 1 (c < 2^31)
 };
 
-__device__ __forceinline__ void split_id(const Layout& L, uint32_t c, uint32_t& r, uint32_t& i) {
-    // r = c / n_local without a hardware divide: magic = floor(2^32 / n_local) + 1 over-estimates by at most one
-    r = __umulhi(c, L.magic);
+// Addresses in 32-bit element offsets (the whole exchange buffer is < 2^31 doubles, checked in bpm_create).
+// With blk = n_local (ld + 2): row(c) = c ld + r 2 n_local, delta(c) = c + r n_local (ld + 1) + n_local ld, r = c / n_local.
+__device__ __forceinline__ uint32_t rank_of(const Layout& L, uint32_t c) {
+    if (L.world == 1) return 0u;
+    // c / n_local without a hardware divide: magic = floor(2^32 / n_local) + 1 over-estimates by at most one
+    uint32_t r = __umulhi(c, L.magic);
     r -= (r * L.n_local > c) ? 1u : 0u;
-    i = c - r * L.n_local;
+    return r;
 }
 __device__ __forceinline__ double* row_ptr(const Layout& L, uint32_t c) {
-    uint32_t r, i; split_id(L, c, r, i);
-    return L.G + (uint64_t)r * L.blk + (uint64_t)i * L.ld;
+    return L.G + (c * L.ld + rank_of(L, c) * (2u * L.n_local));
 }
 __device__ __forceinline__ double* delta_ptr(const Layout& L, uint32_t c) {
-    uint32_t r, i; split_id(L, c, r, i);
-    return L.G + (uint64_t)r * L.blk + (uint64_t)L.n_local * L.ld + i;
+    return L.G + (c + rank_of(L, c) * (L.n_local * (L.ld + 1u)) + L.n_local * L.ld);
 }
 __device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
-    uint32_t r, i; split_id(L, c, r, i);
-    return L.G + (uint64_t)r * L.blk + (uint64_t)L.n_local * (L.ld + 1) + i;
+    return L.G + (c + rank_of(L, c) * (L.n_local * (L.ld + 1u)) + L.n_local * (L.ld + 1u));
 }
 
 struct PhaseArgs {
@@ -580,7 +580,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (a.adapt_on && a.cr_gate) {
             const uint32_t li = c - a.lo;
             double m2[DPL];
-            load_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+            load_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
             double dl = 0.0;
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -693,20 +693,20 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     const double new_ll = accepted ? ll_prop : ll_cur;
     if (a.x_next) {
         // synchronous generation (samplers.py:300-308 delayed_accept): updates are banked, applied after the launch
-        store_row<LPC, DPL>(a.x_next + (uint64_t)li * ld, q, ld, nv);
+        store_row<LPC, DPL>(a.x_next + (uint32_t)(li * ld), q, ld, nv);
         if (accepted && q == 0) a.ll[li] = new_ll;
     } else if (accepted) {
         store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
         if (q == 0) a.ll[li] = new_ll;
     }
-    if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint64_t)li * ld, q, ld, nv);
+    if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
     if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
             double mean[DPL], m2[DPL];
-            load_row<LPC, DPL>(a.w_mean + (uint64_t)li * ld, q, ld, mean);
-            load_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+            load_row<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
+            load_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
             const double cntp = (double)(a.hist_len + 1);
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -714,8 +714,8 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                 mean[s] = mean[s] + d1 / cntp;
                 m2[s] = m2[s] + d1 * (nv[s] - mean[s]);
             }
-            store_row<LPC, DPL>(a.w_mean + (uint64_t)li * ld, q, ld, mean);
-            store_row<LPC, DPL>(a.w_m2 + (uint64_t)li * ld, q, ld, m2);
+            store_row<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
+            store_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
         }
         if (q == 0) {
             const bool gated = a.adapt_on && a.cr_gate;

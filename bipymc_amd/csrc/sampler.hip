@@ -336,6 +336,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->n_local = s->N / s->world;
     s->lo = s->rank * s->n_local;
     if (!pick_shape(s->ld, s->shape)) { delete s; return fail("bpm_create: dim > 512 not supported"); }
+    if ((uint64_t)s->N * (s->ld + 2) >= (1ull << 31)) { delete s; return fail("bpm_create: n_chains * (dim + 2) must stay below 2^31 (32-bit device offsets)"); }
     const int tid = cfg->target_id;
     const int np = cfg->n_target_params;
     bool ok = true;
