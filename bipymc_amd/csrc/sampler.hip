@@ -108,13 +108,7 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
     if (np <= 1) sh = {1, 2, 0};
     else if (np <= 4) sh = {4, 2, 1};
     else if (np <= 16) sh = {16, 2, 2};
-    else if (np <= 64) {
-        sh = {64, 2, 3};
-        // experiment: several chains per wavefront amortise the per-chain control work
-        const char* e = getenv("BPM_SHAPE");
-        if (e && !strcmp(e, "32x4")) sh = {32, 4, 6};
-        if (e && !strcmp(e, "16x8")) sh = {16, 8, 7};
-    }
+    else if (np <= 64) sh = {64, 2, 3};   // (two / four chains per wavefront, 32x4 and 16x8, measured no faster: DESIGN.md)
     else if (np <= 128) sh = {64, 4, 4};
     else if (np <= 256) sh = {64, 8, 5};
     else return false;
@@ -122,21 +116,21 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
 }
 #define SHAPE_TABLE(FN, ...)                                                                     \
     {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
-     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>, FN<__VA_ARGS__ 32, 4>, FN<__VA_ARGS__ 16, 8>}
+     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>}
 #define COMMA ,
 // update-kernel variants: [DE-MC (1 pair) | DREAM del_pairs = 3 (compile-time) | DREAM any del_pairs][shape]
-static PhaseLaunch g_fused_gauss[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
+static PhaseLaunch g_fused_gauss[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
-static PhaseLaunch g_fused_mixture[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
+static PhaseLaunch g_fused_mixture[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
 static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
                                         launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
-static PhaseLaunch g_propose[2][8] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
-static PhaseLaunch g_commit[2][8] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
-static EvalLaunch g_eval_gauss[8] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
-static EvalLaunch g_eval_mixture[8] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
+static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+static PhaseLaunch g_commit[2][6] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
+static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
+static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
 
 // ---- the sampler ------------------------------------------------------------------------
 struct bpm_sampler {
