@@ -93,6 +93,9 @@ def main():
                          % (args.gpus, args.gpus))
 
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
+    ndev = torch.cuda.device_count()
+    if ndev > 0 and local_rank >= ndev:   # launcher exposed one device per process
+        local_rank = 0
     dist = None
     # BPM_FORCE_DIST=1 takes the multi-process path with a single rank (process group + one-rank RCCL
     # communicator): the only way to rehearse it on a one-GPU box
