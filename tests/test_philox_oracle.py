@@ -84,3 +84,29 @@ def test_partition_is_well_mixed():
     flips = np.mean([P.flip_draw(7, t, 0.5) for t in range(T)])
     assert abs(flips - 0.5) < 0.03
     assert not P.flip_draw(7, 0, 0.0) and P.flip_draw(7, 0, 1.0)
+
+
+def test_engine_draw_layout_is_pinned(golden_dir):
+    """Regression pin of the engine-level oracle (draw layout v3: slots, 16-bit fields, float32 Box-Muller,
+    Feistel shuffle): tests/golden/engine_layout_v3.npz was written by this very code; any change of the
+    layout must be deliberate (regenerate the fixture and bump the layout version in DESIGN.md section 4)."""
+    import os
+    from oracle import sampler_ref as R
+    g = np.load(os.path.join(golden_dir, "engine_layout_v3.npz"))
+    p = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(6) + 1.0))
+    s = R.OracleSampler(R.ALGO_DREAM, 12, 6, R.TARGET_GAUSS_EQUICORR, p, seed=2024, burnin_gen=6, n_cr_gen=2)
+    s.init_jitter(np.linspace(-1, 1, 6), 1e-2)
+    s.run(10)
+    np.testing.assert_allclose(s.X, g["dream_state"], rtol=1e-13)
+    np.testing.assert_allclose(s.cr.p_cr, g["dream_p_cr"], rtol=1e-12)
+    assert s.local_n_accepted == int(g["dream_acc"][0])
+    s = R.OracleSampler(R.ALGO_DEMC, 9, 2, R.TARGET_BANANA_2D, R.banana_params(), seed=2025, p_snooker=0.3)
+    s.init_jitter(np.zeros(2), 1e-1)
+    s.run(12)
+    np.testing.assert_allclose(s.X, g["demc_state"], rtol=1e-13)
+    assert s.local_n_accepted == int(g["demc_acc"][0])
+    s = R.OracleSampler(R.ALGO_DEMC_SYNC, 8, 3, R.TARGET_GAUSS_EQUICORR, R.gauss_equicorr_params(0.5, np.sqrt(np.arange(3) + 1.0)), seed=2026)
+    s.init_jitter(np.zeros(3), 1e-1)
+    s.run(12, epsilon=1e-3)
+    np.testing.assert_allclose(s.X, g["sync_state"], rtol=1e-13)
+    assert s.local_n_accepted == int(g["sync_acc"][0])
