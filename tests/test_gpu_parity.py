@@ -389,3 +389,27 @@ def test_demc_sync_mode_parity(N, d, tgt):
     st = eng.stats()
     assert st["local_n_accepted"] == ora.local_n_accepted and st["history_rows"] == 13
     np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-12, atol=1e-9)
+
+
+def test_gpu_reproduces_committed_engine_fixture(golden_dir):
+    """The HIP path against the COMMITTED fixture tests/golden/engine_layout_v3.npz (no oracle call at all):
+    device-side init jitter, DREAM with adaptation, DE-MC with snooker, synchronous DE-MC."""
+    g = np.load(os.path.join(golden_dir, "engine_layout_v3.npz"))
+    e = _engine(algo=R.ALGO_DREAM, n_chains=12, dim=6, target_id=R.TARGET_GAUSS_EQUICORR, target_params=_gauss_params(6),
+                seed=2024, burnin_gen=6, n_cr_gen=2)
+    e.init_chains(np.linspace(-1, 1, 6), 1e-2)
+    e.begin_run(); e.step(10)
+    np.testing.assert_allclose(e.get_state(), g["dream_state"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(e.stats()["p_cr"], g["dream_p_cr"], rtol=1e-8)
+    assert e.stats()["local_n_accepted"] == int(g["dream_acc"][0])
+    e = _engine(algo=R.ALGO_DEMC, n_chains=9, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=2025,
+                p_snooker=0.3)
+    e.init_chains(np.zeros(2), 1e-1)
+    e.begin_run(); e.step(12)
+    np.testing.assert_allclose(e.get_state(), g["demc_state"], rtol=1e-10, atol=1e-13)
+    assert e.stats()["local_n_accepted"] == int(g["demc_acc"][0])
+    e = _engine(algo=R.ALGO_DEMC_SYNC, n_chains=8, dim=3, target_id=R.TARGET_GAUSS_EQUICORR, target_params=_gauss_params(3), seed=2026)
+    e.init_chains(np.zeros(3), 1e-1)
+    e.begin_run(epsilon=1e-3); e.step(12)
+    np.testing.assert_allclose(e.get_state(), g["sync_state"], rtol=1e-9, atol=1e-8)
+    assert e.stats()["local_n_accepted"] == int(g["sync_acc"][0])
