@@ -55,6 +55,7 @@ class DeMcMpi(object):
         self.warm_start = kwargs.get("warm_start", False)
         self.checkpoint = kwargs.get("checkpoint", 0)
         self.log_like_fn = ln_like_fn
+        self._vectorized = bool(kwargs.get("vectorized", False))
         self._ln_kwargs = dict(ln_kwargs)
         self._freeze_ln_like_fn(**self._ln_kwargs)
         if self.n_chains % self.comm.size != 0:
@@ -132,8 +133,7 @@ class DeMcMpi(object):
         if not self.uses_device_target:
             X = self._engine.get_state()
             lo = self.comm.rank * self.n_local
-            ll = np.array([self._call_ln_like(X[lo + i]) for i in range(self.n_local)], dtype=np.float64)
-            self._engine.set_loglike(ll)
+            self._engine.set_loglike(self._eval_ln_like(X[lo:lo + self.n_local]))
 
     def _call_ln_like(self, theta):
         v = self._frozen_ln_like_fn(np.array(theta, dtype=np.float64))
@@ -203,8 +203,15 @@ class DeMcMpi(object):
         """One generation with a Python ln_like_fn: two propose/commit half generations."""
         for _ in range(2):
             props, _ids = self._engine.propose()
-            ll = np.array([self._call_ln_like(p) for p in props], dtype=np.float64)
-            self._engine.commit(ll)
+            self._engine.commit(self._eval_ln_like(props))
+
+    def _eval_ln_like(self, thetas):
+        """ln_like_fn on a block of rows: one Python call per row like the reference (samplers.py:36-43), or
+        -- opt-in `vectorized=True` -- one call on the whole (n, dim) block returning n values."""
+        if self._vectorized and len(thetas):
+            v = np.asarray(self.log_like_fn(np.array(thetas, dtype=np.float64), **self._ln_kwargs), dtype=np.float64)
+            return v.reshape(len(thetas))
+        return np.array([self._call_ln_like(p) for p in thetas], dtype=np.float64)
 
     @property
     def acceptance_fraction(self):
@@ -222,6 +229,16 @@ class DeMcMpi(object):
             std_theta = np.std(chain_slice, axis=0)
             return mean_theta, std_theta, chain_slice
         return None, None, None
+
+    def param_est_moments(self, n_burn):
+        """mean and std (ddof=0) of the super-chain rows >= n_burn, as `param_est` computes them (demc.py:242-246),
+        reduced on the GPU(s) without moving the history to the host; identical on every rank."""
+        cnt, s1, s2, sh = self._engine.reduce_moments(int(n_burn))
+        parts = self.comm.allgather((cnt, s1, s2))
+        n = float(sum(p[0] for p in parts))
+        S1 = np.sum([p[1] for p in parts], axis=0)
+        S2 = np.sum([p[2] for p in parts], axis=0)
+        return sh + S1 / n, np.sqrt(np.maximum(S2 / n - (S1 / n) ** 2, 0.0))
 
     def super_chain_mpi(self, collection_rank=0):
         return self._super_chain(collection_rank)

@@ -401,3 +401,26 @@ def test_posterior_moments_at_baseline_sizes():
     assert abs(in0.mean() - 0.25) < 0.02                                       # mode weights preserved (w = 0.25 / 0.75)
     assert abs(X[in2].var(axis=0).mean() / 0.0625 - 1) < 0.02 and abs(X[in0].var(axis=0).mean() / 0.0625 - 1) < 0.03
     e.close()
+
+
+def test_vectorized_callback_and_device_moments():
+    from bipymc_amd import DreamMpi
+    calls = []
+
+    def ll_batch(thetas, s2=1.0):
+        thetas = np.atleast_2d(thetas)
+        calls.append(thetas.shape[0])
+        return -0.5 * np.sum(thetas ** 2, axis=1) / s2
+
+    a = DreamMpi(ll_batch, np.zeros(4), n_chains=32, seed=4, burnin_gen=50, n_cr_gen=10, vectorized=True, ln_kwargs={"s2": 2.0})
+    b = DreamMpi(lambda th, s2=1.0: float(-0.5 * np.sum(th ** 2) / s2), np.zeros(4), n_chains=32, seed=4, burnin_gen=50,
+                 n_cr_gen=10, ln_kwargs={"s2": 2.0})
+    a.run_mcmc(32 * 301)
+    b.run_mcmc(32 * 301)
+    assert len(calls) == 1 + 2 * 300 and max(calls) == 32              # one call per half generation
+    np.testing.assert_allclose(a.param_est(0)[2], b.param_est(0)[2], rtol=1e-12, atol=1e-14)
+    mean, std, _ = a.param_est(32 * 100)
+    m2, s2 = a.param_est_moments(32 * 100)
+    np.testing.assert_allclose(m2, mean, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s2, std, rtol=1e-9)
+    assert np.all(np.abs(std - np.sqrt(2.0)) < 0.25)
