@@ -39,6 +39,8 @@ def run(rank, world, port, out_dir, case):
             s.param_est(0)
         if case == "dream":
             res["p_cr"] = s.p_cr
+        mm, ss = s.param_est_moments(24)          # device-style reduction, combined across ranks: same on every rank
+        res["mom_mean"], res["mom_std"] = mm, ss
         c = s.get_chain(s.n_chains - 1, 0)          # a chain owned by the last rank, fetched to rank 0
         if rank == 0:
             res["last_chain"] = c.chain

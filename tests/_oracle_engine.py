@@ -90,6 +90,16 @@ class OracleEngine(object):
     def get_history(self, g_lo=0, g_hi=None):
         return np.stack(self.s.history[g_lo:g_hi], axis=0)
 
+    def reduce_moments(self, n_burn=0):
+        """raw moments of this rank's super-chain rows >= n_burn (row g*N + i), about chain 0's current state"""
+        H = np.stack(self.s.history, axis=0)                      # (T, n_local, d)
+        T = H.shape[0]
+        g = np.arange(T)[:, None] * self.n_chains + (self.lo + np.arange(self.n_local))[None, :]
+        sel = g >= n_burn
+        sh = self.s.X[0].copy()
+        rows = H[sel] - sh
+        return int(sel.sum()), rows.sum(axis=0), (rows ** 2).sum(axis=0), sh
+
     def set_adapt_state(self, p_cr=None, delta_m=None, n_cr_updates=None, t_abs=-1):
         if p_cr is not None:
             self.s.cr.p_cr = np.array(p_cr, dtype=float)

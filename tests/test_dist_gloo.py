@@ -47,6 +47,10 @@ def test_dream_two_ranks_equal_one_rank(tmp_path):
     assert int(r0["n_rejected"]) == s.n_rejected + 1
     assert int(r0["local_acc"]) + int(r1["local_acc"]) == s.n_accepted
     assert np.array_equal(r0["last_chain"], s.am_chains[11].chain)
+    # param_est_moments: raw moments reduced per rank, combined through the communicator
+    np.testing.assert_allclose(r0["mom_mean"], mean, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r0["mom_std"], std, rtol=1e-10)
+    np.testing.assert_array_equal(r0["mom_mean"], r1["mom_mean"])
 
 
 def test_demc_snooker_two_ranks_equal_one_rank(tmp_path):
