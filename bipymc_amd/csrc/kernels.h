@@ -369,7 +369,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #ifndef BPM_SCALAR_PARTNERS
 #define BPM_SCALAR_PARTNERS 0   // measured: 19.8 us/generation with lane-parallel partners vs 25.9 all-scalar (cfg2)
 #endif
-    constexpr bool FAST = (LPC == WAVE) && (NP > 0) && (BPM_SCALAR_PARTNERS != 0);
+    // FAST: partner ids straight into registers -- every lane for itself when a lane IS a chain (LPC == 1: no
+    // other lane to share the work with, so the LDS hand-over loop would only re-evaluate the same Philox
+    // block once per partner), or on the scalar unit (experiment switch) for one wavefront per chain
+    constexpr bool FAST = (NP > 0) && (LPC == 1 || ((LPC == WAVE) && (BPM_SCALAR_PARTNERS != 0)));
+    constexpr bool SNK_DIRECT = (LPC == 1);
     const uint32_t dim = a.L.dim, ld = a.L.ld;
     const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;
     // state-dependent loads first: they overlap with all the draw arithmetic below
@@ -444,7 +448,16 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
     const double u_sel = (double)(h0.x >> 16) * 1.52587890625e-05;      // CR select (DREAM) / snooker select (DE-MC)
     const double u_gam = (double)(h0.x & 0xFFFFu) * 1.52587890625e-05;  // gamma = 1 jump select
-    if (!(FAST || RL) || snk_possible) {
+    uint32_t snk_id[3] = {0u, 0u, 0u};
+    if (SNK_DIRECT && snk_possible) {                      // three distinct snooker partners, one Philox block
+        const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
+        uint32_t iz, i1, i2;
+        distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
+        snk_id[0] = pos_to_chain(a, a.pool_off + iz);
+        snk_id[1] = pos_to_chain(a, a.pool_off + i1);
+        snk_id[2] = pos_to_chain(a, a.pool_off + i2);
+    }
+    if (!(FAST || RL) || (snk_possible && !SNK_DIRECT)) {
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
             s_part[cw * MAX_PARTNERS + idx] = pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
@@ -600,8 +613,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (a.mode != 2 && a.k % 10 == 0 && !(u_gam < 0.1)) { gamma = 1.0; wk.jump = 1; }   // demc.py:174-177 (not in samplers.py DeMc)
         wk.gamma = gamma;
         double ra[DPL], rb[DPL];
-        const uint32_t ca = ((FAST || RL) && !snk_possible) ? part.get(0) : part.lds[0];
-        const uint32_t cb = ((FAST || RL) && !snk_possible) ? part.get(1) : part.lds[1];
+        const bool ids_in_regs = (FAST || RL) && (!snk_possible || SNK_DIRECT);
+        const uint32_t ca = ids_in_regs ? part.get(0) : part.lds[0];
+        const uint32_t cb = ids_in_regs ? part.get(1) : part.lds[1];
         load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
         load_row<LPC, DPL>(row_ptr(a.L, cb), q, ld, rb);
 #pragma unroll
@@ -614,9 +628,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (snk_possible && u_sel < a.p_snooker) {
             // snooker update (ter Braak & Vrugt 2008) -- extension, absent from the reference
             double rz[DPL], r1[DPL], r2[DPL];
-            load_row<LPC, DPL>(row_ptr(a.L, part.lds[2]), q, ld, rz);
-            load_row<LPC, DPL>(row_ptr(a.L, part.lds[3]), q, ld, r1);
-            load_row<LPC, DPL>(row_ptr(a.L, part.lds[4]), q, ld, r2);
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[0] : part.lds[2]), q, ld, rz);
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[1] : part.lds[3]), q, ld, r1);
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[2] : part.lds[4]), q, ld, r2);
             double n2 = 0.0, dot = 0.0;
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -654,9 +668,13 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #pragma unroll
                 for (int i = 0; i < 2 * NP; ++i) tr[5 + i] = (int32_t)part.get(i);
             }
+            const bool regs = (FAST || RL) && (!snk_possible || SNK_DIRECT);
 #pragma unroll 1
-            for (uint32_t i = ((FAST || RL) && !snk_possible) ? npart : 0u; i < MAX_PARTNERS; ++i)
-                tr[5 + i] = i < npart ? (int32_t)part.lds[i] : -1;
+            for (uint32_t i = regs ? 2u * P : 0u; i < MAX_PARTNERS; ++i) {
+                int32_t v = -1;
+                if (i < npart) v = regs ? (int32_t)snk_id[i - 2u * P < 3u ? i - 2u * P : 0u] : (int32_t)part.lds[i];
+                tr[5 + i] = v;
+            }
         }
         if (a.trace_mask) {
 #pragma unroll
