@@ -1,0 +1,123 @@
+"""Distributional checks of the on-device random decisions (through the trace hook of the C ABI): the
+frequencies the reference's NumPy draws would have (dream.py:51-80, demc.py:169-177, samplers.py:334-336)."""
+import numpy as np
+import pytest
+
+from oracle import sampler_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(**kw):
+    from bipymc_amd.engine import HipEngine
+    return HipEngine(**kw)
+
+
+def test_dream_decision_frequencies():
+    N, d, G = 2048, 20, 40
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
+    e = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=123,
+                burnin_gen=0, n_cr=3, del_pairs=3)
+    X = np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    e.set_state(X)
+    e.set_trace(True)
+    e.begin_run()
+    cr_counts = np.zeros(3)
+    mask_rate = {0: [], 1: [], 2: []}
+    jump_on, jump_n = 0, 0
+    acc, alpha_sum, n_upd = 0, 0.0, 0
+    partner_hist = np.zeros(N)
+    same_pool_violations = 0
+    for g in range(G):
+        order, _, flip = e.debug_perm(g, True, 0.5)
+        e.step(1)
+        tr = e.get_trace()
+        cr_counts += np.bincount(tr["cr_idx"], minlength=3)
+        for m in range(3):
+            sel = tr["cr_idx"] == m
+            if sel.any():
+                mask_rate[m].append(tr["mask"][sel].mean())
+        if g % 5 == 0:
+            jump_on += tr["jump"].sum(); jump_n += N
+        else:
+            assert not tr["jump"].any()
+        acc += tr["accepted"].sum(); alpha_sum += tr["alpha"].sum(); n_upd += N
+        P_ = tr["partners"][:, :6]
+        np.add.at(partner_hist, P_.reshape(-1), 1)
+        assert np.all(P_[:, 0::2] != P_[:, 1::2])                         # the two members of a pair differ (dream.py:66)
+        # partners come from the OTHER pool (demc.py:103-109,126-132)
+        first = np.zeros(N, dtype=bool); first[order[:N // 2]] = True
+        same_pool_violations += int(np.sum(first[P_] == first[:, None]))
+    assert same_pool_violations == 0
+    # CR ~ Categorical(p_cr = 1/3 each) (dream.py:51)
+    assert np.all(np.abs(cr_counts / cr_counts.sum() - 1 / 3) < 0.01)
+    # P(z <= CR_m) = CR_m; with CR = 1/3 a chain whose mask came out empty gets one forced dimension (dream.py:55-57)
+    p13 = 1 / 3 + (2 / 3) ** d / d
+    assert abs(np.mean(mask_rate[0]) - p13) < 0.01 and abs(np.mean(mask_rate[1]) - 2 / 3) < 0.01 and np.mean(mask_rate[2]) == 1.0
+    # gamma = 1 with probability 0.8 on every 5th generation (dream.py:77-80)
+    assert abs(jump_on / jump_n - 0.8) < 0.015
+    # Bernoulli(alpha) acceptance (samplers.py:334-336): accepted fraction == mean alpha
+    assert abs(acc / n_upd - alpha_sum / n_upd) < 0.01
+    # partners uniform over chains: chi-square-like spread
+    exp = partner_hist.mean()
+    assert abs(partner_hist.std() / np.sqrt(exp) - 1.0) < 0.1
+
+
+def test_demc_decision_frequencies():
+    N, G = 4096, 40
+    e = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=321,
+                p_snooker=0.1)
+    e.set_state(np.random.RandomState(1).normal(size=(N, 2)) + np.array([0, 1.0]))
+    e.set_trace(True)
+    e.begin_run()
+    snk, jump_on, jump_n, n_upd = 0, 0, 0, 0
+    for g in range(G):
+        e.step(1)
+        tr = e.get_trace()
+        snk += tr["snooker"].sum(); n_upd += N
+        if g % 10 == 0:
+            jump_on += tr["jump"].sum(); jump_n += N
+        else:
+            assert not tr["jump"].any()
+        P_ = tr["partners"][:, :5]
+        assert np.all(P_[:, 0] != P_[:, 1])
+        assert np.all((P_[:, 2] != P_[:, 3]) & (P_[:, 2] != P_[:, 4]) & (P_[:, 3] != P_[:, 4]))
+    assert abs(snk / n_upd - 0.1) < 0.006                                   # snooker with probability p_snooker
+    assert abs(jump_on / jump_n - 0.9) < 0.01                               # demc.py:174-177
+
+
+def test_jitter_moments_on_device():
+    """e_u ~ U(-u_eps, u_eps) multiplies, e_n ~ N(0, eps^2) adds (util.py:5-28): recover both from one update of a
+    population whose pairs are (0, 1)-valued so that the pair sum is exactly known."""
+    N, d = 4096, 16
+    params = R.gauss_equicorr_params(0.0, np.full(d, 1e6))                  # flat target: everything is accepted
+    e = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=9)
+    X = np.zeros((N, d))
+    e.set_state(X)
+    e.begin_run(epsilon=0.5)
+    order, _, flip = e.debug_perm(0, True, 0.5)
+    e.step(1)
+    first_group = order[N // 2:] if flip else order[:N // 2]                # updated against a pool that is still all zeros
+    X1 = e.get_state()[first_group]                                         # x' = 0 + gamma*(0 - 0) + e_n
+    assert abs(X1.mean()) < 0.006 and abs(X1.std() - 0.5) < 0.006
+    from scipy import stats
+    assert stats.kstest((X1 / 0.5).reshape(-1)[:20000], "norm").pvalue > 1e-3
+    # uniform multiplicative jitter of DREAM: pairs differ by exactly 1 in every coordinate
+    e = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=10,
+                burnin_gen=0, n_cr=1, del_pairs=1)
+    X = np.zeros((N, d)); X[::2] = 1.0                                      # a - b in {-1, 0, 1}
+    e.set_state(X)
+    e.set_trace(True)
+    e.begin_run(epsilon=0.0, u_epsilon=0.05)
+    order, _, flip = e.debug_perm(0, True, 0.5)
+    e.step(1)
+    first_group = np.zeros(N, dtype=bool)
+    first_group[order[N // 2:] if flip else order[:N // 2]] = True          # their pool still held the initial states
+    tr = e.get_trace()
+    X1 = e.get_state()
+    ab = X[tr["partners"][:, 0]] - X[tr["partners"][:, 1]]
+    sel = first_group & (np.abs(ab[:, 0]) == 1) & (tr["accepted"] == 1)
+    assert sel.sum() > 500
+    ratio = ((X1 - X)[sel] / (tr["gamma"][sel, None] * ab[sel]))            # = 1 + e_u   (n_cr = 1: every coordinate moves)
+    assert abs(ratio.mean() - 1.0) < 0.002 and ratio.min() >= 0.95 and ratio.max() <= 1.05
+    assert abs(ratio.std() - 0.05 / np.sqrt(3)) < 0.001
