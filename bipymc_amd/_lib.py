@@ -65,6 +65,8 @@ SIGNATURES = {
     "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
     "bpm_synchronize": (C.c_int, [_H]),
     "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),
+    "bpm_set_exchange": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "bpm_get_exchange_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_set_history": (C.c_int, [_H, C.c_int64, _dp, _dp]),
     "bpm_reduce_moments": (C.c_int, [_H, C.c_int64, _dp, _dp, _dp, _P(C.c_int64)]),
     "bpm_propose": (C.c_int, [_H, _dp, _ip, _ip]),

@@ -110,6 +110,8 @@ struct PhaseArgs {
     const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     unsigned long long* stamps;  // diagnostic build only
+    double* pack;               // sparse exchange (world > 1): this rank's block [count u32 | pad | ids[cap] | rows[cap][ld]] or nullptr
+    uint32_t pack_cap, pack_nsub, pack_stride;   // per sub-block: capacity (rows), count of sub-blocks, doubles per sub-block          // rows the block can take (even)
     double* x_next;             // mode 2 (synchronous DE-MC): new states go here, the state matrix stays frozen
     uint64_t seed;
     uint64_t t;            // absolute generation
@@ -717,6 +719,22 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
         if (q == 0) a.ll[li] = new_ll;
     }
+    if (a.pack && accepted) {
+        // sparse exchange: only rows that changed travel.  One slot per accepted chain (order irrelevant: the
+        // receivers scatter by chain id); a chain beyond the capacity is counted but not packed -- the host sees
+        // count > cap after the chunk and replays it with the dense all-gather (results identical by construction).
+        // The block is split into pack_nsub sub-blocks with a counter each (a power of two; chain li uses li % nsub): atomics on one
+        // address retire one at a time (~12 ns each), hundreds of acceptances on one counter would cost more than
+        // the update itself.
+        double* sub = a.pack + (uint32_t)((li & (a.pack_nsub - 1u)) * a.pack_stride);
+        uint32_t slot = 0;
+        if (q == 0) slot = atomicAdd(reinterpret_cast<uint32_t*>(sub), 1u);
+        slot = __shfl(slot, (threadIdx.x & (WAVE - 1)) - q);           // lane 0 of the subgroup
+        if (slot < a.pack_cap) {
+            if (q == 0) sub[2 + slot] = (double)c;
+            store_row<LPC, DPL>(sub + 2 + a.pack_cap + (uint32_t)(slot * ld), q, ld, nv);
+        }
+    }
     if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
     if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
     if (ALGO == ALGO_DREAM) {
@@ -931,6 +949,30 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
             }
         }
     }
+}
+
+// Sparse exchange, receiving side: after the all-gather of the packed blocks PK[r] = [count | pad | ids[cap] | rows[cap][ld]]
+// every rank copies the rows the OTHER ranks accepted into its replica of the state matrix.  Block (slot, r).
+// xstat[0] |= 1 when some rank had more accepted rows than capacity, xstat[1] = max count seen (capacity control).
+__global__ __launch_bounds__(WAVE) void exchange_scatter_kernel(Layout L, double* PK, uint32_t nsub, uint32_t stride, uint32_t cap,
+                                                              uint32_t me, uint32_t* xstat) {
+    const uint32_t sb = blockIdx.x / cap, slot = blockIdx.x % cap, r = blockIdx.y;
+    double* blk = PK + ((uint64_t)r * nsub + sb) * stride;
+    const uint32_t cnt = *reinterpret_cast<const uint32_t*>(blk);
+    if (slot == 0 && threadIdx.x == 0) {
+        if (cnt > cap) atomicOr(&xstat[0], 1u);
+        atomicMax(&xstat[1], cnt);
+    }
+    if (r == me) {
+        // own rows are already in place; re-arm the counter for the next half generation (nobody else reads it here)
+        if (slot == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t*>(blk) = 0u;
+        return;
+    }
+    if (slot >= cnt) return;
+    const uint32_t id = (uint32_t)blk[2 + slot];
+    const double* src = blk + 2 + cap + (uint64_t)slot * L.ld;
+    double* dst = row_ptr(L, id);
+    for (uint32_t j = threadIdx.x; j < L.ld; j += WAVE) dst[j] = src[j];
 }
 
 // Shuffle orders of K consecutive generations in one launch: tab[g*N + k] = pi_g(k), inv[g*N + pi_g(k)] = k.

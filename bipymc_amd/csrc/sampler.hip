@@ -174,6 +174,20 @@ struct bpm_sampler {
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
     bool local_group = false;     // test mode: ranks are handles of ONE process, exchanged by device copies
+    // sparse exchange (world > 1, outside CR adaptation): only accepted rows travel, in fixed-capacity packed blocks;
+    // a chunk whose capacity was exceeded is rolled back to its checkpoint and replayed with the dense all-gather
+    bool sparse_enabled = false;
+    bool sparse_active = false;   // the generation being prepared packs its accepted rows
+    uint32_t xnsub = 1;           // sub-blocks per rank (a counter each; local chain li packs into sub-block li % xnsub)
+    uint32_t xcap = 0, xcap_max = 0;   // capacity of a sub-block (rows per half generation, even) and its ceiling
+    double* PK = nullptr;         // packed blocks: rank r at r * xnsub * xstride(), sub-block = [count | ids(cap) | rows(cap * ld)]
+    uint32_t xstride() const { return 2u + xcap * (ld + 1u); }
+    uint32_t* xstat = nullptr;    // [0] overflow flag, [1] largest count seen
+    double* ckpt_G = nullptr;
+    double* ckpt_ll = nullptr;
+    uint32_t* ckpt_acc = nullptr;
+    unsigned long long* ckpt_counters = nullptr;
+    int64_t n_sparse_chunks = 0, n_sparse_replays = 0;
     // run state
     bpm_run_opts_t opts{};
     bool run_open = false;
@@ -289,7 +303,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->x_next, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -414,6 +428,23 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         std::memcpy(&id, cfg->nccl_uid, BPM_UID_BYTES);
         ncclResult_t r = g_rccl.CommInitRank(&s->comm, (int)s->world, id, (int)s->rank);
         if (r != ncclSuccess) { std::string m = std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r); bpm_destroy(s); return fail(m); }
+    }
+    // (a one-rank communicator takes the same path, so a one-GPU box can time and test it through RCCL)
+    if ((s->world > 1 || s->comm) && cfg->algo != BPM_ALGO_DEMC_SYNC && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
+        s->sparse_enabled = getenv("BPM_DENSE_EXCHANGE") == nullptr;
+        s->xnsub = 1u;
+        while (s->xnsub < 16u && 2u * s->xnsub * 8u <= s->n_local) s->xnsub *= 2u;      // power of two, >= 8 chains each
+        s->xcap_max = ((s->n_local + s->xnsub - 1u) / s->xnsub + 1u) & ~1u;    // every chain of a sub-block accepted
+        s->xcap = s->xcap_max;                               // first chunk: cannot overflow; then sized from the counts seen
+        const size_t pk_doubles = (size_t)s->world * s->xnsub * s->xstride();
+        CKD(dev_alloc(&s->PK, pk_doubles));
+        HIPCKD(hipMemsetAsync(s->PK, 0, pk_doubles * sizeof(double), s->stream));
+        CKD(dev_alloc(&s->xstat, 2));
+        HIPCKD(hipMemsetAsync(s->xstat, 0, 2 * sizeof(uint32_t), s->stream));
+        CKD(dev_alloc(&s->ckpt_G, (size_t)s->world * s->L.blk));
+        CKD(dev_alloc(&s->ckpt_ll, s->n_local));
+        CKD(dev_alloc(&s->ckpt_acc, s->n_local));
+        CKD(dev_alloc(&s->ckpt_counters, 4));
     }
     HIPCKD(hipStreamSynchronize(s->stream));
     *out = s;
@@ -620,6 +651,12 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.epsilon = s->opts.epsilon;
         a.u_epsilon = s->opts.u_epsilon;
         a.p_snooker = s->cfg.p_snooker;
+        if (s->sparse_active) {
+            a.pack = s->PK + (uint64_t)s->rank * s->xnsub * s->xstride();
+            a.pack_cap = s->xcap;
+            a.pack_nsub = s->xnsub;
+            a.pack_stride = s->xstride();
+        }
         if (sync) {      // samplers.py:261-308: one launch, every local chain against all other chains, updates banked
             a.algo = (uint32_t)BPM_ALGO_DEMC;
             a.mode = 2u;
@@ -710,24 +747,157 @@ static int finish_generation(bpm_sampler* s) {
     return 0;
 }
 
-static int run_generation_fused(bpm_sampler* s, int64_t n_ahead) {
-    CK(prepare_generation(s, n_ahead));
-    PhaseLaunch fn = pick_fused(s);
-    if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
-    if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) {
-        fn(s->cur_args[0], s->stream);
-        HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(s->G + (uint64_t)s->rank * s->L.blk, s->x_next, (size_t)s->n_local * s->ld * sizeof(double),
-                             hipMemcpyDeviceToDevice, s->stream));      // apply the banked updates
-        CK(allgather_state(s));
-        return finish_generation(s);
+// ---- generation drivers ---------------------------------------------------------------------------------
+// A Group is what advances in lock-step: the single handle of a process (exchange = RCCL on its stream) or, in
+// the local-group test mode, the R handles that stand for the R ranks (exchange = device copies).  Both run the
+// SAME code below, so what the one-GPU tests verify is what a multi-GPU run executes, transport aside.
+struct Group {
+    bpm_sampler** h;
+    int R;
+    bool rccl;
+};
+constexpr int64_t SPARSE_CHUNK = 64;
+
+static int group_sync(const Group& g) {
+    for (int r = 0; r < g.R; ++r) HIPCK(hipStreamSynchronize(g.h[r]->stream));
+    return 0;
+}
+
+// demc.py:93-94,116-117: every rank's block into every replica
+static int exchange_dense(const Group& g) {
+    if (g.rccl) return allgather_state(g.h[0]);
+    if (g.R == 1) return 0;
+    CK(group_sync(g));
+    const bpm_sampler* s0 = g.h[0];
+    for (int r = 0; r < g.R; ++r)
+        for (int o = 0; o < g.R; ++o)
+            if (o != r)
+                HIPCK(hipMemcpyAsync(g.h[o]->G + (uint64_t)r * s0->L.blk, g.h[r]->G + (uint64_t)r * s0->L.blk,
+                                     (size_t)s0->L.blk * sizeof(double), hipMemcpyDeviceToDevice, g.h[r]->stream));
+    return group_sync(g);
+}
+
+// the same exchange with only the accepted rows: all-gather of the packed blocks, then scatter into the replicas
+static int exchange_sparse(const Group& g) {
+    bpm_sampler* s0 = g.h[0];
+    const uint32_t cap = s0->xcap;
+    const uint64_t S = (uint64_t)s0->xnsub * s0->xstride();
+    if (g.rccl) {
+        NCCLCK(g_rccl.AllGather(s0->PK + (uint64_t)s0->rank * S, s0->PK, (size_t)S, ncclDouble, s0->comm, s0->stream));
+    } else {
+        CK(group_sync(g));
+        for (int r = 0; r < g.R; ++r)
+            for (int o = 0; o < g.R; ++o)
+                if (o != r)
+                    HIPCK(hipMemcpyAsync(g.h[o]->PK + (uint64_t)r * S, g.h[r]->PK + (uint64_t)r * S, (size_t)S * sizeof(double),
+                                         hipMemcpyDeviceToDevice, g.h[r]->stream));
+        CK(group_sync(g));
     }
-    for (int ph = 0; ph < 2; ++ph) {
-        if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
-        CK(allgather_state(s));
+    for (int r = 0; r < g.R; ++r) {
+        bpm_sampler* s = g.h[r];
+        hipLaunchKernelGGL(exchange_scatter_kernel, dim3(cap * s->xnsub, s->world), dim3(WAVE), 0, s->stream, s->L, s->PK, s->xnsub,
+                           s->xstride(), cap, s->rank, s->xstat);
     }
     HIPCK(hipGetLastError());
-    return finish_generation(s);
+    return 0;
+}
+
+static int group_generation(const Group& g, int64_t n_ahead, bool sparse, PhaseLaunch fn) {
+    for (int r = 0; r < g.R; ++r) {
+        g.h[r]->sparse_active = sparse;
+        CK(prepare_generation(g.h[r], n_ahead));
+    }
+    if (g.h[0]->cfg.algo == BPM_ALGO_DEMC_SYNC) {
+        for (int r = 0; r < g.R; ++r) {
+            bpm_sampler* s = g.h[r];
+            fn(s->cur_args[0], s->stream);
+            HIPCK(hipMemcpyAsync(s->G + (uint64_t)s->rank * s->L.blk, s->x_next, (size_t)s->n_local * s->ld * sizeof(double),
+                                 hipMemcpyDeviceToDevice, s->stream));      // apply the banked updates
+        }
+        HIPCK(hipGetLastError());
+        CK(exchange_dense(g));
+    } else {
+        for (int ph = 0; ph < 2; ++ph) {
+            for (int r = 0; r < g.R; ++r)
+                if (g.h[r]->cur_args[ph].n_items > 0) fn(g.h[r]->cur_args[ph], g.h[r]->stream);
+            HIPCK(hipGetLastError());
+            CK(sparse ? exchange_sparse(g) : exchange_dense(g));
+        }
+    }
+    for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
+    return 0;
+}
+
+struct HostCkpt {
+    int64_t k_gen, t_abs, hist_rows, rows_logical, w_rows;
+};
+
+static int run_generations(const Group& g, int64_t n_gens) {
+    bpm_sampler* s0 = g.h[0];
+    PhaseLaunch fn = pick_fused(s0);
+    if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
+    const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
+    int64_t done = 0;
+    while (done < n_gens) {
+        const bool adapting = dream && s0->cfg.burnin_gen > s0->k_gen;          // dream.py:92: CR statistics travel in the dense block
+        if (!(s0->sparse_enabled && !adapting)) {
+            CK(group_generation(g, n_gens - done, false, fn));
+            ++done;
+            continue;
+        }
+        // ---- a chunk of generations with the sparse exchange, under a checkpoint
+        const int64_t K = std::min<int64_t>(SPARSE_CHUNK, n_gens - done);
+        std::vector<HostCkpt> hc((size_t)g.R);
+        for (int r = 0; r < g.R; ++r) {
+            bpm_sampler* s = g.h[r];
+            hc[(size_t)r] = HostCkpt{s->k_gen, s->t_abs, s->hist_rows, s->rows_logical, s->w_rows};
+            HIPCK(hipMemcpyAsync(s->ckpt_G, s->G, (size_t)s->world * s->L.blk * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            HIPCK(hipMemcpyAsync(s->ckpt_ll, s->ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            HIPCK(hipMemcpyAsync(s->ckpt_acc, s->acc_count, (size_t)s->n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+            HIPCK(hipMemcpyAsync(s->ckpt_counters, s->counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
+            HIPCK(hipMemsetAsync(s->xstat, 0, 2 * sizeof(uint32_t), s->stream));
+            for (uint32_t b = 0; b < s->xnsub; ++b)      // own counters armed (the capacity, hence the layout, may have changed)
+                HIPCK(hipMemsetAsync(s->PK + ((uint64_t)s->rank * s->xnsub + b) * s->xstride(), 0, sizeof(double), s->stream));
+        }
+        for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, true, fn));
+        bool overflow = false;
+        uint32_t maxc = 0;
+        for (int r = 0; r < g.R; ++r) {
+            bpm_sampler* s = g.h[r];
+            uint32_t xs[2] = {0, 0};
+            HIPCK(hipMemcpyAsync(xs, s->xstat, sizeof(xs), hipMemcpyDeviceToHost, s->stream));
+            HIPCK(hipStreamSynchronize(s->stream));
+            overflow = overflow || xs[0] != 0;
+            maxc = std::max(maxc, xs[1]);
+            s->n_sparse_chunks += 1;
+        }
+        if (overflow) {
+            // some rank accepted more rows than a packed block holds: replicas diverged.  Roll every rank back to the
+            // checkpoint and replay the chunk with the dense exchange; the draws are counter-addressed, so the replay
+            // is exactly the run that would have happened without the sparse exchange.
+            for (int r = 0; r < g.R; ++r) {
+                bpm_sampler* s = g.h[r];
+                HIPCK(hipMemcpyAsync(s->G, s->ckpt_G, (size_t)s->world * s->L.blk * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+                HIPCK(hipMemcpyAsync(s->ll, s->ckpt_ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+                HIPCK(hipMemcpyAsync(s->acc_count, s->ckpt_acc, (size_t)s->n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+                HIPCK(hipMemcpyAsync(s->counters, s->ckpt_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
+                const HostCkpt& k = hc[(size_t)r];
+                s->k_gen = k.k_gen; s->t_abs = k.t_abs; s->hist_rows = k.hist_rows; s->rows_logical = k.rows_logical; s->w_rows = k.w_rows;
+                s->n_sparse_replays += 1;
+            }
+            for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, false, fn));
+        }
+        // capacity for the next chunk from the largest sub-block count seen (identical on every rank: all see all
+        // counters): a margin of ~3 sigma of a Poisson count on top of an observed maximum over >= 64 half generations
+        const uint32_t want = overflow ? 2u * maxc + 8u : maxc + 3u * (uint32_t)std::ceil(std::sqrt((double)maxc)) + 4u;
+        for (int r = 0; r < g.R; ++r) {
+            bpm_sampler* s = g.h[r];
+            s->xcap = std::min<uint32_t>(s->xcap_max, (want + 1u) & ~1u);
+        }
+        done += K;
+    }
+    for (int r = 0; r < g.R; ++r) g.h[r]->sparse_active = false;
+    return 0;
 }
 
 // Lock-step driver of a local group (see bpm_create): handles[r] = rank r of R, all on one GPU.
@@ -739,32 +909,12 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
         if (!s->local_group || (int)s->world != R || (int)s->rank != r) return fail("bpm_local_group_step: handles are not ranks 0..R-1 of one local group");
         if (!s->run_open) return fail("bpm_local_group_step: call bpm_begin_run on every rank first");
         if (s->cfg.outlier_every > 0) return fail("bpm_local_group_step: outlier detection is not emulated");
-        if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_local_group_step: synchronous DE-MC mode is not emulated");
         if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     }
-    bpm_sampler* s0 = handles[0];
-    CK(set_device(s0));
-    PhaseLaunch fn = pick_fused(s0);
-    if (!fn) return fail("bpm_local_group_step: device targets only");
-    for (int64_t g = 0; g < n_gens; ++g) {
-        for (int r = 0; r < R; ++r) CK(prepare_generation(handles[r], n_gens - g));
-        for (int ph = 0; ph < 2; ++ph) {
-            for (int r = 0; r < R; ++r)
-                if (handles[r]->cur_args[ph].n_items > 0) fn(handles[r]->cur_args[ph], handles[r]->stream);
-            HIPCK(hipGetLastError());
-            for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
-            // the all-gather: rank r's block goes into every other rank's replica
-            for (int r = 0; r < R; ++r)
-                for (int o = 0; o < R; ++o)
-                    if (o != r)
-                        HIPCK(hipMemcpyAsync(handles[o]->G + (uint64_t)r * s0->L.blk, handles[r]->G + (uint64_t)r * s0->L.blk,
-                                             (size_t)s0->L.blk * sizeof(double), hipMemcpyDeviceToDevice, handles[r]->stream));
-            for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
-        }
-        for (int r = 0; r < R; ++r) CK(finish_generation(handles[r]));
-    }
-    for (int r = 0; r < R; ++r) HIPCK(hipStreamSynchronize(handles[r]->stream));
-    return 0;
+    CK(set_device(handles[0]));
+    Group g{handles, R, false};
+    CK(run_generations(g, n_gens));
+    return group_sync(g);
 }
 
 extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
@@ -774,7 +924,30 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
-    for (int64_t g = 0; g < n_gens; ++g) CK(run_generation_fused(s, n_gens - g));
+    bpm_sampler* one[1] = {s};
+    Group g{one, 1, s->comm != nullptr};
+    return run_generations(g, n_gens);
+}
+
+// Exchange policy of a world_size > 1 sampler.  sparse: 1 = accepted rows only (default), 0 = dense all-gather;
+// cap > 0 sets the capacity of the next chunk (rows per sub-block per half generation; rounded up to even, clamped to
+// [2, all chains of a sub-block]) -- every rank of a world must be given the same values.
+extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t sparse, int32_t cap) {
+    CK(check_handle(s));
+    if (!s->PK) return sparse ? fail("bpm_set_exchange: this sampler has no sparse exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
+    s->sparse_enabled = sparse != 0;
+    if (cap > 0) s->xcap = std::min<uint32_t>(s->xcap_max, ((uint32_t)cap + 1u) & ~1u);
+    return 0;
+}
+
+// out[0] = sparse exchange enabled, out[1] = current capacity, out[2] = chunks run sparse, out[3] = chunks replayed dense
+extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
+    CK(check_handle(s));
+    if (!out) return fail("bpm_get_exchange_stats: null argument");
+    out[0] = s->sparse_enabled ? 1 : 0;
+    out[1] = (int64_t)s->xcap;
+    out[2] = s->n_sparse_chunks;
+    out[3] = s->n_sparse_replays;
     return 0;
 }
 
@@ -808,6 +981,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     std::vector<hipEvent_t> ev((size_t)n_gens * 4);
     for (auto& e : ev) HIPCK(hipEventCreate(&e));
     PhaseLaunch fn = pick_fused(s);
+    s->sparse_active = false;
     for (int64_t g = 0; g < n_gens; ++g) {
         CK(prepare_generation(s, n_gens - g));
         for (int ph = 0; ph < 2; ++ph) {

@@ -143,6 +143,17 @@ int bpm_synchronize(bpm_handle_t h);
  * nccl_uid that starts with "BPMLOCAL" (no RCCL involved); this call advances all of them n_gens generations
  * in lock-step, doing the per-half-generation all-gather (demc.py:93-94,116-117) with device copies. */
 int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
+/* Exchange policy for world_size > 1 (the Allgather of demc.py:93-94,116-117).  Outside DREAM's CR adaptation
+ * only the rows that were ACCEPTED in a half generation have changed, so by default ranks all-gather
+ * fixed-capacity packed blocks (up to 16 sub-blocks [count | ids | rows] per rank, a counter each) and scatter
+ * them into their replicas.  Generations run in chunks of 64 under a device-side checkpoint; a chunk in which a
+ * sub-block saw more acceptances than its capacity is rolled back and replayed with the dense all-gather (draws
+ * are counter-addressed, so the result is the dense run's, bit for bit).  sparse = 0 selects the dense exchange
+ * always; cap > 0 sets the capacity (rows per sub-block per half generation) of the next chunk -- afterwards it
+ * follows the largest count seen.  Same values on every rank. */
+int bpm_set_exchange(bpm_handle_t h, int32_t sparse, int32_t cap);
+/* out[4] = {sparse enabled, current capacity, chunks run with the sparse exchange, chunks replayed dense} */
+int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop
