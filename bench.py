@@ -74,6 +74,24 @@ def cpu_baseline(seconds_budget=15.0):
                                               CHAINS_PER_GPU * gens / el, gens, os.cpu_count() or 0))
 
 
+def measured_copy_bandwidth(torch, dev):
+    """Device-to-device copy of 1 GiB (read + write = 2 GiB of HBM traffic per pass), HIP-event timed: the
+    achievable-bandwidth yardstick SURVEY section 8(d) asks for beside the 8 TB/s datasheet figure."""
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device="cuda:%d" % dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * n * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     global CHAINS_PER_GPU
     ap = argparse.ArgumentParser()
@@ -196,6 +214,7 @@ def main():
                      acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
 
     if rank == 0:
+        copy_gbs = measured_copy_bandwidth(torch, local_rank)
         out = {
             "metric": "chain-updates/sec", "value": value, "unit": "chain-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +230,8 @@ def main():
                          "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3> (DREAM, Gauss target, 64 lanes/chain, 3 pairs)",
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
-                         "launches_timed": n_launch, "avg_launch_us_event_pairs": pair_ms / pair_n * 1e3},
+                         "launches_timed": n_launch, "avg_launch_us_event_pairs": pair_ms / pair_n * 1e3,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs},
             "posterior": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
