@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/bipymc_hip.h"
@@ -1164,6 +1166,59 @@ extern "C" int bpm_reserve_history(bpm_handle_t s, int64_t total_rows) {
     return ensure_history(s, total_rows);
 }
 
+// Large device-to-host transfers into the caller's pageable buffer.  HIP's own pageable path stages through pinned
+// memory with ONE host thread copying out of it (~10 GB/s here, and the caller's fresh NumPy array page-faults on
+// first touch on that same thread).  Here `n_workers` host threads, each with its own stream and two pinned staging
+// buffers, take chunks from a shared counter: the DMA of a thread's next chunk overlaps its memcpy of the current one.
+static int d2h_rows_parallel(bpm_sampler* s, double* out, const double* src, size_t rows, uint32_t dim, uint32_t ld) {
+    const size_t row_bytes = (size_t)dim * sizeof(double);
+    const size_t chunk_rows = std::max<size_t>(1, ((size_t)8 << 20) / row_bytes);
+    const size_t n_chunks = (rows + chunk_rows - 1) / chunk_rows;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n_workers = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, hw / 2)), n_chunks);
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{0};
+    const int device = s->cfg.device;
+    auto work = [&]() {
+        hipStream_t st = nullptr;
+        double* pin[2] = {nullptr, nullptr};
+        auto ok = [&](hipError_t e) { if (e != hipSuccess) { err.store((int)e); return false; } return true; };
+        if (ok(hipSetDevice(device)) && ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) &&
+            ok(hipHostMalloc((void**)&pin[0], chunk_rows * row_bytes, hipHostMallocDefault)) &&
+            ok(hipHostMalloc((void**)&pin[1], chunk_rows * row_bytes, hipHostMallocDefault))) {
+            auto issue = [&](size_t ch, int b) {
+                const size_t r0 = ch * chunk_rows, nr = std::min(chunk_rows, rows - r0);
+                return ok(hipMemcpy2DAsync(pin[b], row_bytes, src + r0 * ld, (size_t)ld * sizeof(double), row_bytes, nr,
+                                           hipMemcpyDeviceToHost, st));
+            };
+            size_t cur = next.fetch_add(1);
+            int b = 0;
+            bool live = cur < n_chunks && issue(cur, b);
+            while (live && err.load() == 0) {
+                if (!ok(hipStreamSynchronize(st))) break;                 // chunk `cur` is in pin[b]
+                const size_t nxt = next.fetch_add(1);
+                const bool more = nxt < n_chunks;
+                if (more && !issue(nxt, b ^ 1)) break;                    // next DMA runs under this memcpy
+                const size_t r0 = cur * chunk_rows, nr = std::min(chunk_rows, rows - r0);
+                std::memcpy(out + r0 * dim, pin[b], nr * row_bytes);
+                if (!more) break;
+                cur = nxt;
+                b ^= 1;
+            }
+            if (st) (void)hipStreamSynchronize(st);
+        }
+        if (pin[0]) (void)hipHostFree(pin[0]);
+        if (pin[1]) (void)hipHostFree(pin[1]);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_workers; ++w) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (err.load() != 0) return fail(std::string("bpm_get_history: ") + hipGetErrorString((hipError_t)err.load()));
+    return 0;
+}
+
 extern "C" int bpm_get_history(bpm_handle_t s, int64_t g_lo, int64_t g_hi, double* out) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -1171,6 +1226,10 @@ extern "C" int bpm_get_history(bpm_handle_t s, int64_t g_lo, int64_t g_hi, doubl
     if (g_hi == g_lo) return 0;
     if (!out) return fail("bpm_get_history: null argument");
     const size_t rows = (size_t)(g_hi - g_lo) * s->n_local;
+    if (rows * s->dim * sizeof(double) >= ((size_t)128 << 20)) {
+        HIPCK(hipStreamSynchronize(s->stream));
+        return d2h_rows_parallel(s, out, s->hist + (uint64_t)g_lo * s->n_local * s->ld, rows, s->dim, s->ld);
+    }
     HIPCK(hipMemcpy2DAsync(out, s->dim * sizeof(double), s->hist + (uint64_t)g_lo * s->n_local * s->ld,
                            s->ld * sizeof(double), s->dim * sizeof(double), rows, hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));

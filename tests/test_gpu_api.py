@@ -438,3 +438,23 @@ def test_vectorized_callback_and_device_moments():
     np.testing.assert_allclose(m2, mean, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(s2, std, rtol=1e-9)
     assert np.all(np.abs(std - np.sqrt(2.0)) < 0.25)
+
+
+@pytest.mark.parametrize("dim,N,G", [(100, 8192, 24), (7, 65536, 44)])
+def test_large_history_transfer_equals_row_by_row(dim, N, G):
+    """bpm_get_history switches to the multi-threaded pinned-staging copy above 128 MB; it must return exactly what
+    generation-by-generation calls (the plain path) return, also when rows are padded on the device (odd dim)."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D(dim=dim)._bpm_target_spec()
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, burnin_gen=0)
+    e.set_state(np.random.RandomState(1).normal(size=(N, d)))
+    e.begin_run()
+    e.step(G)
+    H = e.get_history()
+    assert H.shape == (G + 1, N, d) and H.nbytes >= 128 << 20
+    for g in range(G + 1):
+        assert np.array_equal(H[g], e.get_history(g, g + 1)[0]), g
+    assert np.array_equal(H[-1], e.get_state())
+    e.close()
