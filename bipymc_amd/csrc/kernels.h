@@ -87,6 +87,7 @@ __device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
     return L.G + (c + rank_of(L, c) * (L.n_local * (L.ld + 1u)) + L.n_local * (L.ld + 1u));
 }
 
+constexpr int PLAN_WORDS = 16;    // chain id | header block (4 words) | up to 10 partner ids | pad
 struct PhaseArgs {
     Layout L;
     double* ll;            // [n_local] cached ln_like of the local chains (samplers.py:330 re-evaluates it)
@@ -108,6 +109,8 @@ struct PhaseArgs {
     const uint32_t* perm_tab;   // [N] shuffle order of this generation, position -> chain id (nullptr: evaluate the bijection)
     const uint32_t* inv_tab;    // [N] its inverse, chain id -> position
     const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
+    const uint32_t* plan;       // [N * PLAN_WORDS] by position in shuffle order: chain id, header block, partner ids of
+                                // this generation, precomputed by plan_kernel (nullptr: drawn in the update kernel)
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     unsigned long long* stamps;  // diagnostic build only
     double* pack;               // sparse exchange (world > 1): this rank's block [count u32 | pad | ids[cap] | rows[cap][ld]] or nullptr
@@ -366,7 +369,8 @@ __device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c)
 // ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
 template <int ALGO, int LPC, int DPL, int NP>
 __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
-                                              uint32_t* s_part, Work<DPL>& wk, unsigned long long* bpm_stamp = nullptr) {
+                                              uint32_t* s_part, Work<DPL>& wk, const uint32_t* rec = nullptr,
+                                              unsigned long long* bpm_stamp = nullptr) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
 #ifndef BPM_SCALAR_PARTNERS
 #define BPM_SCALAR_PARTNERS 0   // measured: 19.8 us/generation with lane-parallel partners vs 25.9 all-scalar (cfg2)
@@ -408,7 +412,15 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     u32x4 h0;
     Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
     part.lds = s_part + cw * MAX_PARTNERS;
-    if (merged) {
+    // PLANNED (RL, one coordinate pair per lane, record of this update precomputed by plan_kernel): header words and
+    // partner ids are scalar loads issued at kernel entry, so the partner rows are requested BEFORE the lanes' own
+    // Philox evaluation instead of after it (draw -> table lookup -> row fetch was a serial chain of ~3 k cycles).
+    const bool planned = RL && DPL == 2 && rec != nullptr;
+    if (planned) {
+        h0.x = rec[1]; h0.y = rec[2]; h0.z = rec[3]; h0.w = rec[4];
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) part.r[i] = rec[5 + i];
+    } else if (merged) {
         const uint32_t uq = (uint32_t)q, hdr_lane = npairs + 2u * (uint32_t)NP;
         const uint32_t pidx = uq - npairs;                       // partner index for lanes [npairs, hdr_lane)
         const uint32_t slot = uq < npairs ? SLOT_DIM0 + uq : (uq < hdr_lane ? SLOT_PAIR0 + (pidx >> 2) : SLOT_HDR0);
@@ -482,6 +494,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         }
     }
     BPM_STAMP(7);
+    if (planned) wpair[0] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)q);      // overlaps with the row fetches
 
     // ---- per-pair draws: one Philox block per coordinate pair
     double eps_n[DPL], eps_u[DPL];
@@ -790,25 +803,54 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(const Phase
     const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
 #ifdef BPM_STAMPS
     unsigned long long bpm_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long bpm_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bpm_rt0)::"memory");
     BPM_STAMP(0);
 #endif
     uint32_t c;
-    const bool active = resolve_chain(a, w, c);
+    bool active;
+    const uint32_t* rec = nullptr;
+    if (LPC == WAVE && DPL == 2 && NP > 0 && ALGO == ALGO_DREAM && a.plan) {
+        // the update's record (by position in shuffle order) carries the chain id: wavefront-uniform scalar loads
+        active = w < a.n_items;
+        if (!active) return;
+        uint32_t pos;
+        if (a.mode == 0) {
+            pos = a.upd_off + w;
+        } else {
+            pos = a.inv_tab[a.lo + w];
+            if ((pos - a.upd_off) >= a.n_upd) return;
+        }
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        rec = a.plan + (uint32_t)(pos * PLAN_WORDS);
+        c = rec[0];
+    } else {
+        active = resolve_chain(a, w, c);
+    }
     if (LPC == WAVE && !active) return;          // whole wavefront idle
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
 #ifdef BPM_STAMPS
     bpm_stamp[1] = 0; BPM_STAMP(1);
-    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, bpm_stamp);
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp);
 #else
-    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk);
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec);
 #endif
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     BPM_STAMP(5);
     finish_update<ALGO, LPC, DPL>(a, c, active, q, wk, ll_prop);
     BPM_STAMP(6);
 #ifdef BPM_STAMPS
+    if (bpm_stamp[2] == 0) bpm_stamp[2] = bpm_rt0;
+    // slot 7: device-wide 100 MHz counter at the end of the wavefront (s_memtime counters are per CU, not comparable
+    // across CUs) with the XCD id in bits 60..63; slot 2 (in-kernel header draw, unused with plan records) holds the
+    // same counter at entry when the wavefront took the planned path
+    {
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        bpm_stamp[7] = (rt & 0x0FFFFFFFFFFFFFFFull) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 60);
+    }
     if (a.stamps && lane == 0) for (int i = 0; i < 8; ++i) a.stamps[(uint64_t)w * 8 + i] = bpm_stamp[i];
 #endif
 }
@@ -992,6 +1034,45 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
 }
 
 // Outlier-chain reset (Vrugt et al. 2009, DREAM; NOT in the reference -- extension).
+// Records of K consecutive generations in one launch, one thread per (generation, position in shuffle order):
+// everything of an update that depends only on (seed, generation, chain id) -- never on chain states -- so it can
+// be drawn ahead of time: the chain id at that position, its header block and its partner chains (dream.py:62-66;
+// the pool of a position in the first group is the second group and vice versa, whatever `flip` says about the
+// order of the two half generations, demc.py:95-100).  Same Philox blocks, same arithmetic as the in-kernel path.
+struct PlanParams {
+    uint64_t seed, t0;
+    uint32_t n_gens, N, np, pad;
+};
+__global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)P.n_gens * P.N) return;
+    const uint32_t g = (uint32_t)(e / P.N), pos = (uint32_t)(e % P.N);
+    const uint64_t t = P.t0 + g;
+    const uint32_t* tg = tab + (uint64_t)g * P.N;
+    const uint32_t n_first = (P.N + 1u) / 2u;
+    const bool first = pos < n_first;
+    const uint32_t pool_off = first ? n_first : 0u, M = first ? P.N - n_first : n_first;
+    const uint32_t c = tg[pos];
+    uint32_t r[PLAN_WORDS];
+#pragma unroll
+    for (int i = 0; i < PLAN_WORDS; ++i) r[i] = 0u;
+    const u32x4 h = chain_block(P.seed, c, t, SLOT_HDR0);
+    r[0] = c; r[1] = h.x; r[2] = h.y; r[3] = h.z; r[4] = h.w;
+#pragma unroll
+    for (int p = 0; p < (PLAN_WORDS - 5) / 2; ++p) {
+        if ((uint32_t)p < P.np) {
+            const u32x4 wb = chain_block(P.seed, c, t, SLOT_PAIR0 + ((uint32_t)p >> 1));
+            uint32_t ia, ib;
+            distinct_pair((p & 1) ? wb.z : wb.x, (p & 1) ? wb.w : wb.y, M, ia, ib);
+            r[5 + 2 * p] = tg[pool_off + ia];
+            r[6 + 2 * p] = tg[pool_off + ib];
+        }
+    }
+    uint4* out = reinterpret_cast<uint4*>(plan + e * PLAN_WORDS);
+#pragma unroll
+    for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+}
+
 // omega_i = mean ln_like of chain i over the history rows [r0, rows).
 __global__ void omega_kernel(const double* llhist, uint32_t n_local, uint32_t r0, uint32_t rows, double* omega) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -168,6 +168,8 @@ struct bpm_sampler {
     uint32_t* perm_tab = nullptr;   // [PERM_CHUNK * N] shuffle orders of the generations [tab_t0, tab_t0 + tab_K)
     uint32_t* inv_tab = nullptr;
     int64_t tab_t0 = -1;
+    uint32_t* plan_tab = nullptr;   // [plan_K * N * PLAN_WORDS] update records of the same generations (plan_kernel) or nullptr
+    int plan_K = 0;                 // generations the plan table holds (<= PERM_CHUNK; 0: no plan)
     int tab_K = 0;
     int tab_shuffle = -1;
     double* gamma_tab = nullptr;    // [dim + 1]
@@ -305,7 +307,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -400,6 +402,16 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
     CKD(dev_alloc(&s->perm_tab, (size_t)PERM_CHUNK * s->N));
+    // update records drawn ahead (plan_kernel): the one-wavefront-per-chain DREAM kernels with compile-time pair count,
+    // while a launch is latency bound (measured on cfg2's target: 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at
+    // 8192, 24.9 vs 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the
+    // shorter critical path gains: 42.7 vs 41.6, 77.9 vs 75.8 at 65536)
+    if (s->n_local <= 16384 && s->N <= 131072 && cfg->algo == BPM_ALGO_DREAM && cfg->del_pairs == 3 && s->shape.idx == 3 && tid != BPM_TARGET_HOST_CALLBACK &&
+        tid != BPM_TARGET_BANANA_2D && getenv("BPM_NO_PLAN") == nullptr && getenv("BPM_NO_PERM_TAB") == nullptr) {
+        const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
+        s->plan_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
+        CKD(dev_alloc(&s->plan_tab, (size_t)s->plan_K * s->N * PLAN_WORDS));
+    }
     CKD(dev_alloc(&s->inv_tab, (size_t)PERM_CHUNK * s->N));
     CKD(dev_alloc(&s->gamma_tab, (size_t)s->dim + 1));
     if (cfg->algo == BPM_ALGO_DEMC_SYNC) CKD(dev_alloc(&s->x_next, row_d));
@@ -555,7 +567,8 @@ static int allgather_state(bpm_sampler* s) {
 static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
     const int shuffle = s->opts.shuffle != 0 ? 1 : 0;
     if (s->tab_shuffle == shuffle && t >= s->tab_t0 && t < s->tab_t0 + s->tab_K) return 0;
-    const int K = (int)std::max<int64_t>(1, std::min<int64_t>(PERM_CHUNK, n_ahead));
+    int K = (int)std::max<int64_t>(1, std::min<int64_t>(PERM_CHUNK, n_ahead));
+    if (s->plan_tab) K = std::min(K, s->plan_K);
     PermKeys keys;
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
@@ -563,6 +576,11 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, keys, (uint32_t)K, s->N,
                        s->perm_tab, s->inv_tab);
     HIPCK(hipGetLastError());
+    if (s->plan_tab) {
+        PlanParams pp{s->cfg.seed, (uint64_t)t, (uint32_t)K, s->N, (uint32_t)s->cfg.del_pairs, 0u};
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, pp, s->perm_tab, s->plan_tab);
+        HIPCK(hipGetLastError());
+    }
     s->tab_t0 = t;
     s->tab_K = K;
     s->tab_shuffle = shuffle;
@@ -621,6 +639,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.pk = pk;
         a.perm_tab = s->perm_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
+        a.plan = s->plan_tab ? s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS : nullptr;
         { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
           if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
         a.gamma_tab = s->gamma_tab;
