@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbipymc_hip.so")
+LIB_PATH = os.environ.get("BPM_LIB_PATH") or os.path.join(_HERE, "libbipymc_hip.so")   # override: experiment builds (tools/)
 
 ABI_VERSION = 1
 ALGO_DEMC, ALGO_DREAM, ALGO_DEMC_SYNC = 0, 1, 2

@@ -779,6 +779,24 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     }
 }
 
+// The kernel argument block is read with scalar loads.  Left alone, the compiler loads each field right before its
+// first use -- ~80 separate s_load + s_waitcnt pairs threaded through the kernel's branches.  Naming the hot fields as
+// SGPR inputs of an empty asm statement in the entry block makes them live there: the loads coalesce into a few wide
+// s_load_dwordx8/x16 behind one wait.  Measured: 13.1 vs 15.2 us/generation for the 4-lanes-per-chain kernel
+// (cfg5/8), no change with one lane per chain, and a LOSS with one wavefront per chain (17.1 vs 15.8, cfg2: there
+// the lazy loads hide behind the row fetches) -- so only kernels with several chains per wavefront do it.
+template <int LPC>
+__device__ __forceinline__ void pin_args(const PhaseArgs& a) {
+    if (LPC != WAVE) {
+        asm volatile("" ::"s"(a.L.G), "s"(a.L.ld), "s"(a.L.dim), "s"(a.ll), "s"(a.hist_row), "s"(a.llhist_row), "s"(a.tparams),
+                     "s"(a.cr_state), "s"(a.acc_count), "s"(a.perm_tab), "s"(a.inv_tab), "s"(a.gamma_tab), "s"(a.plan), "s"(a.pack),
+                     "s"(a.trace_i32), "s"(a.thr[0]), "s"(a.thr[1]), "s"(a.thr[2]), "s"(a.seed), "s"(a.t), "s"(a.k), "s"(a.N),
+                     "s"(a.lo), "s"(a.upd_off), "s"(a.n_upd), "s"(a.pool_off), "s"(a.M), "s"(a.mode), "s"(a.n_items), "s"(a.n_cr));
+        asm volatile("" ::"s"(a.adapt_on), "s"(a.cr_gate), "s"(a.hist_len), "s"(a.epsilon), "s"(a.u_epsilon), "s"(a.L.n_local),
+                     "s"(a.L.world), "s"(a.L.magic), "s"(a.counters), "s"(a.pack_cap), "s"(a.pack_nsub), "s"(a.pack_stride));
+    }
+}
+
 // Which chain does this subgroup update?  mode 0: work item = position in shuffle order (all items
 // active); mode 1: work item = local chain, active iff its position falls in the phase's group.
 __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, uint32_t& c) {
@@ -796,7 +814,18 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 }
 
 template <int ALGO, int TARGET, int LPC, int DPL, int NP>
-__global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(const PhaseArgs a) {
+__global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
+#ifdef BPM_PRELOAD
+    // the four values that locate a wavefront's update record, as leading scalar arguments: with
+    // -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs at wavefront launch (no kernarg load, one miss less
+    // on the critical path); they repeat a.plan, a.upd_off, a.n_items, a.mode
+    const uint32_t* pl_plan, uint32_t pl_upd_off, uint32_t pl_n_items, uint32_t pl_mode,
+#endif
+    const PhaseArgs a) {
+#ifndef BPM_PRELOAD
+    const uint32_t* pl_plan = a.plan;
+    const uint32_t pl_upd_off = a.upd_off, pl_n_items = a.n_items, pl_mode = a.mode;
+#endif
     __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
     const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
@@ -807,22 +836,23 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(const Phase
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bpm_rt0)::"memory");
     BPM_STAMP(0);
 #endif
+    pin_args<LPC>(a);
     uint32_t c;
     bool active;
     const uint32_t* rec = nullptr;
-    if (LPC == WAVE && DPL == 2 && NP > 0 && ALGO == ALGO_DREAM && a.plan) {
+    if (LPC == WAVE && DPL == 2 && NP > 0 && ALGO == ALGO_DREAM && pl_plan) {
         // the update's record (by position in shuffle order) carries the chain id: wavefront-uniform scalar loads
-        active = w < a.n_items;
+        active = w < pl_n_items;
         if (!active) return;
         uint32_t pos;
-        if (a.mode == 0) {
-            pos = a.upd_off + w;
+        if (pl_mode == 0) {
+            pos = pl_upd_off + w;
         } else {
             pos = a.inv_tab[a.lo + w];
-            if ((pos - a.upd_off) >= a.n_upd) return;
+            if ((pos - pl_upd_off) >= a.n_upd) return;
         }
         pos = __builtin_amdgcn_readfirstlane(pos);
-        rec = a.plan + (uint32_t)(pos * PLAN_WORDS);
+        rec = pl_plan + (uint32_t)(pos * PLAN_WORDS);
         c = rec[0];
     } else {
         active = resolve_chain(a, w, c);

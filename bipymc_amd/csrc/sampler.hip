@@ -85,7 +85,12 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
 }
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
+#ifdef BPM_PRELOAD
+    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.plan,
+                       a.upd_off, a.n_items, a.mode, a);
+#else
     hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
+#endif
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_propose(const PhaseArgs& a, hipStream_t s) {
