@@ -49,6 +49,7 @@ constexpr int WAVE = 64;
 // (no workgroup barrier anywhere), so this is purely a dispatch-granularity choice.  Measured (profiles/): one
 // wavefront per workgroup is best for one-wavefront-per-chain (d=100) and one-lane-per-chain (d=2) kernels, four
 // wavefronts for the 4-lanes-per-chain kernel (d=8: 14.8 vs 17.0 us/generation at N=32768).
+// (re-measured with the final kernel: 128- or 256-thread workgroups for one wavefront per chain stay within 1 % of 64)
 constexpr int block_for(int lpc) { return (lpc == 4 || lpc == 16) ? 256 : 64; }
 constexpr int MAX_CR = 8;
 constexpr int TRACE_I32 = 32;   // ints per chain in the debug trace
