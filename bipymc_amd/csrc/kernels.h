@@ -331,10 +331,9 @@ __device__ __forceinline__ void box_muller_pair_f32(uint32_t w1, uint32_t w2, do
     n1 = (double)(r * __builtin_amdgcn_sinf(u2));
 }
 
-// Partner chains of chain c (pool positions -> global ids through the generation's bijection).
-// FAST (one wavefront per chain, compile-time pair count): c is wavefront-uniform, so the pair
-// draws and the Feistel walks run on the scalar unit and the ids live in SGPRs.  Otherwise the
-// lanes of the subgroup resolve them in parallel and hand them over through LDS.
+// Partner chains of chain c (pool positions -> global ids through the generation's bijection): in registers when
+// the pair count is a compile-time constant and a chain is one lane or one wavefront (make_proposal: FAST / RL /
+// planned paths), otherwise resolved by the lanes of the subgroup in parallel and handed over through LDS.
 template <int LPC, int NPART_CT>
 struct Partners {
     uint32_t r[NPART_CT > 0 ? NPART_CT : 1];
@@ -373,13 +372,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
                                               uint32_t* s_part, Work<DPL>& wk, const uint32_t* rec = nullptr,
                                               unsigned long long* bpm_stamp = nullptr) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
-#ifndef BPM_SCALAR_PARTNERS
-#define BPM_SCALAR_PARTNERS 0   // measured: 19.8 us/generation with lane-parallel partners vs 25.9 all-scalar (cfg2)
-#endif
-    // FAST: partner ids straight into registers -- every lane for itself when a lane IS a chain (LPC == 1: no
-    // other lane to share the work with, so the LDS hand-over loop would only re-evaluate the same Philox
-    // block once per partner), or on the scalar unit (experiment switch) for one wavefront per chain
-    constexpr bool FAST = (NP > 0) && (LPC == 1 || ((LPC == WAVE) && (BPM_SCALAR_PARTNERS != 0)));
+    // FAST: partner ids straight into registers, every lane for itself, when a lane IS a chain (LPC == 1: no other
+    // lane to share the work with, so the LDS hand-over loop would only re-evaluate the same Philox block once per
+    // partner).  (Resolving them on the scalar unit for one wavefront per chain measured slower than the lane-parallel
+    // RL path below: 25.9 vs 19.8 us/generation at cfg2.)
+    constexpr bool FAST = (NP > 0) && (LPC == 1);
     constexpr bool SNK_DIRECT = (LPC == 1);
     const uint32_t dim = a.L.dim, ld = a.L.ld;
     const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;

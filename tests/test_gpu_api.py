@@ -210,10 +210,12 @@ def test_rccl_one_rank_communicator():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-def test_sharded_kernel_path_on_one_gpu():
-    """world_size > 1 launches one work item per LOCAL chain and filters by the chain's position in the
-    shuffle order (inverse table); forcing that path on one GPU must reproduce the position-ordered path
-    bit for bit, for every kernel shape."""
+def test_alternative_kernel_paths_on_one_gpu():
+    """Kernel paths that a small single-GPU run does not take by itself must reproduce the default one bit for bit,
+    for every kernel shape: BPM_FORCE_MODE1 -- world_size > 1 launches one work item per LOCAL chain and filters by
+    the chain's position in the shuffle order (inverse table); BPM_NO_PLAN -- header block and partner ids drawn
+    inside the update kernel (what > 16384 chains per GPU use) instead of read from plan_kernel's records;
+    BPM_NO_PERM_TAB -- the shuffle bijection walked in the kernel instead of looked up; and combinations."""
     import subprocess
     import sys
     code = r'''
@@ -235,16 +237,19 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
 '''
     import tempfile
     res = []
-    for force in (False, True):
+    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB")
+    for on in ((), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN")):
         env = dict(os.environ)
-        env.pop("BPM_FORCE_MODE1", None)
-        if force:
-            env["BPM_FORCE_MODE1"] = "1"
+        for k in switches:
+            env.pop(k, None)
+        for k in on:
+            env[k] = "1"
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
             res.append(np.load(f))
-    assert np.array_equal(res[0], res[1])
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)
 
 
 @pytest.mark.parametrize("exchange", ["sparse", "sparse_overflow", "dense"])
