@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <atomic>
@@ -452,7 +453,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if ((s->world > 1 || s->comm) && cfg->algo != BPM_ALGO_DEMC_SYNC && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
         s->sparse_enabled = getenv("BPM_DENSE_EXCHANGE") == nullptr;
         s->xnsub = 1u;
-        while (s->xnsub < 16u && 2u * s->xnsub * 8u <= s->n_local) s->xnsub *= 2u;      // power of two, >= 8 chains each
+        // 4 sub-blocks: ~175 acceptances per counter and half generation at cfg2 cost the same on one GPU as 16
+        // sub-blocks (23.2 vs 23.0 us/generation through a one-rank communicator; ONE counter: 34 us), and the
+        // capacity margin, hence the bytes on the wire, shrinks with the count per sub-block (1.5 x instead of 2.2 x)
+        uint32_t nsub_max = 4u;
+        if (const char* e = getenv("BPM_XNSUB")) nsub_max = (uint32_t)std::max(1, std::min(64, atoi(e)));     // tuning switch
+        while (2u * s->xnsub <= nsub_max && 2u * s->xnsub * 8u <= s->n_local) s->xnsub *= 2u;      // power of two, >= 8 chains each
         s->xcap_max = ((s->n_local + s->xnsub - 1u) / s->xnsub + 1u) & ~1u;    // every chain of a sub-block accepted
         s->xcap = s->xcap_max;                               // first chunk: cannot overflow; then sized from the counts seen
         const size_t pk_doubles = (size_t)s->world * s->xnsub * s->xstride();

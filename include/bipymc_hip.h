@@ -145,7 +145,7 @@ int bpm_synchronize(bpm_handle_t h);
 int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
 /* Exchange policy for world_size > 1 (the Allgather of demc.py:93-94,116-117).  Outside DREAM's CR adaptation
  * only the rows that were ACCEPTED in a half generation have changed, so by default ranks all-gather
- * fixed-capacity packed blocks (up to 16 sub-blocks [count | ids | rows] per rank, a counter each) and scatter
+ * fixed-capacity packed blocks (up to 4 sub-blocks [count | ids | rows] per rank, a counter each) and scatter
  * them into their replicas.  Generations run in chunks of 64 under a device-side checkpoint; a chunk in which a
  * sub-block saw more acceptances than its capacity is rolled back and replayed with the dense all-gather (draws
  * are counter-addressed, so the result is the dense run's, bit for bit).  sparse = 0 selects the dense exchange
