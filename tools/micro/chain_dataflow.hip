@@ -46,8 +46,13 @@ __host__ __device__ inline uint32_t partner_pos(const Params& P, uint32_t g, uin
     return pos < half ? half + r : r;
 }
 
+#ifdef PLAIN_ACCESS      // boundary mode only: ordinary cached loads / stores, as the sampler's kernels use (dataflow results are then invalid)
+__device__ __forceinline__ double ld_agent(const double* p) { return *p; }
+__device__ __forceinline__ void st_agent(double* p, double v) { *p = v; }
+#else
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 
 template <bool DATAFLOW>
 __global__ __launch_bounds__(64) void update_kernel(const Params P, uint32_t g_fixed, uint32_t group_fixed) {
@@ -160,7 +165,12 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<double> got((G + 1) * row);
-    for (int mode = 0; mode < 2; ++mode) {
+#ifdef PLAIN_ACCESS
+    const int n_modes = 1;
+#else
+    const int n_modes = 2;
+#endif
+    for (int mode = 0; mode < n_modes; ++mode) {
         float best = 1e30f;
         size_t bad = 0;
         unsigned h_abort = 0, h_spins = 0;
