@@ -319,6 +319,24 @@ __device__ __forceinline__ void store_row(double* row, int q, uint32_t ld, const
     }
 }
 
+// Streaming (non-temporal) row store for what the update kernels write and do not read back in the same launch:
+// history rows and the Welford moments.  An ordinary store leaves the line dirty in the XCD's L2 until the
+// end-of-kernel release writes everything back -- with 3.3 MB of history per launch that flush sat on the critical
+// path between the two half generations: 14.4 vs 15.7 us/generation at cfg2, 72.0 vs 76.2 at N=65536.  (Agent- or
+// system-scope stores measured slower, 16.5; the accepted state rows gain nothing, they are few.)
+typedef double bpm_d2v __attribute__((ext_vector_type(2)));
+template <int LPC, int DPL>
+__device__ __forceinline__ void store_row_stream(double* row, int q, uint32_t ld, const double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        if (2 * pi < ld) {
+            bpm_d2v t = {v[2 * u], v[2 * u + 1]};
+            __builtin_nontemporal_store(t, reinterpret_cast<bpm_d2v*>(row) + pi);
+        }
+    }
+}
+
 // Two standard normals from two words in float32 on the hardware transcendental units
 // (v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32; the trig units take revolutions, so
 // cos(2 pi u2) needs no multiply and no range reduction).  Used for the per-generation jitter
@@ -746,7 +764,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
             store_row<LPC, DPL>(sub + 2 + a.pack_cap + (uint32_t)(slot * ld), q, ld, nv);
         }
     }
-    if (a.hist_row) store_row<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
+    if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
     if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
@@ -761,8 +779,8 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                 mean[s] = mean[s] + d1 / cntp;
                 m2[s] = m2[s] + d1 * (nv[s] - mean[s]);
             }
-            store_row<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
-            store_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+            store_row_stream<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
+            store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
         }
         if (q == 0) {
             const bool gated = a.adapt_on && a.cr_gate;

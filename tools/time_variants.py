@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, %r)
 from bipymc_amd import _lib as L
@@ -18,9 +18,8 @@ from bipymc_amd.engine import HipEngine
 from bipymc_amd.utils import d100_gauss
 tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
 out = []
-import os
 for N, G in [tuple(int(v) for v in s.split(':')) for s in os.environ.get('SIZES', '8192:1000,65536:200').split(',')]:
-    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=1, burnin_gen=0)
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=1, burnin_gen=0, keep_history=not os.environ.get('NO_HISTORY'))
     e.set_state(np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0))
     e.reserve_history(3 * G + 60)
     e.begin_run()
