@@ -399,7 +399,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     const uint32_t dim = a.L.dim, ld = a.L.ld;
     const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;
     // state-dependent loads first: they overlap with all the draw arithmetic below
-    load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);
+    load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);      // (a non-temporal load of this read-once row measured no faster)
     wk.ll_cur = a.ll[c - a.lo];
     wk.acc_prev = a.acc_count[c - a.lo];
     double pcr[MAX_CR];                        // p_cr (uniform pointer: one scalar load of the whole block)
@@ -969,6 +969,11 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
     __shared__ double s_d[ADAPT_THREADS / WAVE][MAX_CR], s_n[ADAPT_THREADS / WAVE][MAX_CR];
     __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
     const int tid = threadIdx.x;
+    // the adaptation state, requested at entry (uniform address: scalar loads) so that its miss overlaps with the
+    // slot loads instead of following the reduction
+    double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
     double acc_d[MAX_CR], acc_n[MAX_CR];
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
@@ -1006,11 +1011,8 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
     }
     __syncthreads();
     if (tid == 0) {
-        // the whole state in registers first (one burst of loads), written back once: the dependent
-        // read-modify-write chain through global memory was most of this kernel's 11 us
-        double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
-#pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
+        // the whole state is in registers (loaded at entry), written back once: the dependent read-modify-write
+        // chain through global memory was most of this kernel's 11 us
         bool any = false;
 #pragma unroll
         for (int m = 0; m < MAX_CR; ++m) {
