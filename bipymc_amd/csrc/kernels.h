@@ -295,6 +295,7 @@ struct Work {
     uint32_t acc_hi, acc_lo;   // words of the accept uniform
     double ll_cur;             // cached ln_like of the current state, fetched early
     uint32_t acc_prev;         // this chain's accept counter, fetched early
+    double w_mean[DPL], w_m2[DPL];   // burn-in only: Welford moments of this chain's own history, fetched early
     int cr_idx, d_prime, jump, snk;
     uint32_t maskbits;
 };
@@ -402,6 +403,10 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);      // (a non-temporal load of this read-once row measured no faster)
     wk.ll_cur = a.ll[c - a.lo];
     wk.acc_prev = a.acc_count[c - a.lo];
+    if (DREAM && a.adapt_on) {                 // dream.py:128: requested here, used after the proposal and after the accept test
+        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_mean);
+        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_m2);
+    }
     double pcr[MAX_CR];                        // p_cr (uniform pointer: one scalar load of the whole block)
     if (DREAM) {
 #pragma unroll
@@ -428,14 +433,25 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     u32x4 h0;
     Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
     part.lds = s_part + cw * MAX_PARTNERS;
-    // PLANNED (RL, one coordinate pair per lane, record of this update precomputed by plan_kernel): header words and
-    // partner ids are scalar loads issued at kernel entry, so the partner rows are requested BEFORE the lanes' own
-    // Philox evaluation instead of after it (draw -> table lookup -> row fetch was a serial chain of ~3 k cycles).
-    const bool planned = RL && DPL == 2 && rec != nullptr;
+    // PLANNED (record of this update precomputed by plan_kernel): header words and partner ids are loads issued at
+    // kernel entry (scalar ones when a wavefront is one chain), so the partner rows are requested BEFORE the lanes'
+    // own Philox evaluation instead of after it (draw -> table lookup -> row fetch was a serial chain of ~3 k
+    // cycles), and the header / pair / snooker blocks are not evaluated here at all.
+    // (one wavefront per chain only: with several chains per wavefront the records measured no gain -- cfg5/8 13.8 vs
+    // 13.9 us/generation -- or a loss -- cfg3 14.6 vs 12.3)
+    const bool planned = (LPC == WAVE) && rec != nullptr;
+    // the coordinate-pair blocks follow the row requests when a wavefront is one chain with one pair per lane
+    const bool dims_late = planned && RL && DPL == 2;
     if (planned) {
         h0.x = rec[1]; h0.y = rec[2]; h0.z = rec[3]; h0.w = rec[4];
+        if (FAST || RL) {
 #pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) part.r[i] = rec[5 + i];
+            for (int i = 0; i < 2 * NP; ++i) part.r[i] = rec[5 + i];
+        }
+        if (!dims_late) {
+#pragma unroll
+            for (int u = 0; u < DPL / 2; ++u) wpair[u] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)(q + u * LPC));
+        }
     } else if (merged) {
         const uint32_t uq = (uint32_t)q, hdr_lane = npairs + 2u * (uint32_t)NP;
         const uint32_t pidx = uq - npairs;                       // partner index for lanes [npairs, hdr_lane)
@@ -479,7 +495,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     const double u_sel = (double)(h0.x >> 16) * 1.52587890625e-05;      // CR select (DREAM) / snooker select (DE-MC)
     const double u_gam = (double)(h0.x & 0xFFFFu) * 1.52587890625e-05;  // gamma = 1 jump select
     uint32_t snk_id[3] = {0u, 0u, 0u};
-    if (SNK_DIRECT && snk_possible) {                      // three distinct snooker partners, one Philox block
+    if (SNK_DIRECT && snk_possible && planned) {
+        snk_id[0] = rec[5 + 2 * P]; snk_id[1] = rec[6 + 2 * P]; snk_id[2] = rec[7 + 2 * P];
+    } else if (SNK_DIRECT && snk_possible) {               // three distinct snooker partners, one Philox block
         const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
         uint32_t iz, i1, i2;
         distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
@@ -490,7 +508,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     if (!(FAST || RL) || (snk_possible && !SNK_DIRECT)) {
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
-            s_part[cw * MAX_PARTNERS + idx] = pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
+            s_part[cw * MAX_PARTNERS + idx] = planned ? rec[5 + idx] : pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
         // a chain subgroup never spans wavefronts: LDS ops of one wavefront complete in order, so a wavefront-scope
         // fence (compiler ordering + lgkmcnt wait) is all the hand-over needs -- no workgroup barrier
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -510,7 +528,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         }
     }
     BPM_STAMP(7);
-    if (planned) wpair[0] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)q);      // overlaps with the row fetches
+    if (dims_late) wpair[0] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)q);      // overlaps with the row fetches
 
     // ---- per-pair draws: one Philox block per coordinate pair
     double eps_n[DPL], eps_u[DPL];
@@ -622,9 +640,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         BPM_STAMP(4);
         // CR statistic (dream.py:92-93,119-130): BEFORE the accept test, from the proposed jump
         if (a.adapt_on && a.cr_gate) {
-            const uint32_t li = c - a.lo;
-            double m2[DPL];
-            load_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+            const double* m2 = wk.w_m2;
             double dl = 0.0;
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -770,8 +786,8 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
             double mean[DPL], m2[DPL];
-            load_row<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
-            load_row<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+#pragma unroll
+            for (int s = 0; s < DPL; ++s) { mean[s] = wk.w_mean[s]; m2[s] = wk.w_m2[s]; }
             const double cntp = (double)(a.hist_len + 1);
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
@@ -856,7 +872,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     uint32_t c;
     bool active;
     const uint32_t* rec = nullptr;
-    if (LPC == WAVE && DPL == 2 && NP > 0 && ALGO == ALGO_DREAM && pl_plan) {
+    if (LPC == WAVE && pl_plan) {
         // the update's record (by position in shuffle order) carries the chain id: wavefront-uniform scalar loads
         active = w < pl_n_items;
         if (!active) return;
@@ -945,6 +961,10 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
     wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
     wk.ll_cur = a.ll[c - a.lo];
     wk.acc_prev = a.acc_count[c - a.lo];
+    if (ALGO == ALGO_DREAM && a.adapt_on) {
+        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * a.L.ld), q, a.L.ld, wk.w_mean);
+        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * a.L.ld), q, a.L.ld, wk.w_m2);
+    }
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
@@ -1089,7 +1109,7 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
 // order of the two half generations, demc.py:95-100).  Same Philox blocks, same arithmetic as the in-kernel path.
 struct PlanParams {
     uint64_t seed, t0;
-    uint32_t n_gens, N, np, pad;
+    uint32_t n_gens, N, np, snooker;     // np pairs (<= 5); snooker: also the three snooker partners (DE-MC, pools of >= 3)
 };
 __global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1115,6 +1135,14 @@ __global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* p
             r[5 + 2 * p] = tg[pool_off + ia];
             r[6 + 2 * p] = tg[pool_off + ib];
         }
+    }
+    if (P.snooker && P.np == 1u && M >= 3u) {          // DE-MC: the same block and arithmetic as make_proposal's in-kernel path
+        const u32x4 ws = chain_block(P.seed, c, t, SLOT_SNK);
+        uint32_t iz, i1, i2;
+        distinct_three(ws.x, ws.y, ws.z, M, iz, i1, i2);
+        r[7] = tg[pool_off + iz];
+        r[8] = tg[pool_off + i1];
+        r[9] = tg[pool_off + i2];
     }
     uint4* out = reinterpret_cast<uint4*>(plan + e * PLAN_WORDS);
 #pragma unroll

@@ -408,12 +408,14 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
     CKD(dev_alloc(&s->perm_tab, (size_t)PERM_CHUNK * s->N));
-    // update records drawn ahead (plan_kernel): the one-wavefront-per-chain DREAM kernels with compile-time pair count,
-    // while a launch is latency bound (measured on cfg2's target: 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at
-    // 8192, 24.9 vs 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the
-    // shorter critical path gains: 42.7 vs 41.6, 77.9 vs 75.8 at 65536)
-    if (s->n_local <= 16384 && s->N <= 131072 && cfg->algo == BPM_ALGO_DREAM && cfg->del_pairs == 3 && s->shape.idx == 3 && tid != BPM_TARGET_HOST_CALLBACK &&
-        tid != BPM_TARGET_BANANA_2D && getenv("BPM_NO_PLAN") == nullptr && getenv("BPM_NO_PERM_TAB") == nullptr) {
+    // update records drawn ahead (plan_kernel) for the fused device kernels, while a launch is latency bound.  Measured
+    // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
+    // 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the shorter critical
+    // path gains (42.7 vs 41.6, 77.9 vs 75.8 at 65536).
+    static const bool no_plan = getenv("BPM_NO_PLAN") != nullptr || getenv("BPM_NO_PERM_TAB") != nullptr;
+    const uint32_t plan_max_local = getenv("BPM_PLAN_MAX") ? (uint32_t)atoi(getenv("BPM_PLAN_MAX")) : 16384u;     // tuning switch
+    if (!no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local && (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) &&
+        tid != BPM_TARGET_HOST_CALLBACK) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
         s->plan_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
         CKD(dev_alloc(&s->plan_tab, (size_t)s->plan_K * s->N * PLAN_WORDS));
@@ -588,7 +590,8 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
                        s->perm_tab, s->inv_tab);
     HIPCK(hipGetLastError());
     if (s->plan_tab) {
-        PlanParams pp{s->cfg.seed, (uint64_t)t, (uint32_t)K, s->N, (uint32_t)s->cfg.del_pairs, 0u};
+        PlanParams pp{s->cfg.seed, (uint64_t)t, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
+                      (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, pp, s->perm_tab, s->plan_tab);
         HIPCK(hipGetLastError());
     }

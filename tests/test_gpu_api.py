@@ -215,7 +215,8 @@ def test_alternative_kernel_paths_on_one_gpu():
     for every kernel shape: BPM_FORCE_MODE1 -- world_size > 1 launches one work item per LOCAL chain and filters by
     the chain's position in the shuffle order (inverse table); BPM_NO_PLAN -- header block and partner ids drawn
     inside the update kernel (what > 16384 chains per GPU use) instead of read from plan_kernel's records;
-    BPM_NO_PERM_TAB -- the shuffle bijection walked in the kernel instead of looked up; and combinations."""
+    BPM_NO_PERM_TAB -- the shuffle bijection walked in the kernel instead of looked up; BPM_PLAN_MAX -- plan records
+    whatever the number of chains; and combinations."""
     import subprocess
     import sys
     code = r'''
@@ -237,13 +238,14 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
 '''
     import tempfile
     res = []
-    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB")
-    for on in ((), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN")):
+    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX")
+    for on in ((), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
+               ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1")):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)
         for k in on:
-            env[k] = "1"
+            env[k] = "1000000" if k == "BPM_PLAN_MAX" else "1"     # BPM_PLAN_MAX: plan records whatever the number of chains
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
