@@ -227,7 +227,7 @@ def main():
                        "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3> (DREAM, Gauss target, 64 lanes/chain, 3 pairs)",
+                         "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, true> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation)",
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
                          "launches_timed": n_launch, "avg_launch_us_event_pairs": pair_ms / pair_n * 1e3,
