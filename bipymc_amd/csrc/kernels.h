@@ -845,13 +845,14 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
     return active;
 }
 
-// HOT: the steady-state single-GPU case (see phase_args_hot) as its own instantiation.
-__host__ inline bool phase_args_hot(const PhaseArgs& a) {
-    return a.mode == 0 && a.plan != nullptr && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr && a.adapt_on == 0 &&
-           a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.u_epsilon > 0.0 && a.L.world == 1 && a.n_cr == 3 &&
-           a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr;
+// HOT: the steady-state single-GPU case as its own instantiation (1: with plan records, 2: without); 0 = general.
+__host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan) {
+    return a.mode == 0 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+           a.adapt_on == 0 && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
+           a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr &&
+           (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
-template <int ALGO, int TARGET, int LPC, int DPL, int NP, bool HOT = false>
+template <int ALGO, int TARGET, int LPC, int DPL, int NP, int HOT = 0>
 __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
 #ifdef BPM_PRELOAD
     // the four values that locate a wavefront's update record, as leading scalar arguments: with
@@ -876,15 +877,17 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
 #endif
     pin_args<LPC>(a);
     if (HOT) {
-        // the host launches this instantiation only when phase_args_hot(a) holds: the compiler drops every other path
-        // (898 instead of 2520 instructions, 53 instead of 144 branches) and schedules the loads across what were
-        // branch boundaries: 13.6 vs 14.4 us/generation at cfg2, 20.5 vs 22.4 at N=16384
-        __builtin_assume(pl_mode == 0); __builtin_assume(a.mode == 0); __builtin_assume(pl_plan != nullptr);
+        // the host launches this instantiation only when phase_args_hot() holds: the compiler drops every other path
+        // (cfg2's kernel: 898 instead of 2520 instructions, 53 instead of 144 branches) and schedules the loads across
+        // what were branch boundaries: 13.6 vs 14.4 us/generation at cfg2, 20.5 vs 22.4 at N=16384
+        __builtin_assume(pl_mode == 0); __builtin_assume(a.mode == 0);
         __builtin_assume(a.trace_i32 == nullptr); __builtin_assume(a.pack == nullptr); __builtin_assume(a.x_next == nullptr);
         __builtin_assume(a.adapt_on == 0); __builtin_assume(a.hist_row != nullptr); __builtin_assume(a.llhist_row != nullptr);
-        __builtin_assume(a.epsilon > 0.0); __builtin_assume(a.u_epsilon > 0.0); __builtin_assume(a.L.world == 1);
-        __builtin_assume(a.n_cr == 3); __builtin_assume(a.perm_tab != nullptr); __builtin_assume(a.inv_tab != nullptr);
+        __builtin_assume(a.epsilon > 0.0); __builtin_assume(a.L.world == 1);
+        __builtin_assume(a.perm_tab != nullptr); __builtin_assume(a.inv_tab != nullptr);
         __builtin_assume(a.lo == 0); __builtin_assume(a.stamps == nullptr);
+        if (ALGO == ALGO_DREAM) { __builtin_assume(a.u_epsilon > 0.0); __builtin_assume(a.n_cr == 3); }
+        if (HOT == 1) { __builtin_assume(pl_plan != nullptr); } else { __builtin_assume(pl_plan == nullptr); }
     }
     uint32_t c;
     bool active;

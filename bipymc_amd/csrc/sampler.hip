@@ -87,11 +87,12 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 #ifdef BPM_PRELOAD
-    if (ALGO == ALGO_DREAM && NP == 3 && LPC == WAVE && DPL == 2) {      // the headline shape has a specialised instantiation
+    {   // steady-state single-GPU launches take the specialised instantiation (kernels.h: HOT)
+        constexpr int HOT = (LPC == WAVE && DPL == 2) ? 1 : 2;          // the shape that reads plan records / the others
         static const bool no_hot = getenv("BPM_NO_HOT") != nullptr;
-        if (!no_hot && phase_args_hot(a)) {
-            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, (ALGO == ALGO_DREAM && NP == 3 && LPC == WAVE && DPL == 2)>),
-                               dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.plan, a.upd_off, a.n_items, a.mode, a);
+        if (!no_hot && phase_args_hot(a, ALGO == ALGO_DREAM, HOT == 1)) {
+            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
+                               a.plan, a.upd_off, a.n_items, a.mode, a);
             return;
         }
     }
