@@ -860,8 +860,35 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     // on the critical path); they repeat a.plan, a.upd_off, a.n_items, a.mode
     const uint32_t* pl_plan, uint32_t pl_upd_off, uint32_t pl_n_items, uint32_t pl_mode,
 #endif
-    const PhaseArgs a) {
-#ifndef BPM_PRELOAD
+    const PhaseArgs a_in) {
+    // HOT: the host launches this instantiation only when phase_args_hot() holds.  One wavefront per chain: what the
+    // predicate fixes is written into a private copy of the argument block (constants the compiler propagates; an
+    // assumption on a POINTER loaded from the kernarg segment does not survive address-space inference), the non-null /
+    // positive ones are assumed; every other path drops out -- cfg2's kernel: 637 instead of 2520 instructions, 33
+    // instead of 144 branches, 51 instead of 82 VGPRs -- and the loads move across what were branch boundaries:
+    // 12.6 vs 14.4 us/generation at cfg2.  Several chains per wavefront: the copy is not scalarised there (it ends up
+    // in scratch, 30 instead of 12.4 us/generation at cfg5/8), so those kernels only get the assumptions.
+    constexpr bool COPY = (HOT != 0) && (LPC == WAVE);
+    PhaseArgs a_hot;
+    if (COPY) {
+        a_hot = a_in;
+        a_hot.mode = 0; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
+        a_hot.x_next = nullptr; a_hot.adapt_on = 0; a_hot.stamps = nullptr; a_hot.lo = 0; a_hot.L.world = 1;
+        if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
+        if (HOT == 2) a_hot.plan = nullptr;
+    }
+    const PhaseArgs& a = COPY ? a_hot : a_in;
+    if (HOT) {
+        __builtin_assume(a_in.mode == 0); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
+        __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == 0); __builtin_assume(a_in.stamps == nullptr);
+        __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1);
+        __builtin_assume(a_in.hist_row != nullptr); __builtin_assume(a_in.llhist_row != nullptr); __builtin_assume(a_in.epsilon > 0.0);
+        __builtin_assume(a_in.perm_tab != nullptr); __builtin_assume(a_in.inv_tab != nullptr);
+        if (ALGO == ALGO_DREAM) { __builtin_assume(a_in.u_epsilon > 0.0); __builtin_assume(a_in.n_cr == 3); }
+    }
+#ifdef BPM_PRELOAD
+    if (HOT) { __builtin_assume(pl_mode == 0); __builtin_assume((pl_plan != nullptr) == (HOT == 1)); }
+#else
     const uint32_t* pl_plan = a.plan;
     const uint32_t pl_upd_off = a.upd_off, pl_n_items = a.n_items, pl_mode = a.mode;
 #endif
@@ -876,19 +903,6 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     BPM_STAMP(0);
 #endif
     pin_args<LPC>(a);
-    if (HOT) {
-        // the host launches this instantiation only when phase_args_hot() holds: the compiler drops every other path
-        // (cfg2's kernel: 898 instead of 2520 instructions, 53 instead of 144 branches) and schedules the loads across
-        // what were branch boundaries: 13.6 vs 14.4 us/generation at cfg2, 20.5 vs 22.4 at N=16384
-        __builtin_assume(pl_mode == 0); __builtin_assume(a.mode == 0);
-        __builtin_assume(a.trace_i32 == nullptr); __builtin_assume(a.pack == nullptr); __builtin_assume(a.x_next == nullptr);
-        __builtin_assume(a.adapt_on == 0); __builtin_assume(a.hist_row != nullptr); __builtin_assume(a.llhist_row != nullptr);
-        __builtin_assume(a.epsilon > 0.0); __builtin_assume(a.L.world == 1);
-        __builtin_assume(a.perm_tab != nullptr); __builtin_assume(a.inv_tab != nullptr);
-        __builtin_assume(a.lo == 0); __builtin_assume(a.stamps == nullptr);
-        if (ALGO == ALGO_DREAM) { __builtin_assume(a.u_epsilon > 0.0); __builtin_assume(a.n_cr == 3); }
-        if (HOT == 1) { __builtin_assume(pl_plan != nullptr); } else { __builtin_assume(pl_plan == nullptr); }
-    }
     uint32_t c;
     bool active;
     const uint32_t* rec = nullptr;
