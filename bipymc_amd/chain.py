@@ -29,6 +29,18 @@ class McmcChain(object):
         assert input_chain.shape[1] == self._dim                 # chain.py:119
         self._override = input_chain
 
+    def load_chain_state(self, chain_state):
+        self.chain = chain_state                                 # chain.py:95-96
+
+    def append_sample(self, theta_new):
+        """chain.py:51-54.  Samples are appended by the update kernel on the device; a host-side append would
+        fork this chain's history from the sampler's, so it is refused rather than silently diverging."""
+        raise NotImplementedError("bipymc_amd: chain histories are appended on the GPU by run_mcmc(); "
+                                  "use load_chain_state() to replace a chain's host-side view")
+
+    def auto_corr(self, lag):
+        pass                                                     # chain.py:98-102: a stub in the reference as well
+
     def __getitem__(self, get_index):
         if isinstance(get_index, slice):
             return self.chain[get_index]

@@ -138,3 +138,30 @@ def test_statistical_cfg1_shape_on_oracle():
     mean, std, _ = s.param_est(n_burn=10000)
     assert abs(mean[0] - 1.5) < 0.25 and abs(mean[1] - 1.5) < 0.25      # both modes visited
     assert 0.6 < std[0] < 1.2
+
+
+def test_attribute_and_method_surface_of_the_reference_classes():
+    """Every attribute and method SURVEY section 8(b) lists as readable on the reference's DreamMpi / DeMcMpi
+    (demc.py:14-338, dream.py:17-140, samplers.py:30-80, chain.py:13-124) exists here, with the reference's meaning."""
+    t = dblgauss_rv.BimodeGauss_2D()
+    common = ["am_chains", "n_chains", "dim", "comm", "rank_chain_ids", "n_accepted", "n_rejected", "local_n_accepted",
+              "local_n_rejected", "acceptance_fraction", "h5_file", "checkpoint", "warm_start", "frozen_ln_like_fn",
+              "run_mcmc", "param_est", "super_chain_mpi", "gather_all_chains", "iter_local_chains", "iter_all_chains",
+              "get_chain", "get_chain_rank", "save_state", "load_state", "init_chains", "init_warmstart_chain"]
+    dream_only = ["CR", "p_cr", "n_cr_updates", "delta_m", "gamma_scale", "del_pairs", "burnin_gen", "p_cr_update_gen", "n_cr"]
+    d = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, engine_factory=oracle_factory, seed=2,
+                 ln_kwargs={}, inflate=3.0)                       # unknown kwargs are accepted silently (samplers.py:36-43)
+    m = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, engine_factory=oracle_factory, seed=2)
+    for name in common + dream_only:
+        assert hasattr(d, name), name
+    for name in common:
+        assert hasattr(m, name), name
+    assert d.gamma_scale == 1.0 and d.burnin_gen == 300 and d.p_cr_update_gen == 50          # dream.py:20-27 defaults
+    assert list(d.rank_chain_ids) == list(range(8)) and d.comm.size == 1 and d.comm.rank == 0
+    assert d.local_n_accepted == 0 and d.local_n_rejected == 1                               # demc.py:67-68 before any update
+    assert abs(d.frozen_ln_like_fn(np.array([0.0, 0.0])) - t.ln_like(np.array([0.0, 0.0]))) < 1e-14
+    c = d.am_chains[3]
+    for name in ("chain", "current_pos", "global_id", "chain_len", "dim", "append_sample"):   # chain.py:13-124
+        assert hasattr(c, name), name
+    with pytest.raises(AssertionError):
+        DreamMpi(t.ln_like, np.zeros(2), n_chains=3, mpi_comm=None, engine_factory=oracle_factory)   # samplers.py:249
