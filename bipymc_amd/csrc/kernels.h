@@ -845,10 +845,11 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
     return active;
 }
 
-// HOT: the steady-state single-GPU case as its own instantiation (1: with plan records, 2: without); 0 = general.
-__host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan) {
+// HOT: the single-GPU cases as their own instantiations: 1 = steady state with plan records, 2 = steady state without,
+// 3 / 4 = the same during DREAM's CR adaptation (burn-in); 0 = the general kernel.
+__host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
     return a.mode == 0 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
-           a.adapt_on == 0 && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
+           (a.adapt_on != 0) == adapting && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
@@ -873,21 +874,21 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     if (COPY) {
         a_hot = a_in;
         a_hot.mode = 0; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
-        a_hot.x_next = nullptr; a_hot.adapt_on = 0; a_hot.stamps = nullptr; a_hot.lo = 0; a_hot.L.world = 1;
+        a_hot.x_next = nullptr; a_hot.adapt_on = (HOT >= 3) ? 1u : 0u; a_hot.stamps = nullptr; a_hot.lo = 0; a_hot.L.world = 1;
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
-        if (HOT == 2) a_hot.plan = nullptr;
+        if (HOT == 2 || HOT == 4) a_hot.plan = nullptr;
     }
     const PhaseArgs& a = COPY ? a_hot : a_in;
     if (HOT) {
         __builtin_assume(a_in.mode == 0); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
-        __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == 0); __builtin_assume(a_in.stamps == nullptr);
+        __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == ((HOT >= 3) ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
         __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1);
         __builtin_assume(a_in.hist_row != nullptr); __builtin_assume(a_in.llhist_row != nullptr); __builtin_assume(a_in.epsilon > 0.0);
         __builtin_assume(a_in.perm_tab != nullptr); __builtin_assume(a_in.inv_tab != nullptr);
         if (ALGO == ALGO_DREAM) { __builtin_assume(a_in.u_epsilon > 0.0); __builtin_assume(a_in.n_cr == 3); }
     }
 #ifdef BPM_PRELOAD
-    if (HOT) { __builtin_assume(pl_mode == 0); __builtin_assume((pl_plan != nullptr) == (HOT == 1)); }
+    if (HOT) { __builtin_assume(pl_mode == 0); __builtin_assume((pl_plan != nullptr) == (HOT == 1 || HOT == 3)); }
 #else
     const uint32_t* pl_plan = a.plan;
     const uint32_t pl_upd_off = a.upd_off, pl_n_items = a.n_items, pl_mode = a.mode;

@@ -87,12 +87,18 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 #ifdef BPM_PRELOAD
-    {   // steady-state single-GPU launches take the specialised instantiation (kernels.h: HOT)
-        constexpr int HOT = (LPC == WAVE && DPL == 2) ? 1 : 2;          // the shape that reads plan records / the others
+    {   // single-GPU launches take a specialised instantiation (kernels.h: HOT): steady state, or DREAM's burn-in
+        constexpr bool PLAN = (LPC == WAVE && DPL == 2);                  // the shape that reads plan records
+        constexpr int HOT_STEADY = PLAN ? 1 : 2, HOT_ADAPT = (ALGO == ALGO_DREAM) ? (PLAN ? 3 : 4) : HOT_STEADY;
         static const bool no_hot = getenv("BPM_NO_HOT") != nullptr;
-        if (!no_hot && phase_args_hot(a, ALGO == ALGO_DREAM, HOT == 1)) {
-            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
-                               a.plan, a.upd_off, a.n_items, a.mode, a);
+        if (!no_hot && phase_args_hot(a, ALGO == ALGO_DREAM, PLAN, false)) {
+            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_STEADY>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
+                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
+            return;
+        }
+        if (!no_hot && ALGO == ALGO_DREAM && phase_args_hot(a, true, PLAN, true)) {
+            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_ADAPT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
+                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
             return;
         }
     }
