@@ -1020,7 +1020,43 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
 // cr_state: p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
 // ---------------------------------------------------------------------------------
 constexpr int ADAPT_THREADS = 1024;     // one round of loads for N = 8192 (measured: 512 threads +5 us, 256 threads +16 us per generation)
-__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state) {
+constexpr int ADAPT_UNR = 8;            // independent load pairs in flight per thread
+constexpr uint32_t ADAPT_SPAN = ADAPT_THREADS * ADAPT_UNR;      // chains one workgroup covers in one round of loads
+
+// dream.py:132-140 given this generation's sums over all chains; the state arrives in registers and is written back once
+__device__ __forceinline__ void cr_apply(const double* tot_d, const double* tot_n, uint32_t n_cr, double* cr_state, double* p_cr,
+                                         double* delta_m, double* n_upd) {
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) {
+        if (m < (int)n_cr && tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
+    }
+    if (!any) return;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && n_upd[m] != 0.0) ? 1u : 0u;
+    if (nz == n_cr) {
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) s += p_cr[m];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) {
+        if (m < (int)n_cr) {
+            cr_state[m] = p_cr[m] / s;                                                          // dream.py:140
+            cr_state[MAX_CR + m] = delta_m[m];
+            cr_state[2 * MAX_CR + m] = n_upd[m];
+        }
+    }
+}
+
+// part == nullptr: ONE workgroup walks all N slots and applies the update (N <= 16384: one or two rounds of loads).
+// part != nullptr: workgroup b sums the slots of chains [b, b + 1) * ADAPT_SPAN in one round and leaves its sums in
+// part[b] = (delta sums[MAX_CR] | counts[MAX_CR]); cr_final_kernel adds the workgroups' sums in index order and applies
+// the update.  (One workgroup for everything took 170 us per generation at N = 262144: a serial chain of 32 rounds.)
+__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state, double* part) {
     __shared__ double s_d[ADAPT_THREADS / WAVE][MAX_CR], s_n[ADAPT_THREADS / WAVE][MAX_CR];
     __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
     const int tid = threadIdx.x;
@@ -1032,15 +1068,17 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
     double acc_d[MAX_CR], acc_n[MAX_CR];
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
-    constexpr int UNR = 8;                              // 8 independent load pairs in flight per thread
-    for (uint32_t base = tid; base < N; base += ADAPT_THREADS * UNR) {
+    constexpr int UNR = ADAPT_UNR;
+    const uint32_t lo = part ? blockIdx.x * ADAPT_SPAN : 0u;
+    const uint32_t hi = part ? (lo + ADAPT_SPAN < N ? lo + ADAPT_SPAN : N) : N;
+    for (uint32_t base = lo + tid; base < hi; base += ADAPT_THREADS * UNR) {
         int idx[UNR];
         double dl[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const uint32_t c = base + (uint32_t)u * ADAPT_THREADS;
-            idx[u] = c < N ? (int)*cridx_ptr(L, c) : -1;
-            dl[u] = c < N ? *delta_ptr(L, c) : 0.0;
+            idx[u] = c < hi ? (int)*cridx_ptr(L, c) : -1;
+            dl[u] = c < hi ? *delta_ptr(L, c) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -1062,38 +1100,32 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
     if (tid < (int)n_cr) {
         double d = 0.0, n = 0.0;
         for (int w = 0; w < ADAPT_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
+        if (part) {
+            part[(uint64_t)blockIdx.x * 2 * MAX_CR + tid] = d;
+            part[(uint64_t)blockIdx.x * 2 * MAX_CR + MAX_CR + tid] = n;
+        }
         tot_d[tid] = d; tot_n[tid] = n;
     }
     __syncthreads();
-    if (tid == 0) {
-        // the whole state is in registers (loaded at entry), written back once: the dependent read-modify-write
-        // chain through global memory was most of this kernel's 11 us
-        bool any = false;
+    if (tid == 0 && !part) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
+}
+
+__global__ __launch_bounds__(WAVE) void cr_final_kernel(const double* part, uint32_t n_blocks, uint32_t n_cr, double* cr_state) {
+    __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
+    const int tid = threadIdx.x;
+    double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
 #pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) {
-            if (m < (int)n_cr && tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
+    for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
+    if (tid < (int)n_cr) {
+        double d = 0.0, n = 0.0;
+        for (uint32_t b = 0; b < n_blocks; ++b) {           // workgroups in index order: the same sum on every rank, every run
+            d += part[(uint64_t)b * 2 * MAX_CR + tid];
+            n += part[(uint64_t)b * 2 * MAX_CR + MAX_CR + tid];
         }
-        if (any) {
-            uint32_t nz = 0;
-#pragma unroll
-            for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && n_upd[m] != 0.0) ? 1u : 0u;
-            if (nz == n_cr) {
-#pragma unroll
-                for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
-            }
-            double s = 0.0;
-#pragma unroll
-            for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) s += p_cr[m];
-#pragma unroll
-            for (int m = 0; m < MAX_CR; ++m) {
-                if (m < (int)n_cr) {
-                    cr_state[m] = p_cr[m] / s;                                                          // dream.py:140
-                    cr_state[MAX_CR + m] = delta_m[m];
-                    cr_state[2 * MAX_CR + m] = n_upd[m];
-                }
-            }
-        }
+        tot_d[tid] = d; tot_n[tid] = n;
     }
+    __syncthreads();
+    if (tid == 0) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
 }
 
 // Sparse exchange, receiving side: after the all-gather of the packed blocks PK[r] = [count | pad | ids[cap] | rows[cap][ld]]

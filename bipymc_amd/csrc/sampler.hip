@@ -175,7 +175,8 @@ struct bpm_sampler {
     double* w_m2 = nullptr;
     int64_t w_rows = 0;        // history rows folded into the Welford moments
     double* tparams = nullptr;
-    double* cr_state = nullptr;            // p_cr | delta_m | n_cr_updates (MAX_CR each)
+    double* cr_state = nullptr;
+    double* cr_part = nullptr;    // per-workgroup sums of the two-stage CR reduction (N > 16384)            // p_cr | delta_m | n_cr_updates (MAX_CR each)
     unsigned long long* counters = nullptr;  // device: [2] = NaN ratios
     uint32_t* acc_count = nullptr;           // device: accepted updates per local chain, this run
     int64_t gens_this_run_local = 0;
@@ -327,7 +328,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->counters, s->acc_count,
+    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -782,8 +783,16 @@ static int outlier_check(bpm_sampler* s) {
 
 static int finish_generation(bpm_sampler* s) {
     if (s->gen_adapt_on) {
-        hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
-                           s->cr_state);
+        if (s->N <= 2 * ADAPT_SPAN) {
+            hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
+                               s->cr_state, (double*)nullptr);
+        } else {            // one round of loads per workgroup, then the workgroups' sums in index order
+            const uint32_t nb = (s->N + ADAPT_SPAN - 1) / ADAPT_SPAN;
+            if (!s->cr_part) CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR));
+            hipLaunchKernelGGL(cr_adapt_kernel, dim3(nb), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
+                               s->cr_state, s->cr_part);
+            hipLaunchKernelGGL(cr_final_kernel, dim3(1), dim3(WAVE), 0, s->stream, s->cr_part, nb, (uint32_t)s->cfg.n_cr, s->cr_state);
+        }
         HIPCK(hipGetLastError());
         s->w_rows += 1;
     }

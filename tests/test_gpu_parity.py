@@ -212,6 +212,22 @@ def test_dream_generation_parity(d, N, P_):
     print("fraction of state entries bit-identical to the oracle per generation:", exact)
 
 
+def test_cr_adaptation_two_stage_reduction_matches_oracle():
+    """Above 16384 chains the per-generation CR reduction runs as one workgroup per 8192 chains plus a final kernel
+    (cr_adapt_kernel with partial sums + cr_final_kernel); same decisions, delta_m and p_cr as the oracle."""
+    d, N = 2, 20000
+    eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 77, del_pairs=3, burnin_gen=100, n_cr_gen=2, n_cr=3)
+    X = np.random.RandomState(5).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _start(eng, ora, X)
+    for g in range(6):
+        _check_generation(eng, ora, N, d, True, 6)
+    st = eng.stats()
+    assert ora.cr.n_cr_updates.sum() > 3 * N
+    np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
+    np.testing.assert_allclose(st["delta_m"], ora.cr.delta_m, rtol=1e-9)
+    np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+
+
 def test_dream_mixture_generation_parity():
     N, d = 40, 8
     eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, _mix_params(), 77, burnin_gen=4, n_cr_gen=2)
