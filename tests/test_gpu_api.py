@@ -466,3 +466,34 @@ def test_large_history_transfer_equals_row_by_row(dim, N, G):
         assert np.array_equal(H[g], e.get_history(g, g + 1)[0]), g
     assert np.array_equal(H[-1], e.get_state())
     e.close()
+
+
+def test_long_run_crosses_many_table_chunks_and_stays_stationary():
+    """20000 generations in one run_mcmc-sized step: 313 chunks of shuffle tables / plan records, a 33 GB history written
+    by streaming stores, generation counters far beyond the 16-bit range.  Started from exact draws of the target the
+    pooled moments of ALL rows must stay at the analytic values, and the last row must still be a plausible draw."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    np.random.seed(11)
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    N, G = 2048, 20000
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=9, burnin_gen=0)
+    e.set_state(g.rvs(N))
+    e.begin_run()
+    e.step(G)
+    st = e.stats()
+    assert st["k_gen"] == G and st["history_rows"] == G + 1
+    assert st["local_n_accepted"] + st["local_n_rejected"] == N * G + 1
+    assert 0.1 < st["local_n_accepted"] / (N * G) < 0.35
+    cnt, s1, s2, sh = e.reduce_moments(0)
+    assert cnt == N * (G + 1)
+    mean, var = sh + s1 / cnt, s2 / cnt - (s1 / cnt) ** 2
+    sig2 = np.arange(d) + 1.0
+    assert np.max(np.abs(mean) / np.sqrt(sig2)) < 0.02
+    assert abs(np.mean(var / sig2) - 1) < 0.01 and np.max(np.abs(var / sig2 - 1)) < 0.03
+    X = e.get_state()
+    assert abs(np.mean(X.var(axis=0) / sig2) - 1) < 0.05                      # the final population alone (2048 draws)
+    assert np.array_equal(e.get_history(G, G + 1)[0], X)
+    e.close()
