@@ -214,6 +214,13 @@ struct bpm_sampler {
     uint32_t* ckpt_acc = nullptr;
     unsigned long long* ckpt_counters = nullptr;
     int64_t n_sparse_chunks = 0, n_sparse_replays = 0;
+    // steady-state generations on one GPU are replayed as a HIP graph (a chain of 2 K kernel nodes per chunk of K generations)
+    // (a ring of executable graphs: refreshing the arguments of one that is still running would wait for it)
+    static constexpr int GRAPH_RING = 3;
+    hipGraphExec_t gexec[GRAPH_RING] = {nullptr, nullptr, nullptr};
+    int64_t gexec_gens[GRAPH_RING] = {0, 0, 0};       // generations each instantiated graph holds
+    int gexec_next = 0;
+    int64_t n_graph_chunks = 0;
     // run state
     bpm_run_opts_t opts{};
     bool run_open = false;
@@ -328,6 +335,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
+    for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
@@ -895,15 +903,80 @@ struct HostCkpt {
     int64_t k_gen, t_abs, hist_rows, rows_logical, w_rows;
 };
 
+// Up to one table window of steady-state generations (single GPU) as one graph launch.  *done_gens = 0: not applicable
+// here (too few generations left in the window), the caller runs a plain generation.
+constexpr int64_t GRAPH_MIN_GENS = 4;
+static int graph_chunk(bpm_sampler* s, int64_t n_left, PhaseLaunch fn, int64_t* done_gens) {
+    *done_gens = 0;
+    CK(ensure_perm_table(s, s->t_abs, n_left));                       // table / record kernels run outside the capture
+    const int64_t K = std::min<int64_t>(n_left, s->tab_t0 + s->tab_K - s->t_abs);
+    if (K < GRAPH_MIN_GENS) return 0;
+    if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + K));  // (a reallocation cannot be captured)
+    hipGraph_t graph = nullptr;
+    HIPCK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int64_t i = 0; i < K && rc == 0; ++i) {
+        s->sparse_active = false;
+        rc = prepare_generation(s, n_left - i);
+        if (rc == 0) {
+            for (int ph = 0; ph < 2; ++ph)
+                if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
+            rc = finish_generation(s);                                 // host counters only in the steady state
+        }
+    }
+    const hipError_t ec = hipStreamEndCapture(s->stream, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess) return fail(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ec));
+    const int slot = s->gexec_next;
+    s->gexec_next = (slot + 1) % bpm_sampler::GRAPH_RING;
+    hipGraphExec_t& ge = s->gexec[slot];
+    if (ge && s->gexec_gens[slot] == K) {                              // same topology: refresh the arguments in place
+        hipGraphNode_t err_node = nullptr;
+        hipGraphExecUpdateResult res;
+        if (hipGraphExecUpdate(ge, graph, &err_node, &res) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(ge);
+            ge = nullptr;
+        }
+    } else if (ge) {
+        (void)hipGraphExecDestroy(ge);
+        ge = nullptr;
+    }
+    if (!ge) {
+        const hipError_t ei = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+        if (ei != hipSuccess) { (void)hipGraphDestroy(graph); ge = nullptr; return fail(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ei)); }
+        s->gexec_gens[slot] = K;
+    }
+    const hipError_t el = hipGraphLaunch(ge, s->stream);
+    (void)hipGraphDestroy(graph);
+    if (el != hipSuccess) return fail(std::string("hipGraphLaunch failed: ") + hipGetErrorString(el));
+    s->n_graph_chunks += 1;
+    *done_gens = K;
+    return 0;
+}
+
 static int run_generations(const Group& g, int64_t n_gens) {
     bpm_sampler* s0 = g.h[0];
     PhaseLaunch fn = pick_fused(s0);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
     int64_t done = 0;
+    static const bool use_graph = getenv("BPM_GRAPH") != nullptr;      // opt-in: measured slower than stream launches here, see below
     while (done < n_gens) {
         const bool adapting = dream && s0->cfg.burnin_gen > s0->k_gen;          // dream.py:92: CR statistics travel in the dense block
         if (!(s0->sparse_enabled && !adapting)) {
+            // One GPU, no exchange, nothing but the two update kernels per generation (after burn-in: no cr_adapt, no
+            // outlier check, no moment rebuild): the launches of a whole chunk can be captured and replayed as ONE graph
+            // launch.  For empty kernels a dependent graph node costs 0.65 us less than a dependent stream launch
+            // (tools/micro/launch_overhead.hip: 1.92 vs 2.63 us), but with the update kernel and its 440-byte argument
+            // block the replay measured SLOWER: 13.1 vs 12.5 us/generation at cfg2 (host side 180 us per 64-generation
+            // chunk, fully hidden; a ring of executable graphs so that no update waits for a running one).  Hence opt-in
+            // (BPM_GRAPH=1), kept bit-identical by tests/test_gpu_api.py::test_alternative_kernel_paths_on_one_gpu.
+            if (use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !adapting && s0->cfg.algo != BPM_ALGO_DEMC_SYNC) {
+                int64_t Kg = 0;
+                CK(graph_chunk(s0, n_gens - done, fn, &Kg));
+                if (Kg > 0) { done += Kg; continue; }
+            }
             CK(group_generation(g, n_gens - done, false, fn));
             ++done;
             continue;

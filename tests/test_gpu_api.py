@@ -217,7 +217,8 @@ def test_alternative_kernel_paths_on_one_gpu():
     inside the update kernel (what > 16384 chains per GPU use) instead of read from plan_kernel's records;
     BPM_NO_PERM_TAB -- the shuffle bijection walked in the kernel instead of looked up; BPM_PLAN_MAX -- plan records
     whatever the number of chains; BPM_NO_HOT -- the general instantiation instead of the one specialised for the
-    steady-state single-GPU case (which the default run takes after burn-in); and combinations."""
+    steady-state single-GPU case (which the default run takes after burn-in); BPM_GRAPH -- HIP-graph replay of steady-state
+    chunks instead of stream launches; and combinations."""
     import subprocess
     import sys
     code = r'''
@@ -239,8 +240,8 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
 '''
     import tempfile
     res = []
-    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT")
-    for on in ((), ("BPM_NO_HOT",), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
+    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH")
+    for on in ((), ("BPM_NO_HOT",), ("BPM_GRAPH",), ("BPM_GRAPH", "BPM_NO_HOT"), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
                ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1")):
         env = dict(os.environ)
         for k in switches:

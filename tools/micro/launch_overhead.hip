@@ -25,6 +25,27 @@ int main() {
     printf("empty 1024x256      : %.2f us/launch\n", timeit(s, 2000, [&] { hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, d); }));
     printf("empty big-arg 4096x64: %.2f us/launch\n", timeit(s, 2000, [&] { hipLaunchKernelGGL(k_empty_big, dim3(4096), dim3(64), 0, s, b, d); }));
     printf("touch 6.5MB 3200x256: %.2f us/launch\n", timeit(s, 2000, [&] { hipLaunchKernelGGL(k_touch, dim3(3200), dim3(256), 0, s, x, 819200); }));
+    {   // the same dependent chain as ONE graph launch (stream capture of 2000 launches, replayed)
+        hipGraph_t g; hipGraphExec_t ge;
+        const int n = 2000;
+        for (int variant = 0; variant < 3; ++variant) {
+            hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+            for (int i = 0; i < n; ++i) {
+                if (variant == 0) hipLaunchKernelGGL(k_empty, dim3(4096), dim3(64), 0, s, d);
+                else if (variant == 1) hipLaunchKernelGGL(k_touch, dim3(3200), dim3(256), 0, s, x, 819200);
+                else hipLaunchKernelGGL(k_empty_big, dim3(4096), dim3(64), 0, s, b, d);
+            }
+            hipStreamEndCapture(s, &g);
+            hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            hipGraphLaunch(ge, s); hipStreamSynchronize(s);
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int r = 0; r < 5; ++r) hipGraphLaunch(ge, s);
+            hipStreamSynchronize(s);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / (5.0 * n);
+            printf("graph of %d x %s: %.2f us/launch\n", n, variant == 0 ? "empty 4096x64" : (variant == 1 ? "touch 6.5MB 3200x256" : "empty big-arg (640 B) 4096x64"), us);
+            hipGraphExecDestroy(ge); hipGraphDestroy(g);
+        }
+    }
     hipStream_t s0 = 0;
     printf("empty 4096x64 null stream: %.2f us/launch\n", timeit(s0, 2000, [&] { hipLaunchKernelGGL(k_empty, dim3(4096), dim3(64), 0, s0, d); }));
     return 0;
