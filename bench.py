@@ -224,7 +224,8 @@ def main():
                                    "n_chains=%d (%d per GPU), del_pairs=3, n_cr=3, steady state after %d burn-in "
                                    "generations, history appended every generation" % (n_chains, CHAINS_PER_GPU, BURNIN_GEN),
                        "n_chains": n_chains, "dim": DIM, "parallelism": "chains sharded x%d" % world,
-                       "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s},
+                       "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s,
+                       "exchange": eng.exchange_stats() if use_dist else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, true> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation)",
