@@ -117,6 +117,12 @@ struct PhaseArgs {
     double* pack;               // sparse exchange (world > 1): this rank's block [count u32 | pad | ids[cap] | rows[cap][ld]] or nullptr
     uint32_t pack_cap, pack_nsub, pack_stride;   // per sub-block: capacity (rows), count of sub-blocks, doubles per sub-block          // rows the block can take (even)
     double* x_next;             // mode 2 (synchronous DE-MC): new states go here, the state matrix stays frozen
+    // replay exchange (world > 1): the owner of a chain publishes ONE BYTE per update -- accepted or not -- and every
+    // other rank recomputes the accepted proposals itself (phase_replay_kernel): all inputs of a proposal (the replicated
+    // state matrix, counter-addressed draws, update records) are already on every rank
+    uint8_t* accbits;           // this rank's [n_local] accept bytes, written by the update kernel (or nullptr)
+    const uint8_t* accbits_all; // replay kernel: the gathered [N] bytes, by global chain id
+    uint32_t replay;            // 1 in phase_replay_kernel: the chain is remote -- nothing indexed by (chain - lo) may be touched
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
@@ -401,8 +407,12 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     const uint32_t P = NP > 0 ? (uint32_t)NP : a.P;
     // state-dependent loads first: they overlap with all the draw arithmetic below
     load_row<LPC, DPL>(row_ptr(a.L, c), q, ld, wk.x);      // (a non-temporal load of this read-once row measured no faster)
-    wk.ll_cur = a.ll[c - a.lo];
-    wk.acc_prev = a.acc_count[c - a.lo];
+    wk.ll_cur = 0.0;
+    wk.acc_prev = 0u;
+    if (!a.replay) {
+        wk.ll_cur = a.ll[c - a.lo];
+        wk.acc_prev = a.acc_count[c - a.lo];
+    }
     if (DREAM && a.adapt_on) {                 // dream.py:128: requested here, used after the proposal and after the accept test
         load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_mean);
         load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_m2);
@@ -751,6 +761,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     if (q == 0) {
         if (accepted) a.acc_count[li] = wk.acc_prev + 1u;
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
+        if (a.accbits) a.accbits[li] = accepted ? (uint8_t)1 : (uint8_t)0;
     }
     double nv[DPL];
 #pragma unroll
@@ -850,7 +861,7 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
     return a.mode == 0 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            (a.adapt_on != 0) == adapting && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
-           a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr &&
+           a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr && a.accbits == nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 template <int ALGO, int TARGET, int LPC, int DPL, int NP, int HOT = 0>
@@ -874,6 +885,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     if (COPY) {
         a_hot = a_in;
         a_hot.mode = 0; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
+        a_hot.accbits = nullptr; a_hot.replay = 0u;
         a_hot.x_next = nullptr; a_hot.adapt_on = (HOT >= 3) ? 1u : 0u; a_hot.stamps = nullptr; a_hot.lo = 0; a_hot.L.world = 1;
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
         if (HOT == 2 || HOT == 4) a_hot.plan = nullptr;
@@ -950,6 +962,37 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     }
     if (a.stamps && lane == 0) for (int i = 0; i < 8; ++i) a.stamps[(uint64_t)w * 8 + i] = bpm_stamp[i];
 #endif
+}
+
+// Replay exchange, receiving side: one work item per position of the half generation's update group; the item of a
+// chain that lives on ANOTHER rank and whose owner accepted its update (accbits_all) rebuilds that proposal -- same
+// records / draws / arithmetic as the owner's update kernel, hence the same bits -- and writes it into this rank's
+// replica.  Partner rows come from the other group, which nobody writes in this half generation; each row of the update
+// group is written by exactly one item.  No ln-like, no accept test, no history: those are the owner's.
+template <int ALGO, int LPC, int DPL, int NP>
+__global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const PhaseArgs a) {
+    __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
+    bool active = w < a.n_upd;
+    uint32_t pos = a.upd_off + (active ? w : 0u);
+    const uint32_t* rec = nullptr;
+    uint32_t c;
+    if (LPC == WAVE && a.plan) {
+        if (!active) return;
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        rec = a.plan + (uint32_t)(pos * PLAN_WORDS);
+        c = rec[0];
+    } else {
+        c = pos_to_chain(a, pos);
+    }
+    active = active && (c - a.lo) >= a.L.n_local && a.accbits_all[c] != 0;      // remote, and accepted by its owner
+    if (LPC == WAVE && !active) return;
+    if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);
+    Work<DPL> wk;
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec);
+    if (active) store_row<LPC, DPL>(row_ptr(a.L, c), q, a.L.ld, wk.p);
 }
 
 // Host-callback ln_like_fn: proposals out ...

@@ -151,6 +151,13 @@ static PhaseLaunch g_fused_mixture[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC 
 static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
                                         launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
 static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+template <int ALGO, int NP, int LPC, int DPL>
+static void launch_replay(const PhaseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((phase_replay_kernel<ALGO, LPC, DPL, NP>), dim3(grid_for(a.n_upd, LPC)), dim3(block_for(LPC)), 0, s, a);
+}
+// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][shape]: the same pair-count variants as the update kernels (no target: no ln-like)
+static PhaseLaunch g_replay[3][6] = {SHAPE_TABLE(launch_replay, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 3 COMMA),
+                                     SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 0 COMMA)};
 static PhaseLaunch g_commit[2][6] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
 static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
 static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
@@ -203,6 +210,12 @@ struct bpm_sampler {
     // sparse exchange (world > 1, outside CR adaptation): only accepted rows travel, in fixed-capacity packed blocks;
     // a chunk whose capacity was exceeded is rolled back to its checkpoint and replayed with the dense all-gather
     bool sparse_enabled = false;
+    // replay exchange (the default for world > 1 outside CR adaptation): owners publish one accept byte per update, every
+    // other rank recomputes the accepted proposals into its replica (phase_replay_kernel)
+    bool replay_enabled = false;
+    bool replay_active = false;   // the generation being prepared writes accept bytes
+    uint8_t* accbits_all = nullptr;   // [N] accept bytes by global chain id; this rank's block at rank * n_local
+    int64_t n_replay_gens = 0;
     bool sparse_active = false;   // the generation being prepared packs its accepted rows
     uint32_t xnsub = 1;           // sub-blocks per rank (a counter each; local chain li packs into sub-block li % xnsub)
     uint32_t xcap = 0, xcap_max = 0;   // capacity of a sub-block (rows per half generation, even) and its ceiling
@@ -337,7 +350,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -477,7 +490,14 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     }
     // (a one-rank communicator takes the same path, so a one-GPU box can time and test it through RCCL)
     if ((s->world > 1 || s->comm) && cfg->algo != BPM_ALGO_DEMC_SYNC && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
-        s->sparse_enabled = getenv("BPM_DENSE_EXCHANGE") == nullptr;
+        // BPM_EXCHANGE = dense | rows | replay (default replay); BPM_DENSE_EXCHANGE=1 is the older spelling of dense
+        const char* xe = getenv("BPM_EXCHANGE");
+        const bool want_dense = getenv("BPM_DENSE_EXCHANGE") != nullptr || (xe && std::strcmp(xe, "dense") == 0);
+        const bool want_rows = xe && std::strcmp(xe, "rows") == 0;
+        s->replay_enabled = !want_dense && !want_rows;
+        s->sparse_enabled = !want_dense && want_rows;
+        CKD(dev_alloc(&s->accbits_all, (size_t)s->N));
+        HIPCKD(hipMemsetAsync(s->accbits_all, 0, (size_t)s->N, s->stream));
         s->xnsub = 1u;
         // 4 sub-blocks: ~175 acceptances per counter and half generation at cfg2 cost the same on one GPU as 16
         // sub-blocks (23.2 vs 23.0 us/generation through a one-rank communicator; ONE counter: 34 us), and the
@@ -710,6 +730,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.epsilon = s->opts.epsilon;
         a.u_epsilon = s->opts.u_epsilon;
         a.p_snooker = s->cfg.p_snooker;
+        if (s->replay_active) a.accbits = s->accbits_all + (uint64_t)s->rank * s->n_local;
         if (s->sparse_active) {
             a.pack = s->PK + (uint64_t)s->rank * s->xnsub * s->xstride();
             a.pack_cap = s->xcap;
@@ -829,6 +850,13 @@ struct Group {
 };
 constexpr int64_t SPARSE_CHUNK = 64;
 
+// BPM_LOCAL_SERIAL=1 (tools/emulate_ranks.py): the emulated ranks of a local group take turns on the GPU, so that a kernel
+// trace shows each rank's kernels as they would run on a GPU of their own
+static bool local_serial(const Group& g) {
+    static const bool on = getenv("BPM_LOCAL_SERIAL") != nullptr;
+    return on && g.R > 1;
+}
+
 static int group_sync(const Group& g) {
     for (int r = 0; r < g.R; ++r) HIPCK(hipStreamSynchronize(g.h[r]->stream));
     return 0;
@@ -868,14 +896,51 @@ static int exchange_sparse(const Group& g) {
         bpm_sampler* s = g.h[r];
         hipLaunchKernelGGL(exchange_scatter_kernel, dim3(cap * s->xnsub, s->world), dim3(WAVE), 0, s->stream, s->L, s->PK, s->xnsub,
                            s->xstride(), cap, s->rank, s->xstat);
+        if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
     }
     HIPCK(hipGetLastError());
     return 0;
 }
 
-static int group_generation(const Group& g, int64_t n_ahead, bool sparse, PhaseLaunch fn) {
+// demc.py:93-94,116-117 with one byte per local chain on the wire: all-gather of the accept bytes, then every rank
+// recomputes the accepted updates of the other ranks' chains of this half generation into its replica
+static int exchange_replay(const Group& g, int ph) {
+    bpm_sampler* s0 = g.h[0];
+    if (g.rccl) {
+        NCCLCK(g_rccl.AllGather(s0->accbits_all + (uint64_t)s0->rank * s0->n_local, s0->accbits_all, (size_t)s0->n_local, ncclUint8,
+                                s0->comm, s0->stream));
+    } else if (g.R > 1) {
+        CK(group_sync(g));
+        for (int r = 0; r < g.R; ++r)
+            for (int o = 0; o < g.R; ++o)
+                if (o != r)
+                    HIPCK(hipMemcpyAsync(g.h[o]->accbits_all + (uint64_t)r * s0->n_local, g.h[r]->accbits_all + (uint64_t)r * s0->n_local,
+                                         (size_t)s0->n_local, hipMemcpyDeviceToDevice, g.h[r]->stream));
+        CK(group_sync(g));
+    }
     for (int r = 0; r < g.R; ++r) {
-        g.h[r]->sparse_active = sparse;
+        bpm_sampler* s = g.h[r];
+        if (s->world == 1) continue;                        // (one-rank communicator: nobody else's chains)
+        PhaseArgs a = s->cur_args[ph];
+        if (a.n_upd == 0) continue;
+        a.replay = 1u;
+        a.accbits = nullptr;
+        a.accbits_all = s->accbits_all;
+        a.trace_i32 = nullptr; a.trace_f64 = nullptr; a.trace_mask = nullptr;
+        a.pack = nullptr; a.hist_row = nullptr; a.llhist_row = nullptr; a.adapt_on = 0u;
+        const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
+        g_replay[v][s->shape.idx](a, s->stream);
+        if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// xmode: how the half generations' updates reach the other ranks: 0 dense all-gather, 1 accepted rows, 2 accept bytes + replay
+static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLaunch fn) {
+    for (int r = 0; r < g.R; ++r) {
+        g.h[r]->sparse_active = xmode == 1;
+        g.h[r]->replay_active = xmode == 2;
         CK(prepare_generation(g.h[r], n_ahead));
     }
     if (g.h[0]->cfg.algo == BPM_ALGO_DEMC_SYNC) {
@@ -889,10 +954,12 @@ static int group_generation(const Group& g, int64_t n_ahead, bool sparse, PhaseL
         CK(exchange_dense(g));
     } else {
         for (int ph = 0; ph < 2; ++ph) {
-            for (int r = 0; r < g.R; ++r)
+            for (int r = 0; r < g.R; ++r) {
                 if (g.h[r]->cur_args[ph].n_items > 0) fn(g.h[r]->cur_args[ph], g.h[r]->stream);
+                if (local_serial(g)) HIPCK(hipStreamSynchronize(g.h[r]->stream));
+            }
             HIPCK(hipGetLastError());
-            CK(sparse ? exchange_sparse(g) : exchange_dense(g));
+            CK(xmode == 2 ? exchange_replay(g, ph) : (xmode == 1 ? exchange_sparse(g) : exchange_dense(g)));
         }
     }
     for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
@@ -977,7 +1044,9 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 CK(graph_chunk(s0, n_gens - done, fn, &Kg));
                 if (Kg > 0) { done += Kg; continue; }
             }
-            CK(group_generation(g, n_gens - done, false, fn));
+            const bool replay = s0->replay_enabled && !adapting;       // burn-in: delta / cr_idx of every chain travel in the dense block
+            CK(group_generation(g, n_gens - done, replay ? 2 : 0, fn));
+            if (replay) for (int r = 0; r < g.R; ++r) g.h[r]->n_replay_gens += 1;
             ++done;
             continue;
         }
@@ -995,7 +1064,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             for (uint32_t b = 0; b < s->xnsub; ++b)      // own counters armed (the capacity, hence the layout, may have changed)
                 HIPCK(hipMemsetAsync(s->PK + ((uint64_t)s->rank * s->xnsub + b) * s->xstride(), 0, sizeof(double), s->stream));
         }
-        for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, true, fn));
+        for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, 1, fn));
         bool overflow = false;
         uint32_t maxc = 0;
         for (int r = 0; r < g.R; ++r) {
@@ -1021,7 +1090,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 s->k_gen = k.k_gen; s->t_abs = k.t_abs; s->hist_rows = k.hist_rows; s->rows_logical = k.rows_logical; s->w_rows = k.w_rows;
                 s->n_sparse_replays += 1;
             }
-            for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, false, fn));
+            for (int64_t i = 0; i < K; ++i) CK(group_generation(g, n_gens - done - i, 0, fn));
         }
         // capacity for the next chunk from the largest sub-block count seen (identical on every rank: all see all
         // counters): a margin of ~3 sigma of a Poisson count on top of an observed maximum over >= 64 half generations
@@ -1032,7 +1101,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
         }
         done += K;
     }
-    for (int r = 0; r < g.R; ++r) g.h[r]->sparse_active = false;
+    for (int r = 0; r < g.R; ++r) { g.h[r]->sparse_active = false; g.h[r]->replay_active = false; }
     return 0;
 }
 
@@ -1065,25 +1134,29 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     return run_generations(g, n_gens);
 }
 
-// Exchange policy of a world_size > 1 sampler.  sparse: 1 = accepted rows only (default), 0 = dense all-gather;
-// cap > 0 sets the capacity of the next chunk (rows per sub-block per half generation; rounded up to even, clamped to
-// [2, all chains of a sub-block]) -- every rank of a world must be given the same values.
-extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t sparse, int32_t cap) {
+// Exchange policy of a world_size > 1 sampler.  mode: 2 = accept bytes + replay (default), 1 = accepted rows in packed
+// blocks, 0 = dense all-gather; cap > 0 sets the capacity of the next chunk of mode 1 (rows per sub-block per half
+// generation; rounded up to even, clamped to [2, all chains of a sub-block]).  The same values on every rank of a world.
+extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     CK(check_handle(s));
-    if (!s->PK) return sparse ? fail("bpm_set_exchange: this sampler has no sparse exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
-    s->sparse_enabled = sparse != 0;
+    if (mode < 0 || mode > 2) return fail("bpm_set_exchange: mode must be 0 (dense), 1 (rows) or 2 (replay)");
+    if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
+    s->sparse_enabled = mode == 1;
+    s->replay_enabled = mode == 2;
     if (cap > 0) s->xcap = std::min<uint32_t>(s->xcap_max, ((uint32_t)cap + 1u) & ~1u);
     return 0;
 }
 
-// out[0] = sparse exchange enabled, out[1] = current capacity, out[2] = chunks run sparse, out[3] = chunks replayed dense
+// out[0] = mode (0 dense, 1 rows, 2 replay), out[1] = current capacity of mode 1, out[2] = chunks run with mode 1,
+// out[3] = chunks of mode 1 replayed dense, out[4] = generations exchanged by replay
 extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     CK(check_handle(s));
     if (!out) return fail("bpm_get_exchange_stats: null argument");
-    out[0] = s->sparse_enabled ? 1 : 0;
+    out[0] = s->replay_enabled ? 2 : (s->sparse_enabled ? 1 : 0);
     out[1] = (int64_t)s->xcap;
     out[2] = s->n_sparse_chunks;
     out[3] = s->n_sparse_replays;
+    out[4] = s->n_replay_gens;
     return 0;
 }
 
@@ -1118,6 +1191,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     for (auto& e : ev) HIPCK(hipEventCreate(&e));
     PhaseLaunch fn = pick_fused(s);
     s->sparse_active = false;
+    s->replay_active = false;
     for (int64_t g = 0; g < n_gens; ++g) {
         CK(prepare_generation(s, n_gens - g));
         for (int ph = 0; ph < 2; ++ph) {

@@ -163,14 +163,18 @@ class HipEngine(object):
                     p_cr=np.array(st.p_cr[:n]), delta_m=np.array(st.delta_m[:n]),
                     n_cr_updates=np.array(st.n_cr_updates[:n]))
 
-    def set_exchange(self, sparse=True, cap=0):
-        """world_size > 1: accepted-rows-only exchange (default) or dense all-gather; cap = rows per sub-block per half generation"""
-        L.check(self.lib.bpm_set_exchange(self._h, int(bool(sparse)), int(cap)))
+    EXCHANGE_MODES = {"dense": 0, "rows": 1, "replay": 2}
+
+    def set_exchange(self, mode="replay", cap=0):
+        """world_size > 1: "replay" (accept bytes + recomputation, default), "rows" (accepted rows in packed blocks; cap =
+        rows per sub-block per half generation) or "dense" (all-gather of whole blocks)"""
+        L.check(self.lib.bpm_set_exchange(self._h, self.EXCHANGE_MODES[mode], int(cap)))
 
     def exchange_stats(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 5)()
         L.check(self.lib.bpm_get_exchange_stats(self._h, out))
-        return dict(sparse=bool(out[0]), cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]))
+        return dict(mode=["dense", "rows", "replay"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
+                    replay_gens=int(out[4]))
 
     def history_rows(self):
         return int(self.stats()["history_rows"])

@@ -143,16 +143,19 @@ int bpm_synchronize(bpm_handle_t h);
  * nccl_uid that starts with "BPMLOCAL" (no RCCL involved); this call advances all of them n_gens generations
  * in lock-step, doing the per-half-generation all-gather (demc.py:93-94,116-117) with device copies. */
 int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
-/* Exchange policy for world_size > 1 (the Allgather of demc.py:93-94,116-117).  Outside DREAM's CR adaptation
- * only the rows that were ACCEPTED in a half generation have changed, so by default ranks all-gather
- * fixed-capacity packed blocks (up to 4 sub-blocks [count | ids | rows] per rank, a counter each) and scatter
- * them into their replicas.  Generations run in chunks of 64 under a device-side checkpoint; a chunk in which a
- * sub-block saw more acceptances than its capacity is rolled back and replayed with the dense all-gather (draws
- * are counter-addressed, so the result is the dense run's, bit for bit).  sparse = 0 selects the dense exchange
- * always; cap > 0 sets the capacity (rows per sub-block per half generation) of the next chunk -- afterwards it
- * follows the largest count seen.  Same values on every rank. */
-int bpm_set_exchange(bpm_handle_t h, int32_t sparse, int32_t cap);
-/* out[4] = {sparse enabled, current capacity, chunks run with the sparse exchange, chunks replayed dense} */
+/* Exchange policy for world_size > 1: what the Allgather of demc.py:93-94,116-117 moves.  Outside DREAM's CR
+ * adaptation (where delta / cr_idx of every chain travel with the dense block) a half generation only changes the rows
+ * that were ACCEPTED, and everything a proposal is made of -- the replicated state matrix, counter-addressed draws,
+ * update records -- is on every rank already.  mode 2 (default), "replay": owners all-gather ONE BYTE per local chain
+ * (accepted or not) and every rank recomputes the other ranks' accepted proposals into its replica with the update
+ * kernel's own proposal code (bit-identical by construction).  mode 1, "rows": ranks all-gather fixed-capacity packed
+ * blocks (up to 4 sub-blocks [count | ids | rows] per rank) and scatter them; generations run in chunks of 64 under a
+ * device-side checkpoint, a chunk in which a sub-block overflowed is rolled back and repeated with mode 0; cap > 0
+ * sets the capacity (rows per sub-block per half generation) of the next chunk, afterwards it follows the largest
+ * count seen.  mode 0: the dense all-gather of whole blocks.  The same values on every rank. */
+int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
+/* out[5] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
+ *           generations exchanged by replay} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.

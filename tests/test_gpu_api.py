@@ -256,16 +256,17 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "sparse_overflow", "dense"])
+@pytest.mark.parametrize("exchange", ["replay", "rows", "rows_overflow", "dense"])
 @pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8", "demc_banana_snooker", "dream_gauss7_pairs2"])
 @pytest.mark.parametrize("R", [2, 4])
 def test_multi_rank_equals_single_rank_on_device(case, R, exchange):
     """The world_size > 1 device path (rank blocks of the exchange buffer, per-rank history / ln_like /
     Welford / accept counters, local-chain launch mode, CR statistics travelling in the gathered block)
     emulated with R handles on ONE GPU (bpm_local_group_step; the RCCL all-gather replaced by device
-    copies): chain histories and p_cr must equal the single-rank run bit for bit.  `exchange`: the default
-    accepted-rows-only exchange, the same with a capacity of 2 rows (every chunk overflows, is rolled back to its
-    checkpoint and replayed dense), and the dense all-gather."""
+    copies): chain histories and p_cr must equal the single-rank run bit for bit.  `exchange`: the default accept-byte
+    exchange with replay of the accepted proposals on the receiving ranks, the accepted-rows exchange, the same with a
+    capacity of 2 rows (every chunk overflows, is rolled back to its checkpoint and repeated dense), and the dense
+    all-gather."""
     import ctypes as C
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
@@ -279,7 +280,7 @@ def test_multi_rank_equals_single_rank_on_device(case, R, exchange):
     else:
         spec, algo, N, kw = d100_gauss.Gauss_100D(dim=7)._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=20, n_cr_gen=2, del_pairs=2)
     tid, tp, d = spec
-    G = 14 if exchange != "sparse_overflow" else 150        # 150: three chunks, so the capacity adapts after a replay
+    G = 14 if exchange != "rows_overflow" else 150        # 150: three chunks, so the capacity adapts after a rollback
     x0 = np.random.RandomState(3).normal(size=(N, d)) + 0.5
     one = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
     one.set_state(x0)
@@ -294,18 +295,21 @@ def test_multi_rank_equals_single_rank_on_device(case, R, exchange):
     for e in ranks:
         e.set_state(x0)
         e.begin_run(flip=0.4)
-        e.set_exchange(sparse=exchange != "dense", cap=2 if exchange == "sparse_overflow" else 0)
+        e.set_exchange(mode=exchange.split("_")[0], cap=2 if exchange == "rows_overflow" else 0)
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
     L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
     xs = [e.exchange_stats() for e in ranks]
     assert all(x == xs[0] for x in xs)                                 # every rank took the same decisions
-    n_sparse_gens = G - (kw.get("burnin_gen", 0) if algo == L.ALGO_DREAM else 0)     # CR adaptation runs dense
-    if exchange == "dense" or n_sparse_gens <= 0:
-        assert xs[0]["chunks"] == 0
+    n_sparse_gens = max(0, G - (kw.get("burnin_gen", 0) if algo == L.ALGO_DREAM else 0))     # CR adaptation runs dense
+    assert xs[0]["mode"] == exchange.split("_")[0]
+    if exchange == "replay":
+        assert xs[0]["replay_gens"] == n_sparse_gens and xs[0]["chunks"] == 0
+    elif exchange == "dense" or n_sparse_gens == 0:
+        assert xs[0]["chunks"] == 0 and xs[0]["replay_gens"] == 0
     else:
-        assert xs[0]["chunks"] >= 1 and xs[0]["sparse"]
-        assert (xs[0]["replays"] >= 1) == (exchange == "sparse_overflow")
-        if exchange == "sparse_overflow":
+        assert xs[0]["chunks"] >= 1 and xs[0]["replay_gens"] == 0
+        assert (xs[0]["replays"] >= 1) == (exchange == "rows_overflow")
+        if exchange == "rows_overflow":
             assert xs[0]["replays"] < xs[0]["chunks"] and xs[0]["cap"] > 2     # the capacity grew and later chunks fit
     HR = np.concatenate([e.get_history() for e in ranks], axis=1)      # ranks own contiguous id blocks (demc.py:39)
     assert HR.shape == H1.shape

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: R ranks of a world emulated on ONE GPU (bpm_local_group_step: the real kernels, layouts and host logic of a
+multi-GPU run, the all-gathers done by device copies) at BASELINE config 4's per-rank shape (8192 chains of the 100-D
+Gaussian per rank).  Run under `rocprofv3 --kernel-trace --stats` to read the per-rank kernel times of an R-GPU run --
+update kernel in the sharded mode, replay / scatter kernels -- which is everything but the RCCL transfer.
+usage: emulate_ranks.py R [replay|rows|dense] [generations]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bipymc_amd import _lib as L          # noqa: E402
+from bipymc_amd.engine import HipEngine   # noqa: E402
+from bipymc_amd.utils import d100_gauss   # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = sys.argv[2] if len(sys.argv) > 2 else "replay"
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+g = d100_gauss.Gauss_100D()
+tid, tp, d = g._bpm_target_spec()
+N = 8192 * R
+np.random.seed(3)
+x0 = g.rvs(N)
+uid = b"BPMLOCAL" + bytes(120)
+ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
+                   nccl_uid=uid, burnin_gen=0, keep_history=False) for r in range(R)]
+for e in ranks:
+    e.set_state(x0)
+    e.begin_run()
+    e.set_exchange(mode=mode)
+arr = (C.c_void_p * R)(*[e._h for e in ranks])
+L.check(ranks[0].lib.bpm_local_group_step(arr, R, 5))
+t0 = time.perf_counter()
+L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+dt = time.perf_counter() - t0
+acc = sum(e.stats()["local_n_accepted"] for e in ranks) / float(N * (G + 5))
+print("R=%d mode=%s N=%d: %d generations, %.1f us per generation for ALL ranks serialised on one GPU (acceptance %.3f); %s"
+      % (R, mode, N, G, dt / G * 1e6, acc, ranks[0].exchange_stats()))
