@@ -558,7 +558,10 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
                 if (!found && uc < cum) { idx = m; thr = a.thr[m]; found = true; }   // k 2^-16 <= CR_m  <=>  k <= thr[m]
             }
         }
-        if (!found) thr = a.thr[a.n_cr - 1];
+        if (!found) {                                    // (no dynamic index into the argument block: it must stay scalarisable)
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) if (m == (int)a.n_cr - 1) thr = a.thr[m];
+        }
         wk.cr_idx = idx;
     }
     int cnt = 0;
@@ -856,8 +859,15 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
     return active;
 }
 
-// HOT: the single-GPU cases as their own instantiations: 1 = steady state with plan records, 2 = steady state without,
-// 3 / 4 = the same during DREAM's CR adaptation (burn-in); 0 = the general kernel.
+// HOT: frequent cases as their own instantiations: 1 = single GPU, steady state, with plan records, 2 = the same without,
+// 3 / 4 = the same during DREAM's CR adaptation (burn-in), 5 / 6 = a rank of a multi-GPU world in the steady state
+// with the replay exchange (sharded launch mode, accept bytes), with / without plan records; 0 = the general kernel.
+__host__ inline bool phase_args_hot_sharded(const PhaseArgs& a, bool dream, bool with_plan) {
+    return a.mode == 1 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+           a.adapt_on == 0 && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world > 1 &&
+           a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && a.accbits != nullptr && a.replay == 0 &&
+           (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
+}
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
     return a.mode == 0 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            (a.adapt_on != 0) == adapting && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
@@ -881,26 +891,27 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     // 12.6 vs 14.4 us/generation at cfg2.  Several chains per wavefront: the copy is not scalarised there (it ends up
     // in scratch, 30 instead of 12.4 us/generation at cfg5/8), so those kernels only get the assumptions.
     constexpr bool COPY = (HOT != 0) && (LPC == WAVE);
+    constexpr bool SHARD = (HOT == 5 || HOT == 6), ADAPT = (HOT == 3 || HOT == 4), NOPLAN = (HOT == 2 || HOT == 4 || HOT == 6);
     PhaseArgs a_hot;
     if (COPY) {
         a_hot = a_in;
-        a_hot.mode = 0; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
-        a_hot.accbits = nullptr; a_hot.replay = 0u;
-        a_hot.x_next = nullptr; a_hot.adapt_on = (HOT >= 3) ? 1u : 0u; a_hot.stamps = nullptr; a_hot.lo = 0; a_hot.L.world = 1;
+        a_hot.mode = SHARD ? 1u : 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
+        a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
+        if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
-        if (HOT == 2 || HOT == 4) a_hot.plan = nullptr;
+        if (NOPLAN) a_hot.plan = nullptr;
     }
     const PhaseArgs& a = COPY ? a_hot : a_in;
     if (HOT) {
-        __builtin_assume(a_in.mode == 0); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
-        __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == ((HOT >= 3) ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
-        __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1);
+        __builtin_assume(a_in.mode == (SHARD ? 1u : 0u)); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
+        __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == (ADAPT ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
+        if (!SHARD) { __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1); }
         __builtin_assume(a_in.hist_row != nullptr); __builtin_assume(a_in.llhist_row != nullptr); __builtin_assume(a_in.epsilon > 0.0);
         __builtin_assume(a_in.perm_tab != nullptr); __builtin_assume(a_in.inv_tab != nullptr);
         if (ALGO == ALGO_DREAM) { __builtin_assume(a_in.u_epsilon > 0.0); __builtin_assume(a_in.n_cr == 3); }
     }
 #ifdef BPM_PRELOAD
-    if (HOT) { __builtin_assume(pl_mode == 0); __builtin_assume((pl_plan != nullptr) == (HOT == 1 || HOT == 3)); }
+    if (HOT) { __builtin_assume(pl_mode == (SHARD ? 1u : 0u)); __builtin_assume((pl_plan != nullptr) == !NOPLAN); }
 #else
     const uint32_t* pl_plan = a.plan;
     const uint32_t pl_upd_off = a.upd_off, pl_n_items = a.n_items, pl_mode = a.mode;
@@ -970,7 +981,15 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
 // replica.  Partner rows come from the other group, which nobody writes in this half generation; each row of the update
 // group is written by exactly one item.  No ln-like, no accept test, no history: those are the owner's.
 template <int ALGO, int LPC, int DPL, int NP>
-__global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const PhaseArgs a) {
+__global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const PhaseArgs a_in) {
+    // (what the host fixed for every replay launch as compile-time constants, as in phase_fused_kernel's HOT copies)
+    PhaseArgs a_rep;
+    if (LPC == WAVE) {
+        a_rep = a_in;
+        a_rep.replay = 1u; a_rep.adapt_on = 0u; a_rep.trace_i32 = nullptr; a_rep.trace_f64 = nullptr; a_rep.trace_mask = nullptr;
+        a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u;
+    }
+    const PhaseArgs& a = (LPC == WAVE) ? a_rep : a_in;
     __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
     const int cw = lane / LPC, q = lane % LPC;

@@ -96,6 +96,11 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
                                s, a.plan, a.upd_off, a.n_items, a.mode, a);
             return;
         }
+        if (!no_hot && phase_args_hot_sharded(a, ALGO == ALGO_DREAM, PLAN)) {
+            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, (PLAN ? 5 : 6)>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
+                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
+            return;
+        }
         if (!no_hot && ALGO == ALGO_DREAM && phase_args_hot(a, true, PLAN, true)) {
             hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_ADAPT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
                                s, a.plan, a.upd_off, a.n_items, a.mode, a);

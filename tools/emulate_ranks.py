@@ -27,7 +27,7 @@ np.random.seed(3)
 x0 = g.rvs(N)
 uid = b"BPMLOCAL" + bytes(120)
 ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
-                   nccl_uid=uid, burnin_gen=0, keep_history=False) for r in range(R)]
+                   nccl_uid=uid, burnin_gen=0) for r in range(R)]
 for e in ranks:
     e.set_state(x0)
     e.begin_run()
