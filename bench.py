@@ -228,7 +228,7 @@ def main():
                        "exchange": eng.exchange_stats() if use_dist else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, true> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation)",
+                         "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, %d> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation%s)" % ((5, " of the sharded launch mode") if world > 1 else (1, "")),
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
                          "launches_timed": n_launch, "avg_launch_us_event_pairs": pair_ms / pair_n * 1e3,
