@@ -502,3 +502,40 @@ def test_long_run_crosses_many_table_chunks_and_stays_stationary():
     assert abs(np.mean(X.var(axis=0) / sig2) - 1) < 0.05                      # the final population alone (2048 draws)
     assert np.array_equal(e.get_history(G, G + 1)[0], X)
     e.close()
+
+
+@pytest.mark.parametrize("exchange", ["replay", "rows"])
+def test_eight_rank_world_equals_single_rank(exchange):
+    """The shape the scaling bench runs (8 ranks, the 100-D Gaussian, one wavefront per chain, plan records, the sharded
+    steady-state instantiation, replay of seven other ranks' accepted proposals), emulated on one GPU at 128 chains per
+    rank: 60 generations including a DREAM burn-in with CR adaptation must equal the single-rank run bit for bit."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    R, N, G = 8, 1024, 60
+    kw = dict(burnin_gen=12, n_cr_gen=3)
+    np.random.seed(8)
+    x0 = g.rvs(N)
+    one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=21, **kw)
+    one.set_state(x0)
+    one.begin_run()
+    one.step(G)
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=21, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run()
+        e.set_exchange(mode=exchange)
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    HR = np.concatenate([e.get_history() for e in ranks], axis=1)
+    assert np.array_equal(HR, one.get_history())
+    for e in ranks:
+        assert np.array_equal(e.get_state(), one.get_state())
+        np.testing.assert_array_equal(e.stats()["p_cr"], one.stats()["p_cr"])
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == one.stats()["local_n_accepted"]
+    assert ranks[0].exchange_stats()["replay_gens" if exchange == "replay" else "chunks"] > 0
