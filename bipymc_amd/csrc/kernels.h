@@ -112,6 +112,8 @@ struct PhaseArgs {
     const double* gamma_tab;    // [dim + 1] DREAM gamma_base by d' (dream.py:61), host-evaluated
     const uint32_t* plan;       // [N * PLAN_WORDS] by position in shuffle order: chain id, header block, partner ids of
                                 // this generation, precomputed by plan_kernel (nullptr: drawn in the update kernel)
+    const uint32_t* rec_tab;    // what the update kernel reads its records from: `plan` (item w -> record rec_off + w, rec_off =
+    uint32_t rec_off;           // upd_off), or this rank's compacted records of the half generation (plan_local_kernel, rec_off = 0)
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     unsigned long long* stamps;  // diagnostic build only
     double* pack;               // sparse exchange (world > 1): this rank's block [count u32 | pad | ids[cap] | rows[cap][ld]] or nullptr
@@ -861,15 +863,15 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 
 // HOT: frequent cases as their own instantiations: 1 = single GPU, steady state, with plan records, 2 = the same without,
 // 3 / 4 = the same during DREAM's CR adaptation (burn-in), 5 / 6 = a rank of a multi-GPU world in the steady state
-// with the replay exchange (sharded launch mode, accept bytes), with / without plan records; 0 = the general kernel.
+// with the replay exchange (accept bytes; its compacted records when 5, none when 6); 0 = the general kernel.
 __host__ inline bool phase_args_hot_sharded(const PhaseArgs& a, bool dream, bool with_plan) {
-    return a.mode == 1 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+    return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            a.adapt_on == 0 && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world > 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && a.accbits != nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
-    return a.mode == 0 && (a.plan != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+    return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            (a.adapt_on != 0) == adapting && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr && a.accbits == nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
 #ifdef BPM_PRELOAD
     // the four values that locate a wavefront's update record, as leading scalar arguments: with
     // -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs at wavefront launch (no kernarg load, one miss less
-    // on the critical path); they repeat a.plan, a.upd_off, a.n_items, a.mode
+    // on the critical path); they repeat a.rec_tab, a.rec_off, a.n_items, a.mode
     const uint32_t* pl_plan, uint32_t pl_upd_off, uint32_t pl_n_items, uint32_t pl_mode,
 #endif
     const PhaseArgs a_in) {
@@ -895,15 +897,15 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     PhaseArgs a_hot;
     if (COPY) {
         a_hot = a_in;
-        a_hot.mode = SHARD ? 1u : 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
+        a_hot.mode = 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
         a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
         if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
-        if (NOPLAN) a_hot.plan = nullptr;
+        if (NOPLAN) { a_hot.plan = nullptr; a_hot.rec_tab = nullptr; }
     }
     const PhaseArgs& a = COPY ? a_hot : a_in;
     if (HOT) {
-        __builtin_assume(a_in.mode == (SHARD ? 1u : 0u)); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
+        __builtin_assume(a_in.mode == 0u); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
         __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == (ADAPT ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
         if (!SHARD) { __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1); }
         __builtin_assume(a_in.hist_row != nullptr); __builtin_assume(a_in.llhist_row != nullptr); __builtin_assume(a_in.epsilon > 0.0);
@@ -911,10 +913,10 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
         if (ALGO == ALGO_DREAM) { __builtin_assume(a_in.u_epsilon > 0.0); __builtin_assume(a_in.n_cr == 3); }
     }
 #ifdef BPM_PRELOAD
-    if (HOT) { __builtin_assume(pl_mode == (SHARD ? 1u : 0u)); __builtin_assume((pl_plan != nullptr) == !NOPLAN); }
+    if (HOT) { __builtin_assume(pl_mode == 0u); __builtin_assume((pl_plan != nullptr) == !NOPLAN); }
 #else
-    const uint32_t* pl_plan = a.plan;
-    const uint32_t pl_upd_off = a.upd_off, pl_n_items = a.n_items, pl_mode = a.mode;
+    const uint32_t* pl_plan = a.rec_tab;
+    const uint32_t pl_upd_off = a.rec_off, pl_n_items = a.n_items, pl_mode = a.mode;
 #endif
     __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
@@ -1276,6 +1278,55 @@ __global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* p
     uint4* out = reinterpret_cast<uint4*>(plan + e * PLAN_WORDS);
 #pragma unroll
     for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+}
+
+// A rank's own records of K generations, compacted: block (group, generation) walks the positions of that group in
+// order and copies the records whose chain lives on this rank to local[(g * 2 + group) * n_local + k], k counting up;
+// count[g * 2 + group] = how many.  The update kernel of a multi-GPU rank then runs exactly like the single-GPU one
+// (item k -> record k, no idle items, no position lookup); the host reads the counts once per table window to size the
+// launches.  Fixed-order block scan: the same list on every run.
+constexpr int PLAN_LOCAL_THREADS = 1024;
+__global__ __launch_bounds__(PLAN_LOCAL_THREADS) void plan_local_kernel(const uint32_t* plan, uint32_t N, uint32_t lo, uint32_t n_local,
+                                                                        uint32_t* local, uint32_t* count) {
+    __shared__ uint32_t s_wave[PLAN_LOCAL_THREADS / WAVE];
+    __shared__ uint32_t s_running;
+    const uint32_t grp = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const uint32_t n_first = (N + 1u) / 2u;
+    const uint32_t off = grp ? n_first : 0u, n = grp ? N - n_first : n_first;
+    const uint4* src = reinterpret_cast<const uint4*>(plan + (uint64_t)g * N * PLAN_WORDS);
+    uint4* dst = reinterpret_cast<uint4*>(local + ((uint64_t)g * 2 + grp) * n_local * PLAN_WORDS);
+    if (tid == 0) s_running = 0u;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += PLAN_LOCAL_THREADS) {
+        const uint32_t i = t0 + tid;
+        const bool valid = i < n;
+        uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) r0 = src[(uint64_t)(off + i) * (PLAN_WORDS / 4)];
+        const bool mine = valid && (r0.x - lo) < n_local;                    // word 0 of a record = the chain id
+        const unsigned long long b = __ballot(mine);
+        const uint32_t lane = tid & (WAVE - 1), wv = tid / WAVE;
+        const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+        for (uint32_t k = 0; k < PLAN_LOCAL_THREADS / WAVE; ++k) {
+            const uint32_t v = s_wave[k];
+            if (k < wv) wave_off += v;
+            total += v;
+        }
+        const uint32_t base = s_running;
+        if (mine) {
+            const uint64_t o = (uint64_t)(base + wave_off + before) * (PLAN_WORDS / 4);
+            const uint64_t s = (uint64_t)(off + i) * (PLAN_WORDS / 4);
+            dst[o] = r0;
+#pragma unroll
+            for (int q = 1; q < PLAN_WORDS / 4; ++q) dst[o + q] = src[s + q];
+        }
+        __syncthreads();
+        if (tid == 0) s_running = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) count[g * 2u + grp] = s_running;
 }
 
 // omega_i = mean ln_like of chain i over the history rows [r0, rows).

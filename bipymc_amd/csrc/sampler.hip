@@ -93,22 +93,22 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
         static const bool no_hot = getenv("BPM_NO_HOT") != nullptr;
         if (!no_hot && phase_args_hot(a, ALGO == ALGO_DREAM, PLAN, false)) {
             hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_STEADY>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
+                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
             return;
         }
         if (!no_hot && phase_args_hot_sharded(a, ALGO == ALGO_DREAM, PLAN)) {
             hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, (PLAN ? 5 : 6)>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
+                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
             return;
         }
         if (!no_hot && ALGO == ALGO_DREAM && phase_args_hot(a, true, PLAN, true)) {
             hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_ADAPT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.plan, a.upd_off, a.n_items, a.mode, a);
+                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
             return;
         }
     }
-    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.plan,
-                       a.upd_off, a.n_items, a.mode, a);
+    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.rec_tab,
+                       a.rec_off, a.n_items, a.mode, a);
 #else
     hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
 #endif
@@ -204,6 +204,10 @@ struct bpm_sampler {
     int64_t tab_t0 = -1;
     uint32_t* plan_tab = nullptr;   // [plan_K * N * PLAN_WORDS] update records of the same generations (plan_kernel) or nullptr
     int plan_K = 0;                 // generations the plan table holds (<= PERM_CHUNK; 0: no plan)
+    // world > 1: this rank's own records of each half generation, compacted (plan_local_kernel), and how many there are
+    uint32_t* plan_local = nullptr;     // [plan_K * 2 * n_local * PLAN_WORDS]
+    uint32_t* plan_count = nullptr;     // device [plan_K * 2]
+    std::vector<uint32_t> plan_count_h; // the same on the host, read once per table window
     int tab_K = 0;
     int tab_shuffle = -1;
     double* gamma_tab = nullptr;    // [dim + 1]
@@ -355,7 +359,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->plan_local, s->plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -461,6 +465,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
         s->plan_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
         CKD(dev_alloc(&s->plan_tab, (size_t)s->plan_K * s->N * PLAN_WORDS));
+        if (s->world > 1 && getenv("BPM_NO_PLAN_LOCAL") == nullptr) {
+            CKD(dev_alloc(&s->plan_local, (size_t)s->plan_K * 2 * s->n_local * PLAN_WORDS));
+            CKD(dev_alloc(&s->plan_count, (size_t)s->plan_K * 2));
+            s->plan_count_h.assign((size_t)s->plan_K * 2, 0u);
+        }
     }
     CKD(dev_alloc(&s->inv_tab, (size_t)PERM_CHUNK * s->N));
     CKD(dev_alloc(&s->gamma_tab, (size_t)s->dim + 1));
@@ -643,6 +652,13 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
                       (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, pp, s->perm_tab, s->plan_tab);
         HIPCK(hipGetLastError());
+        if (s->plan_local) {        // this rank's records, compacted; the counts size the launches of this window: one sync per <= 64 generations
+            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, s->stream, s->plan_tab, s->N, s->lo,
+                               s->n_local, s->plan_local, s->plan_count);
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(s->plan_count_h.data(), s->plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+            HIPCK(hipStreamSynchronize(s->stream));
+        }
     }
     s->tab_t0 = t;
     s->tab_K = K;
@@ -703,6 +719,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.perm_tab = s->perm_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.plan = s->plan_tab ? s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS : nullptr;
+        a.rec_tab = a.plan;
         { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
           if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
         a.gamma_tab = s->gamma_tab;
@@ -724,6 +741,16 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         const bool by_chain = s->world > 1 || force_mode1;
         a.mode = by_chain ? 1u : 0u;
         a.n_items = by_chain ? s->n_local : a.n_upd;
+        a.rec_off = a.upd_off;
+        if (by_chain && s->plan_local) {
+            // a rank of a world with its compacted records: item k -> its k-th local update of this half generation,
+            // exactly the single-GPU launch shape (no idle items, no position lookup)
+            const uint64_t slot = (uint64_t)(s->t_abs - s->tab_t0) * 2 + (a.upd_off == 0 ? 0u : 1u);
+            a.rec_tab = s->plan_local + slot * s->n_local * PLAN_WORDS;
+            a.rec_off = 0u;
+            a.n_items = s->plan_count_h[(size_t)slot];
+            a.mode = 0u;
+        }
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;
