@@ -3,7 +3,9 @@
 // log-like cache, history, Welford moments, CR statistics), runs the generation
 // loop of bipymc/demc.py:63-151 as back-to-back kernel launches on one HIP stream
 // and, for world_size > 1, replaces the two MPI_Allgathers per generation
-// (demc.py:93-94,116-117) with in-place RCCL all-gathers on the same stream.
+// (demc.py:93-94,116-117) with in-place RCCL all-gathers on the same stream: of one
+// accept byte per chain followed by a replay of the accepted proposals (default), of
+// packed accepted rows, or of whole rank blocks (burn-in, synchronous mode).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
