@@ -7,6 +7,7 @@
 // accept byte per chain followed by a replay of the accepted proposals (default), of
 // packed accepted rows, or of whole rank blocks (burn-in, synchronous mode).
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -1418,6 +1419,11 @@ static int d2h_rows_parallel(bpm_sampler* s, double* out, const double* src, siz
     const size_t n_chunks = (rows + chunk_rows - 1) / chunk_rows;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int n_workers = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, hw / 2)), n_chunks);
+    {   // the caller's buffer is typically a fresh anonymous mapping (np.empty): ask for transparent huge pages before the
+        // first touch -- 800 k page faults of 4 KiB otherwise cost as much as the copy itself
+        const uintptr_t b0 = ((uintptr_t)out + 4095u) & ~(uintptr_t)4095u, b1 = ((uintptr_t)out + rows * row_bytes) & ~(uintptr_t)4095u;
+        if (b1 > b0) (void)madvise((void*)b0, (size_t)(b1 - b0), MADV_HUGEPAGE);
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> err{0};
     const int device = s->cfg.device;
