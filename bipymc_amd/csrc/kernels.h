@@ -866,13 +866,13 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 // with the replay exchange (accept bytes; its compacted records when 5, none when 6); 0 = the general kernel.
 __host__ inline bool phase_args_hot_sharded(const PhaseArgs& a, bool dream, bool with_plan) {
     return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
-           a.adapt_on == 0 && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world > 1 &&
+           a.adapt_on == 0 && a.epsilon > 0.0 && a.L.world > 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && a.accbits != nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
     return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
-           (a.adapt_on != 0) == adapting && a.hist_row != nullptr && a.llhist_row != nullptr && a.epsilon > 0.0 && a.L.world == 1 &&
+           (a.adapt_on != 0) == adapting && a.epsilon > 0.0 && a.L.world == 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr && a.accbits == nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
         __builtin_assume(a_in.mode == 0u); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
         __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == (ADAPT ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
         if (!SHARD) { __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1); }
-        __builtin_assume(a_in.hist_row != nullptr); __builtin_assume(a_in.llhist_row != nullptr); __builtin_assume(a_in.epsilon > 0.0);
+        __builtin_assume(a_in.epsilon > 0.0);
         __builtin_assume(a_in.perm_tab != nullptr); __builtin_assume(a_in.inv_tab != nullptr);
         if (ALGO == ALGO_DREAM) { __builtin_assume(a_in.u_epsilon > 0.0); __builtin_assume(a_in.n_cr == 3); }
     }
