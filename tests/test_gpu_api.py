@@ -3,6 +3,7 @@ tests/test_banana.py, tests/test_100dgauss.py) driven through bipymc_amd.DeMcMpi
 host-callback ln_like_fn path, checkpoints, and size-independent properties at BASELINE sizes."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -190,9 +191,27 @@ def test_full_size_properties(cfg):
     assert np.array_equal(outs[0][2], outs[1][2])
 
 
-def test_rccl_one_rank_communicator():
+def _prefetch_with_progress(path, capsys):
+    """Read a large shared library into the page cache in 32 MiB chunks, one visible dot per chunk.  On a fresh box
+    dlopen of the 573 MB librccl pages in from a cold image for minutes; done silently inside a captured test that
+    looks like a hang to a watchdog that wants output every few minutes."""
+    if not os.path.exists(path):
+        return
+    with capsys.disabled():
+        sys.stdout.write("[paging in %s " % os.path.basename(path))
+        sys.stdout.flush()
+        with open(path, "rb", buffering=0) as f:
+            while f.read(32 << 20):
+                sys.stdout.write(".")
+                sys.stdout.flush()
+        sys.stdout.write("]")
+        sys.stdout.flush()
+
+
+def test_rccl_one_rank_communicator(capsys):
     """RCCL is loaded on demand; a one-rank communicator runs the in-place all-gather after each half
     generation on the sampler's stream and must not change any result."""
+    _prefetch_with_progress("/opt/rocm/lib/librccl.so.1", capsys)
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
     from bipymc_amd.utils import d100_gauss
