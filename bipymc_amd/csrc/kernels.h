@@ -885,14 +885,14 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     const uint32_t* pl_plan, uint32_t pl_upd_off, uint32_t pl_n_items, uint32_t pl_mode,
 #endif
     const PhaseArgs a_in) {
-    // HOT: the host launches this instantiation only when phase_args_hot() holds.  One wavefront per chain: what the
+    // HOT: the host launches this instantiation only when phase_args_hot() / phase_args_hot_sharded() holds.  What the
     // predicate fixes is written into a private copy of the argument block (constants the compiler propagates; an
-    // assumption on a POINTER loaded from the kernarg segment does not survive address-space inference), the non-null /
-    // positive ones are assumed; every other path drops out -- cfg2's kernel: 637 instead of 2520 instructions, 33
+    // assumption on a POINTER loaded from the kernarg segment does not survive address-space inference), the positive /
+    // non-null ones are assumed; every other path drops out -- cfg2's kernel: 637 instead of 2520 instructions, 33
     // instead of 144 branches, 51 instead of 82 VGPRs -- and the loads move across what were branch boundaries:
-    // 12.6 vs 14.4 us/generation at cfg2.  Several chains per wavefront: the copy is not scalarised there (it ends up
-    // in scratch, 30 instead of 12.4 us/generation at cfg5/8), so those kernels only get the assumptions.
-    constexpr bool COPY = (HOT != 0) && (LPC == WAVE);
+    // 12.5 vs 14.4 us/generation at cfg2, 11.0 vs 12.9 at cfg5/8.  (The copy stays in registers only as long as nothing
+    // indexes the argument block dynamically: one `a.thr[n_cr - 1]` had put it into scratch, 30 us/generation at cfg5/8.)
+    constexpr bool COPY = (HOT != 0);
     constexpr bool SHARD = (HOT == 5 || HOT == 6), ADAPT = (HOT == 3 || HOT == 4), NOPLAN = (HOT == 2 || HOT == 4 || HOT == 6);
     PhaseArgs a_hot;
     if (COPY) {
