@@ -358,6 +358,12 @@ __device__ __forceinline__ void box_muller_pair_f32(uint32_t w1, uint32_t w2, do
     n1 = (double)(r * __builtin_amdgcn_sinf(u2));
 }
 
+// Lane K of every quad (4 consecutive lanes) to all four lanes of that quad: one DPP move, no LDS.
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, false);
+}
+
 // Partner chains of chain c (pool positions -> global ids through the generation's bijection): in registers when
 // the pair count is a compile-time constant and a chain is one lane or one wavefront (make_proposal: FAST / RL /
 // planned paths), otherwise resolved by the lanes of the subgroup in parallel and handed over through LDS.
@@ -443,7 +449,12 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     const bool merged = RL && DPL == 2 && (npairs + 2u * (uint32_t)NP + 1u <= (uint32_t)WAVE);
     u32x4 wpair[DPL / 2];
     u32x4 h0;
-    Partners<LPC, (FAST || RL) ? 2 * NP : 0> part;
+    // QUAD (DREAM, 4 lanes per chain, three pairs, d <= 8): the chain's seven Philox blocks -- four coordinate pairs,
+    // header, two pair-selection blocks -- in TWO evaluations per lane instead of four (header once per lane and every
+    // partner index on its own lane of the LDS hand-over loop), shared inside the quad by DPP quad_perm broadcasts
+    constexpr bool QUAD = DREAM && LPC == 4 && DPL == 2 && NP == 3;
+    constexpr bool REGS = FAST || RL || QUAD;             // partner ids live in registers
+    Partners<LPC, REGS ? 2 * NP : 0> part;
     part.lds = s_part + cw * MAX_PARTNERS;
     // PLANNED (record of this update precomputed by plan_kernel): header words and partner ids are loads issued at
     // kernel entry (scalar ones when a wavefront is one chain), so the partner rows are requested BEFORE the lanes'
@@ -486,6 +497,23 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         }
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) part.r[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, npairs + i);
+    } else if (QUAD) {
+        wpair[0] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)q);
+        // second evaluation: lane 0 (and 3) the header block, lanes 1 and 2 the two pair-selection blocks
+        const u32x4 wb = chain_block(a.seed, c, a.t, q == 1 ? SLOT_PAIR0 : (q == 2 ? SLOT_PAIR0 + 1u : SLOT_HDR0));
+        h0.x = quad_bcast<0>(wb.x); h0.y = quad_bcast<0>(wb.y); h0.z = quad_bcast<0>(wb.z); h0.w = quad_bcast<0>(wb.w);
+        uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+        if (q == 1 || q == 2) {                                    // lane 1: pairs 0 and 1, lane 2: pair 2 (partner_pos's layout)
+            uint32_t ia, ib;
+            distinct_pair(wb.x, wb.y, a.M, ia, ib);
+            i0 = pos_to_chain(a, a.pool_off + ia); i1 = pos_to_chain(a, a.pool_off + ib);
+            if (q == 1) {
+                distinct_pair(wb.z, wb.w, a.M, ia, ib);
+                i2 = pos_to_chain(a, a.pool_off + ia); i3 = pos_to_chain(a, a.pool_off + ib);
+            }
+        }
+        part.r[0] = quad_bcast<1>(i0); part.r[1] = quad_bcast<1>(i1); part.r[2] = quad_bcast<1>(i2); part.r[3] = quad_bcast<1>(i3);
+        part.r[4] = quad_bcast<2>(i0); part.r[5] = quad_bcast<2>(i1);
     } else {
         // one header block: (select16|gamma16, forced dim [DREAM] / snooker gamma [DE-MC], accept hi, accept lo)
         h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
@@ -517,7 +545,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         snk_id[1] = pos_to_chain(a, a.pool_off + i1);
         snk_id[2] = pos_to_chain(a, a.pool_off + i2);
     }
-    if (!(FAST || RL) || (snk_possible && !SNK_DIRECT)) {
+    if (!REGS || (snk_possible && !SNK_DIRECT)) {
 #pragma unroll 1
         for (uint32_t idx = (uint32_t)q; idx < npart; idx += LPC)
             s_part[cw * MAX_PARTNERS + idx] = planned ? rec[5 + idx] : pos_to_chain(a, a.pool_off + partner_pos(a, c, idx, 2 * P));
@@ -675,7 +703,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (a.mode != 2 && a.k % 10 == 0 && !(u_gam < 0.1)) { gamma = 1.0; wk.jump = 1; }   // demc.py:174-177 (not in samplers.py DeMc)
         wk.gamma = gamma;
         double ra[DPL], rb[DPL];
-        const bool ids_in_regs = (FAST || RL) && (!snk_possible || SNK_DIRECT);
+        const bool ids_in_regs = REGS && (!snk_possible || SNK_DIRECT);
         const uint32_t ca = ids_in_regs ? part.get(0) : part.lds[0];
         const uint32_t cb = ids_in_regs ? part.get(1) : part.lds[1];
         load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
@@ -726,11 +754,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (q == 0) {
             int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
             tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
-            if (FAST || RL) {
+            if (REGS) {
 #pragma unroll
                 for (int i = 0; i < 2 * NP; ++i) tr[5 + i] = (int32_t)part.get(i);
             }
-            const bool regs = (FAST || RL) && (!snk_possible || SNK_DIRECT);
+            const bool regs = REGS && (!snk_possible || SNK_DIRECT);
 #pragma unroll 1
             for (uint32_t i = regs ? 2u * P : 0u; i < MAX_PARTNERS; ++i) {
                 int32_t v = -1;
