@@ -460,8 +460,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     // kernel entry (scalar ones when a wavefront is one chain), so the partner rows are requested BEFORE the lanes'
     // own Philox evaluation instead of after it (draw -> table lookup -> row fetch was a serial chain of ~3 k
     // cycles), and the header / pair / snooker blocks are not evaluated here at all.
-    // (one wavefront per chain only: with several chains per wavefront the records measured no gain -- cfg5/8 13.8 vs
-    // 13.9 us/generation -- or a loss -- cfg3 14.6 vs 12.3)
+    // (one wavefront per chain only.  With 4 lanes per chain the records measured no gain, cfg5/8 13.8 vs 13.9 us/generation;
+    // with one lane per chain a loss -- cfg3 14.6 vs 12.3 with 64-byte records per lane, 13.8 vs 12.6 from a
+    // structure-of-arrays table whose loads coalesce: at 65536 chains plan_kernel itself costs 1.3 us per generation)
     const bool planned = (LPC == WAVE) && rec != nullptr;
     // the coordinate-pair blocks follow the row requests when a wavefront is one chain with one pair per lane
     const bool dims_late = planned && RL && DPL == 2;

@@ -87,26 +87,31 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
     const uint32_t cpw = (uint32_t)(block_for(lpc) / lpc);
     return (n_items + cpw - 1) / cpw;
 }
+#ifdef BPM_PRELOAD
+template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
+static void launch_hot(const PhaseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.rec_tab,
+                       a.rec_off, a.n_items, a.mode, a);
+}
+#endif
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 #ifdef BPM_PRELOAD
-    {   // single-GPU launches take a specialised instantiation (kernels.h: HOT): steady state, or DREAM's burn-in
-        constexpr bool PLAN = (LPC == WAVE && DPL == 2);                  // the shape that reads plan records
-        constexpr int HOT_STEADY = PLAN ? 1 : 2, HOT_ADAPT = (ALGO == ALGO_DREAM) ? (PLAN ? 3 : 4) : HOT_STEADY;
+    {   // frequent cases take a specialised instantiation (kernels.h: HOT): steady state, DREAM's burn-in, a rank of a world
+        constexpr bool CAN_PLAN = (LPC == WAVE && DPL == 2);               // the shape that can read plan records
+        const bool wp = CAN_PLAN && a.rec_tab != nullptr;
+        constexpr bool DREAM_ = ALGO == ALGO_DREAM;
         static const bool no_hot = getenv("BPM_NO_HOT") != nullptr;
-        if (!no_hot && phase_args_hot(a, ALGO == ALGO_DREAM, PLAN, false)) {
-            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_STEADY>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+        if (!no_hot && phase_args_hot(a, DREAM_, wp, false)) {
+            if (wp) launch_hot<ALGO, T, NP, LPC, DPL, (CAN_PLAN ? 1 : 2)>(a, s); else launch_hot<ALGO, T, NP, LPC, DPL, 2>(a, s);
             return;
         }
-        if (!no_hot && phase_args_hot_sharded(a, ALGO == ALGO_DREAM, PLAN)) {
-            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, (PLAN ? 5 : 6)>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+        if (!no_hot && phase_args_hot_sharded(a, DREAM_, wp)) {
+            if (wp) launch_hot<ALGO, T, NP, LPC, DPL, (CAN_PLAN ? 5 : 6)>(a, s); else launch_hot<ALGO, T, NP, LPC, DPL, 6>(a, s);
             return;
         }
-        if (!no_hot && ALGO == ALGO_DREAM && phase_args_hot(a, true, PLAN, true)) {
-            hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT_ADAPT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0,
-                               s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+        if (!no_hot && DREAM_ && phase_args_hot(a, true, wp, true)) {
+            if (wp) launch_hot<ALGO, T, NP, LPC, DPL, (DREAM_ ? (CAN_PLAN ? 3 : 4) : 2)>(a, s); else launch_hot<ALGO, T, NP, LPC, DPL, (DREAM_ ? 4 : 2)>(a, s);
             return;
         }
     }
