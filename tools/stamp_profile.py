@@ -14,13 +14,21 @@ L.LIB_PATH = os.path.join(ROOT, "build_variants", "libbipymc_stamps.so")
 from bipymc_amd.engine import HipEngine   # noqa: E402
 from bipymc_amd.utils import d100_gauss   # noqa: E402
 
-tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
-for N in (1024, 8192, 65536):
-    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=1, burnin_gen=0)
+WHICH = os.environ.get("STAMP_TARGET", "gauss100")      # gauss100 (DREAM, one wavefront per chain) | banana (DE-MC, one lane per chain)
+if WHICH == "banana":
+    from bipymc_amd.utils import banana_rv
+    tid, tp, d = banana_rv.Banana_2D()._bpm_target_spec()
+    ALGO, SIZES, CPW = L.ALGO_DEMC, (8192, 65536, 262144), 64
+else:
+    tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
+    ALGO, SIZES, CPW = L.ALGO_DREAM, (1024, 8192, 65536), 1
+for N in SIZES:
+    e = HipEngine(algo=ALGO, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=1, burnin_gen=0)
     lib = e.lib
     lib.bpm_debug_stamps.restype = C.c_int
     lib.bpm_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     e.set_state(np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0))
+    n_items = N // 2
     L.check(lib.bpm_debug_stamps(e._h, None, 0))        # allocate
     e.begin_run()
     e.step(30)
