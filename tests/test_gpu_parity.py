@@ -328,6 +328,16 @@ def test_errors_are_reported_not_thrown():
         eng.step(1)                 # begin_run first
     with pytest.raises(BpmError):
         eng.get_history(0, 5)
+    # exchange policy: a single-GPU sampler only has the dense (no-op) exchange; bad modes are refused
+    import ctypes as C
+    assert eng.exchange_stats() == dict(mode="dense", cap=0, chunks=0, replays=0, replay_gens=0)
+    eng.set_exchange(mode="dense")
+    with pytest.raises(BpmError, match="dense exchange"):
+        eng.set_exchange(mode="replay")
+    assert eng.lib.bpm_set_exchange(eng._h, C.c_int32(7), C.c_int32(0)) != 0
+    with pytest.raises(ValueError):
+        _engine(algo=R.ALGO_DEMC, n_chains=8, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=1,
+                world_size=3, rank=0, nccl_uid=b"BPMLOCAL" + bytes(120))           # n_chains % world_size != 0
 
 
 def test_outlier_chain_reset_matches_oracle():
