@@ -434,7 +434,15 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     double gtab[DPL];
     if (DREAM && LPC == WAVE) {
 #pragma unroll
-        for (int u = 0; u < DPL; ++u) gtab[u] = ((uint32_t)(q + u * WAVE) <= dim) ? a.gamma_tab[q + u * WAVE] : 0.0;
+        for (int u = 0; u < DPL; ++u) {
+            // every lane loads (index clamped to the table's last entry), the lanes beyond dim are zeroed by a select on the
+            // loaded value.  As a predicated load (`cond ? tab[i] : 0.0`) the zero of those lanes is a second write to the
+            // load's destination register, which the compiler guards with s_waitcnt vmcnt(0): every wavefront then sat
+            // out its own-row fetch before it could even request the partner rows.
+            const uint32_t gi = (uint32_t)(q + u * WAVE);
+            const double gl = a.gamma_tab[gi <= dim ? gi : dim];
+            gtab[u] = gi <= dim ? gl : 0.0;
+        }
     }
     const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
     const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
