@@ -558,3 +558,40 @@ def test_eight_rank_world_equals_single_rank(exchange):
         np.testing.assert_array_equal(e.stats()["p_cr"], one.stats()["p_cr"])
     assert sum(e.stats()["local_n_accepted"] for e in ranks) == one.stats()["local_n_accepted"]
     assert ranks[0].exchange_stats()["replay_gens" if exchange == "replay" else "chunks"] > 0
+
+
+def test_config4_shape_eight_ranks_equal_single_rank():
+    """BASELINE config 4 itself -- 65536 chains of the 100-D Gaussian as 8 ranks of 8192 -- emulated on one GPU: 130
+    generations (40 of burn-in with CR adaptation and the dense exchange, then the replay exchange with rank-local
+    records) leave every replica, p_cr and the accept counts exactly where the single-rank run of 65536 chains ends."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    R, N, G = 8, 65536, 130
+    kw = dict(burnin_gen=40, n_cr_gen=10)
+    np.random.seed(4)
+    x0 = g.rvs(N)
+    one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, keep_history=False, **kw)
+    one.set_state(x0)
+    one.begin_run()
+    one.step(G)
+    X1, st1 = one.get_state(), one.stats()
+    one.close()
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run()
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    assert ranks[0].exchange_stats()["mode"] == "replay" and ranks[0].exchange_stats()["replay_gens"] == G - 40
+    for e in ranks:
+        assert np.array_equal(e.get_state(), X1)
+        np.testing.assert_array_equal(e.stats()["p_cr"], st1["p_cr"])
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == st1["local_n_accepted"]
+    for e in ranks:
+        e.close()
