@@ -207,15 +207,34 @@ struct bpm_sampler {
     double* trace_f64 = nullptr;
     uint8_t* trace_mask = nullptr;
     double* scratch = nullptr;   // small device scratch (theta0, var, moments)
-    uint32_t* perm_tab = nullptr;   // [PERM_CHUNK * N] shuffle orders of the generations [tab_t0, tab_t0 + tab_K)
+    // Per-generation tables that depend only on (seed, generation, N) -- shuffle orders, update records -- are built a WINDOW
+    // of win_K generations at a time (window W = generations [W win_K, (W + 1) win_K)), on a second stream, into one of two
+    // buffers: while the update kernels of window W run, window W + 1 is built beside them, so the update kernels never wait
+    // for a table (round 1 built the tables of a bpm_step call on the update stream, at the head of the call).
+    struct TabBuf {
+        uint32_t* perm = nullptr;       // [win_K * N] shuffle orders, position -> chain id
+        uint32_t* inv = nullptr;        // [win_K * N] chain id -> position
+        uint32_t* plan = nullptr;       // [win_K * N * PLAN_WORDS] update records (plan_kernel) or nullptr
+        uint32_t* plan_local = nullptr; // world > 1: [win_K * 2 * n_local * PLAN_WORDS] this rank's own records of each half generation, compacted
+        uint32_t* plan_count = nullptr; // device [win_K * 2]: how many
+        uint32_t* count_h = nullptr;    // the same in pinned host memory, copied by the build stream
+        int64_t W = -1;                 // window held (or being built)
+        int shuffle = -1;
+        hipEvent_t built = nullptr;     // recorded on the build stream behind the window's last kernel / copy
+    };
+    TabBuf tb[2];
+    int cur = -1;                       // buffer the update stream is using
+    int win_K = 0;                      // generations per window (<= PERM_CHUNK)
+    bool plan_on = false, plan_local_on = false;
+    hipStream_t aux = nullptr;          // build stream
+    hipEvent_t ev_main = nullptr;       // "everything enqueued on the update stream so far": a build may not overwrite a buffer before it
+    // the current window (aliases into tb[cur])
+    uint32_t* perm_tab = nullptr;
     uint32_t* inv_tab = nullptr;
+    uint32_t* plan_tab = nullptr;
+    uint32_t* plan_local = nullptr;
+    const uint32_t* plan_count_h = nullptr;
     int64_t tab_t0 = -1;
-    uint32_t* plan_tab = nullptr;   // [plan_K * N * PLAN_WORDS] update records of the same generations (plan_kernel) or nullptr
-    int plan_K = 0;                 // generations the plan table holds (<= PERM_CHUNK; 0: no plan)
-    // world > 1: this rank's own records of each half generation, compacted (plan_local_kernel), and how many there are
-    uint32_t* plan_local = nullptr;     // [plan_K * 2 * n_local * PLAN_WORDS]
-    uint32_t* plan_count = nullptr;     // device [plan_K * 2]
-    std::vector<uint32_t> plan_count_h; // the same on the host, read once per table window
     int tab_K = 0;
     int tab_shuffle = -1;
     double* gamma_tab = nullptr;    // [dim + 1]
@@ -364,14 +383,22 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (!s) return 0;
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->perm_tab, s->inv_tab, s->plan_tab, s->plan_local, s->plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].plan_local, s->tb[0].plan_count,
+                    s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].plan_local, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& B : s->tb) {
+        if (B.count_h) (void)hipHostFree(B.count_h);
+        if (B.built) (void)hipEventDestroy(B.built);
+    }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_main) (void)hipEventDestroy(s->ev_main);
+    if (s->aux) (void)hipStreamDestroy(s->aux);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return 0;
@@ -436,8 +463,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     } while (0)
     HIPCKD(hipSetDevice(cfg->device));
     HIPCKD(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCKD(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
+    HIPCKD(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
+    for (auto& B : s->tb) HIPCKD(hipEventCreateWithFlags(&B.built, hipEventDisableTiming));
     s->L.blk = (uint64_t)s->n_local * (s->ld + 2);
     s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
     s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
@@ -461,25 +491,31 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc(&s->acc_count, s->n_local));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
-    CKD(dev_alloc(&s->perm_tab, (size_t)PERM_CHUNK * s->N));
     // update records drawn ahead (plan_kernel) for the fused device kernels, while a launch is latency bound.  Measured
     // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
     // 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the shorter critical
     // path gains (42.7 vs 41.6, 77.9 vs 75.8 at 65536).
     static const bool no_plan = getenv("BPM_NO_PLAN") != nullptr || getenv("BPM_NO_PERM_TAB") != nullptr;
     const uint32_t plan_max_local = getenv("BPM_PLAN_MAX") ? (uint32_t)atoi(getenv("BPM_PLAN_MAX")) : 16384u;     // tuning switch
-    if (!no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local && (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) &&
-        tid != BPM_TARGET_HOST_CALLBACK) {
+    s->win_K = PERM_CHUNK;
+    s->plan_on = !no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local &&
+                 (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) && tid != BPM_TARGET_HOST_CALLBACK;
+    if (s->plan_on) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
-        s->plan_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
-        CKD(dev_alloc(&s->plan_tab, (size_t)s->plan_K * s->N * PLAN_WORDS));
-        if (s->world > 1 && getenv("BPM_NO_PLAN_LOCAL") == nullptr) {
-            CKD(dev_alloc(&s->plan_local, (size_t)s->plan_K * 2 * s->n_local * PLAN_WORDS));
-            CKD(dev_alloc(&s->plan_count, (size_t)s->plan_K * 2));
-            s->plan_count_h.assign((size_t)s->plan_K * 2, 0u);
+        s->win_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
+        s->plan_local_on = s->world > 1 && getenv("BPM_NO_PLAN_LOCAL") == nullptr;
+    }
+    for (auto& B : s->tb) {
+        CKD(dev_alloc(&B.perm, (size_t)s->win_K * s->N));
+        CKD(dev_alloc(&B.inv, (size_t)s->win_K * s->N));
+        if (s->plan_on) CKD(dev_alloc(&B.plan, (size_t)s->win_K * s->N * PLAN_WORDS));
+        if (s->plan_local_on) {
+            CKD(dev_alloc(&B.plan_local, (size_t)s->win_K * 2 * s->n_local * PLAN_WORDS));
+            CKD(dev_alloc(&B.plan_count, (size_t)s->win_K * 2));
+            HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&B.count_h), (size_t)s->win_K * 2 * sizeof(uint32_t), hipHostMallocDefault));
         }
     }
-    CKD(dev_alloc(&s->inv_tab, (size_t)PERM_CHUNK * s->N));
+    if (s->plan_on) s->plan_tab = s->tb[0].plan;       // (non-null from here on: "this sampler launches with records")
     CKD(dev_alloc(&s->gamma_tab, (size_t)s->dim + 1));
     if (cfg->algo == BPM_ALGO_DEMC_SYNC) CKD(dev_alloc(&s->x_next, row_d));
     {
@@ -614,6 +650,8 @@ extern "C" int bpm_get_loglike(bpm_handle_t s, double* ll_local) {
     return 0;
 }
 
+static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead);
+
 extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -633,6 +671,9 @@ extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
     HIPCK(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));     // demc.py:67
     HIPCK(hipStreamSynchronize(s->stream));
     s->run_open = true;
+    // the tables of the window this run starts in (and of the next one) are built from here on, beside whatever the caller does
+    // before its first bpm_step
+    if (s->cfg.algo != BPM_ALGO_DEMC_SYNC) CK(ensure_perm_table(s, s->t_abs, 1));
     return 0;
 }
 
@@ -642,35 +683,58 @@ static int allgather_state(bpm_sampler* s) {
     return 0;
 }
 
-// Shuffle orders for the generations [t, t + n_ahead) (at most PERM_CHUNK) in one launch.
-static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t n_ahead) {
-    const int shuffle = s->opts.shuffle != 0 ? 1 : 0;
-    if (s->tab_shuffle == shuffle && t >= s->tab_t0 && t < s->tab_t0 + s->tab_K) return 0;
-    int K = (int)std::max<int64_t>(1, std::min<int64_t>(PERM_CHUNK, n_ahead));
-    if (s->plan_tab) K = std::min(K, s->plan_K);
+// Window W of the per-generation tables into buffer b, on the build stream.
+static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
+    bpm_sampler::TabBuf& B = s->tb[b];
+    const int K = s->win_K;
+    const int64_t t0 = W * K;
+    // the update stream may still read what this buffer holds (an older window): the build starts behind everything enqueued there so far
+    HIPCK(hipEventRecord(s->ev_main, s->stream));
+    HIPCK(hipStreamWaitEvent(s->aux, s->ev_main, 0));
     PermKeys keys;
-    for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t + g), s->N, shuffle != 0);
+    for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
     const uint64_t n = (uint64_t)K * s->N;
-    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, keys, (uint32_t)K, s->N,
-                       s->perm_tab, s->inv_tab);
+    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->aux, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
-    if (s->plan_tab) {
-        PlanParams pp{s->cfg.seed, (uint64_t)t, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
+    if (B.plan) {
+        PlanParams pp{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
                       (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, pp, s->perm_tab, s->plan_tab);
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->aux, pp, B.perm, B.plan);
         HIPCK(hipGetLastError());
-        if (s->plan_local) {        // this rank's records, compacted; the counts size the launches of this window: one sync per <= 64 generations
-            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, s->stream, s->plan_tab, s->N, s->lo,
-                               s->n_local, s->plan_local, s->plan_count);
+        if (B.plan_local) {        // this rank's records, compacted; the counts size the launches of the window
+            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, s->aux, B.plan, s->N, s->lo,
+                               s->n_local, B.plan_local, B.plan_count);
             HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(s->plan_count_h.data(), s->plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-            HIPCK(hipStreamSynchronize(s->stream));
+            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->aux));
         }
     }
-    s->tab_t0 = t;
+    HIPCK(hipEventRecord(B.built, s->aux));
+    B.W = W;
+    B.shuffle = shuffle;
+    return 0;
+}
+
+// The tables of generation t are current on the update stream; on entering a window the next one is started on the build
+// stream.  In a run that crosses windows the update kernels therefore find every window but the very first already built
+// (bpm_begin_run starts that one), and a rank of a world finds its launch sizes on the host without stalling.
+static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
+    const int shuffle = s->opts.shuffle != 0 ? 1 : 0;
+    if (s->cur >= 0 && s->tab_shuffle == shuffle && t >= s->tab_t0 && t < s->tab_t0 + s->tab_K) return 0;
+    const int K = s->win_K;
+    const int64_t W = t / K;
+    const int b = (int)(W & 1);
+    bpm_sampler::TabBuf& B = s->tb[b];
+    if (B.W != W || B.shuffle != shuffle) CK(build_window(s, b, W, shuffle));
+    HIPCK(hipStreamWaitEvent(s->stream, B.built, 0));
+    if (B.plan_local) HIPCK(hipEventSynchronize(B.built));        // the window's launch sizes (count_h)
+    s->cur = b;
+    s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_local = B.plan_local; s->plan_count_h = B.count_h;
+    s->tab_t0 = W * K;
     s->tab_K = K;
     s->tab_shuffle = shuffle;
+    bpm_sampler::TabBuf& Bn = s->tb[b ^ 1];
+    if (Bn.W != W + 1 || Bn.shuffle != shuffle) CK(build_window(s, b ^ 1, W + 1, shuffle));
     return 0;
 }
 
@@ -756,7 +820,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             const uint64_t slot = (uint64_t)(s->t_abs - s->tab_t0) * 2 + (a.upd_off == 0 ? 0u : 1u);
             a.rec_tab = s->plan_local + slot * s->n_local * PLAN_WORDS;
             a.rec_off = 0u;
-            a.n_items = s->plan_count_h[(size_t)slot];
+            a.n_items = s->plan_count_h[(size_t)slot];      // (pinned host copy, complete: ensure_perm_table waited for the window's build)
             a.mode = 0u;
         }
         a.algo = (uint32_t)s->cfg.algo;

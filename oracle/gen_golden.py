@@ -19,6 +19,9 @@ Fixtures written:
       steps_dream_gauss16.npz      update of short reference runs (DREAM d=2 N=10 with CR
       steps_demc_banana.npz        adaptation active; DREAM d=16 equicorrelated Gaussian
                                    N=8; DE-MC banana N=8)
+      steps_demc_serial_banana.npz the SERIAL sampler bipymc.samplers.DeMc (samplers.py:261-308,
+                                   delayed_accept=True): pool = np.delete(range(N), i), no gamma
+                                   jump, updates banked until every chain has proposed
   G3  e2e_anchor_cfg1.json         end-to-end moments of a seed-42 cfg1-like run
 
 Usage:  python oracle/gen_golden.py [--out tests/golden]
@@ -85,6 +88,53 @@ def _import_reference():
     from bipymc.demc import DeMcMpi
     from bipymc.utils import d100_gauss, dblgauss_rv, banana_rv
     return DreamMpi, DeMcMpi, d100_gauss, dblgauss_rv, banana_rv
+
+
+def record_serial_demc(sampler, n, theta_0, **run_kwargs):
+    """Run the serial `bipymc.samplers.DeMc.run_mcmc(n, theta_0)` (samplers.py:261-308) recording, per chain
+    update, the draws it made (pair = CHAIN IDS chosen from np.delete(range(N), i); normal jitter; accept
+    decision) and the proposal / ratio it computed, and per generation the chain states before and after."""
+    cls = type(sampler)
+    rec = Recorder()
+    updates = []
+    orig_ratio = cls._mut_prop_ratio
+    orig_init = cls._init_chains
+    frozen = sampler._frozen_ln_like_fn
+    mark = {"i0": 0}
+
+    def init(self, theta_0, varepsilon=1e-6, **kw):
+        orig_init(self, theta_0, varepsilon, **kw)
+        mark["i0"] = len(rec.calls)                       # draws of chain.py:27 end here
+
+    def ratio(self, fn, current_theta, mut_theta):
+        alpha = orig_ratio(self, fn, current_theta, mut_theta)
+        updates.append(dict(current=np.array(current_theta).copy(), prop=np.array(mut_theta).copy(), alpha=float(alpha),
+                            ll_prop=float(frozen(mut_theta)), ll_cur=float(frozen(current_theta)), n_calls=len(rec.calls)))
+        return alpha
+
+    cls._mut_prop_ratio = ratio
+    cls._init_chains = init
+    try:
+        with rec:
+            sampler.run_mcmc(n, theta_0, **run_kwargs)
+    finally:
+        cls._mut_prop_ratio = orig_ratio
+        cls._init_chains = orig_init
+    # per update the reference draws: choice (pair ids), multivariate_normal (jitter), then -- after the ratio --
+    # choice (accept)
+    calls = rec.calls
+    pos = mark["i0"]
+    for u in updates:
+        seg = calls[pos:u["n_calls"]]
+        assert [c[0] for c in seg] == ["choice", "multivariate_normal"], [c[0] for c in seg]
+        u["pair"] = seg[0][1].astype(np.int64)
+        u["eps_n"] = seg[1][1].reshape(-1)
+        name, acc = calls[u["n_calls"]]
+        assert name == "choice"
+        u["accept_draw"] = bool(acc)
+        pos = u["n_calls"] + 1
+    assert pos == len(calls)
+    return updates
 
 
 class Recorder(object):
@@ -379,6 +429,27 @@ def main():
     pk = pack_demc(ups, gens, 2, meta)
     pk["init_state"] = init
     np.savez_compressed(os.path.join(out, "steps_demc_banana.npz"), **pk)
+
+    # (iv) the SERIAL DeMc of samplers.py:237-308 (delayed_accept=True, the default) on the banana
+    from bipymc.samplers import DeMc
+    np.random.seed(45)
+    meta = dict(target="Banana_2D", n_chains=8, dim=2, n=8 * 21, varepsilon=1e-6, inflate=1e1, seed=45, delayed_accept=True)
+    s = DeMc(ban.ln_like, n_chains=8)
+    ups = record_serial_demc(s, meta["n"], np.zeros(2))
+    N = meta["n_chains"]
+    n_gens = len(ups) // N
+    assert len(ups) == n_gens * N and n_gens == 20
+    hist = np.array([c.chain for c in s.am_chains])            # (N, T, d): chain.py:51-54, one row per generation
+    assert hist.shape == (N, n_gens + 1, 2)
+    pk = dict(
+        current=np.array([u["current"] for u in ups]), pair=np.array([u["pair"] for u in ups]),
+        eps_n=np.array([u["eps_n"] for u in ups]), accept_draw=np.array([u["accept_draw"] for u in ups]),
+        prop=np.array([u["prop"] for u in ups]), alpha=np.array([u["alpha"] for u in ups]),
+        ll_prop=np.array([u["ll_prop"] for u in ups]), ll_cur=np.array([u["ll_cur"] for u in ups]),
+        history=np.transpose(hist, (1, 0, 2)).copy(),           # (T, N, d): row g = every chain after generation g
+        super_chain=s.super_chain, n_accepted=np.array(s.n_accepted), n_rejected=np.array(s.n_rejected),
+        meta=np.array(json.dumps(meta)))
+    np.savez_compressed(os.path.join(out, "steps_demc_serial_banana.npz"), **pk)
 
     # ---- G3: end-to-end anchor (cfg1 shape, shortened) ------------------
     np.random.seed(42)

@@ -267,6 +267,32 @@ def welford_std(count, m2):
     return np.sqrt(m2 / count)
 
 
+def others_position_to_id(i, pos):
+    """samplers.py:274: np.delete(np.array(range(N)), i)[pos] -- the pool of chain i is every OTHER chain, in id order."""
+    pos = np.asarray(pos)
+    return pos + (pos >= np.asarray(i))
+
+
+def demc_sync_generation(X, ll, ids, pair_a, pair_b, gamma, eps_n, accept, ll_fn):
+    """One generation of the serial DeMc with delayed_accept=True (samplers.py:268-308), every draw an explicit input.
+
+    X (N, d): states at the START of the generation; ids: the chains updated here (all N in the reference; a rank's
+    block in a sharded run); pair_a / pair_b: CHAIN IDS of the mutation pair of each chain (what
+    `np.random.choice(valid_pool_ids, replace=False, size=2)` returns, :275); gamma: scalar, no gamma = 1 jump in this
+    sampler (:263,281); eps_n (n, d): the var_ball draw (:283); accept: callable alpha -> bool array (the
+    metropolis_accept decisions, :289).  Every proposal is made from X -- also for partners that already accepted in
+    this sweep -- because updates are banked until every chain has proposed (:296-308).
+    Returns (new rows of `ids`, new ll of `ids`, prop, ll_prop, alpha, accepted)."""
+    cur = X[ids]
+    prop = demc_proposal(cur, X[pair_a], X[pair_b], np.full(len(ids), gamma), eps_n)      # samplers.py:281-283
+    ll_prop = ll_fn(prop)
+    alpha = mut_prop_ratio(ll[ids], ll_prop)                                              # samplers.py:287-289
+    accepted = accept(alpha)
+    new_rows = np.where(accepted[:, None], prop, cur)                                     # banked_prop_array, :290-303
+    new_ll = np.where(accepted, ll_prop, ll[ids])
+    return new_rows, new_ll, prop, ll_prop, alpha, accepted
+
+
 def snooker_third(wz, w1, w2, m):
     """Three distinct pool positions (z, z1, z2) from three words."""
     iz = P.mulhi(wz, m)
@@ -475,16 +501,13 @@ class OracleSampler(object):
             eps_n = np.zeros((n, d))
         wp = P.chain_block(seed, ids, t, P.SLOT_PAIR0)
         ia, ib = P.distinct_pair(wp[:, 0], wp[:, 1], N - 1)
-        ia = ia + (ia >= ids)                        # positions in np.delete(range(N), i)
-        ib = ib + (ib >= ids)
+        ia = others_position_to_id(ids, ia)          # positions in np.delete(range(N), i)
+        ib = others_position_to_id(ids, ib)
         gamma = demc_gamma_base(d, gamma_kw)
-        cur = self.X[ids]
-        prop = demc_proposal(cur, self.X[ia], self.X[ib], np.full(n, gamma), eps_n)
-        ll_prop = self._ll(prop)
-        alpha = mut_prop_ratio(self.ll[ids], ll_prop)
-        accepted = metropolis_accept(alpha, P.u01_53(h0[:, 2], h0[:, 3]))
-        new_local = np.where(accepted[:, None], prop, cur)
-        self.ll[ids] = np.where(accepted, ll_prop, self.ll[ids])
+        ua = P.u01_53(h0[:, 2], h0[:, 3])
+        new_local, new_ll, prop, ll_prop, alpha, accepted = demc_sync_generation(
+            self.X, self.ll, ids, ia, ib, gamma, eps_n, lambda al: metropolis_accept(al, ua), self._ll)
+        self.ll[ids] = new_ll
         na = int(np.count_nonzero(accepted))
         self.local_n_accepted += na
         self.local_n_rejected += n - na

@@ -6,6 +6,9 @@
                                                           -> per-dispatch counter values of the kernels whose name contains the
                                                              substring: all-mean and the mean of the last `last_n` dispatches
                                                              (steady state: bench.py's post-burn-in launches)
+  rocpd_summary.py timeline <kt_results.db> [last_n]      -> the last `last_n` dispatches in start order: start offset (us), duration,
+                                                             gap since the previous dispatch ended, kernel name (what a short timed
+                                                             window really contains)
 """
 import sqlite3
 import sys
@@ -35,9 +38,22 @@ def pmc(path, counter, sub="phase_fused_kernel", last_n=40):
           % (counter, sub, len(vals), sum(vals) / len(vals), len(tail), sum(tail) / len(tail), min(tail), max(tail)))
 
 
+def timeline(path, last_n=80):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()[-last_n:]
+    t0, prev_end = rows[0][1], None
+    print("start_us  dur_us  gap_us  kernel")
+    for name, st, en in rows:
+        short = name.split("(")[0][-70:]
+        print("%9.2f %7.2f %7.2f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, 0.0 if prev_end is None else (st - prev_end) / 1e3, short))
+        prev_end = en
+
+
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "timeline":
+        timeline(sys.argv[2], *([int(sys.argv[3])] if len(sys.argv) > 3 else []))
     elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:5] or ["phase_fused_kernel"]), *([int(sys.argv[5])] if len(sys.argv) > 5 else []))
     else:
