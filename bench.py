@@ -187,11 +187,12 @@ def main():
     # ---- warm-up
     eng.step(args.warmup)
     fence()
-    # ---- timed region: exactly K generations.  Wall clock for `value`; a HIP event pair recorded on the
-    # sampler's own stream around the same K generations for the kernel's per-launch duration (step_timed returns
-    # when the second event has completed, i.e. the sampler's stream is already drained when fence() runs).
+    # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two HIP events
+    # bound to the first and the last update-kernel dispatch of the same K generations on the sampler's own stream
+    # (bpm_step_timed: end of launch 1 -> end of launch 2K, i.e. 2K - 1 back-to-back launch periods; it returns with the
+    # sampler's stream drained).
     t0 = time.perf_counter()
-    ev_ms = eng.step_timed(args.steps)
+    ev_ms, ev_launches = eng.step_timed(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -205,8 +206,8 @@ def main():
     # ---- dominant kernel (phase_fused_kernel): 2 launches per generation, back to back on one stream; at
     # N = 1 nothing else runs in the region, so event time / launches is its average launch duration
     # (inter-launch gaps included; rocprofv3 --kernel-trace gives the gap-free figure, profiles/).
-    n_launch = 2 * args.steps
-    k_avg_ms = ev_ms / n_launch
+    n_launch = ev_launches
+    k_avg_ms = ev_ms / max(n_launch, 1)
     units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
     achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9
     pair_ms, pair_n = eng.step_profiled(32)                       # cross-check: an event pair around every launch
@@ -254,7 +255,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             # the same K generations by the HIP event pair on the sampler's stream (no host launch / wake-up latency)
-            "value_event_timed": n_chains * args.steps / (ev_ms * 1e-3),
+            "value_event_timed": n_chains / (2.0 * k_avg_ms * 1e-3),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "DREAM, 100-D equicorrelated Gaussian (tests/test_100dgauss.py target), "
                                    "n_chains=%d (%d per GPU), del_pairs=3, n_cr=3, steady state after %d burn-in "

@@ -51,6 +51,7 @@ _H = C.c_void_p
 SIGNATURES = {
     "bpm_last_error": (C.c_char_p, []),
     "bpm_abi_version": (C.c_int, []),
+    "bpm_device_count": (C.c_int, [_ip]),
     "bpm_get_unique_id": (C.c_int, [C.c_char_p]),
     "bpm_create": (C.c_int, [_P(BpmConfig), _P(_H)]),
     "bpm_destroy": (C.c_int, [_H]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "bpm_get_loglike": (C.c_int, [_H, _dp]),
     "bpm_begin_run": (C.c_int, [_H, _P(BpmRunOpts)]),
     "bpm_step": (C.c_int, [_H, C.c_int64]),
-    "bpm_step_timed": (C.c_int, [_H, C.c_int64, _P(C.c_float)]),
+    "bpm_step_timed": (C.c_int, [_H, C.c_int64, _P(C.c_float), _P(C.c_int64)]),
     "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
     "bpm_synchronize": (C.c_int, [_H]),
     "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),
@@ -108,6 +109,12 @@ def load():
         raise ImportError("bipymc_amd: libbipymc_hip.so ABI %d != binding ABI %d" % (lib.bpm_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(load().bpm_device_count(C.byref(n)))
+    return int(n.value)
 
 
 def check(rc):

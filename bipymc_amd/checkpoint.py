@@ -44,11 +44,27 @@ def write(path, hist, adapt=None):
     return target
 
 
+def _is_hdf5(path):
+    """HDF5 signature (the 8 bytes every HDF5 file starts with, at offset 0 for files h5py writes)."""
+    try:
+        with open(path, "rb") as f:
+            return f.read(8) == b"\x89HDF\r\n\x1a\n"
+    except (IOError, OSError):
+        return False
+
+
 def read(path, n_chains, dim):
-    """-> (hist (T, N, dim), adapt dict)."""
+    """-> (hist (T, N, dim), adapt dict).  The format is decided by what is ON DISK, not by what this interpreter could
+    write: `path` itself if it is an HDF5 file (the reference's write_chain_h5 layout, chain.py:59-70; needs h5py), else the
+    NumPy twin `path` (when it ends in .npz) or `path + ".npz"`."""
+    import os
     adapt = {}
     chains = []
-    if _use_h5(path):
+    path = str(path)
+    if os.path.exists(path) and _is_hdf5(path):
+        if not _have_h5py():
+            raise IOError("checkpoint %s is an HDF5 file but h5py is not importable here; install h5py or convert it to the "
+                          ".npz layout (keys chains/chain_id_<i>)" % path)
         import h5py
         with h5py.File(path, "r") as f:
             for i in range(n_chains):
@@ -57,10 +73,9 @@ def read(path, n_chains, dim):
                 for k in f["bipymc_amd"]:
                     adapt[k] = f["bipymc_amd"][k][()]
     else:
-        import os
-        target = path if str(path).endswith(".npz") else str(path) + ".npz"
+        target = path if path.endswith(".npz") else path + ".npz"
         if not os.path.exists(target):
-            raise IOError("checkpoint %s not found (h5py unavailable: .npz layout expected)" % target)
+            raise IOError("checkpoint not found: neither an HDF5 file %s nor its NumPy twin %s" % (path, target))
         with np.load(target) as f:
             for i in range(n_chains):
                 chains.append(f["chains/chain_id_" + str(i)])

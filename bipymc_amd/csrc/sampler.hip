@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -80,6 +81,15 @@ static int load_rccl() {
     } while (0)
 
 // ---- kernel dispatch ---------------------------------------------------------------
+// bpm_step_timed: the NEXT update-kernel launch of this thread carries this event as its stop event (hipExtLaunchKernelGGL
+// binds it to the dispatch itself: its time stamp is the kernel's end, and no marker packet enters the queue)
+static thread_local hipEvent_t g_stop_event = nullptr;
+static thread_local int64_t g_timed_launches = 0;
+static inline hipEvent_t take_stop_event() {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}
 typedef void (*PhaseLaunch)(const PhaseArgs&, hipStream_t);
 typedef void (*EvalLaunch)(const double*, uint32_t, uint32_t, uint32_t, const double*, double*, hipStream_t);
 
@@ -90,8 +100,9 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
 #ifdef BPM_PRELOAD
 template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.rec_tab,
-                       a.rec_off, a.n_items, a.mode, a);
+    hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
+                          nullptr, take_stop_event(), 0, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+    ++g_timed_launches;
 }
 #endif
 template <int ALGO, int T, int NP, int LPC, int DPL>
@@ -115,11 +126,13 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
             return;
         }
     }
-    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a.rec_tab,
-                       a.rec_off, a.n_items, a.mode, a);
+    hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
+                          nullptr, take_stop_event(), 0, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
 #else
-    hipLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
+    hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
+                          nullptr, take_stop_event(), 0, a);
 #endif
+    ++g_timed_launches;
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_propose(const PhaseArgs& a, hipStream_t s) {
@@ -184,6 +197,10 @@ struct bpm_sampler {
     Layout L{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // bpm_step_timed: ev0 rides on the first update launch of the call, ev1 on the last one
+    bool timed_want_first = false;
+    int64_t timed_last_gen = -1;      // t_abs of the call's last generation (-1: not timing)
+    int64_t timed_l0 = 0, timed_l1 = 0;   // launch counter values at those two launches
     double* G = nullptr;
     double* ll = nullptr;
     double* hist = nullptr;
@@ -208,9 +225,10 @@ struct bpm_sampler {
     uint8_t* trace_mask = nullptr;
     double* scratch = nullptr;   // small device scratch (theta0, var, moments)
     // Per-generation tables that depend only on (seed, generation, N) -- shuffle orders, update records -- are built a WINDOW
-    // of win_K generations at a time (window W = generations [W win_K, (W + 1) win_K)), on a second stream, into one of two
-    // buffers: while the update kernels of window W run, window W + 1 is built beside them, so the update kernels never wait
-    // for a table (round 1 built the tables of a bpm_step call on the update stream, at the head of the call).
+    // of win_K generations at a time (window W = generations [W win_K, (W + 1) win_K)) into one of two buffers, one window
+    // AHEAD of the update kernels: entering window W enqueues the build of W + 1.  A bpm_step call therefore never starts
+    // with a table build (round 1 built the tables of a call at its head: 13 us inside a timed window of 20 generations),
+    // and a rank of a world finds the launch sizes of a window on the host without a stall.
     struct TabBuf {
         uint32_t* perm = nullptr;       // [win_K * N] shuffle orders, position -> chain id
         uint32_t* inv = nullptr;        // [win_K * N] chain id -> position
@@ -226,7 +244,7 @@ struct bpm_sampler {
     int cur = -1;                       // buffer the update stream is using
     int win_K = 0;                      // generations per window (<= PERM_CHUNK)
     bool plan_on = false, plan_local_on = false;
-    hipStream_t aux = nullptr;          // build stream
+    hipStream_t aux = nullptr;          // optional second build stream (BPM_TAB_AUX=1); default: the update stream builds, one window ahead
     hipEvent_t ev_main = nullptr;       // "everything enqueued on the update stream so far": a build may not overwrite a buffer before it
     // the current window (aliases into tb[cur])
     uint32_t* perm_tab = nullptr;
@@ -369,6 +387,13 @@ static int reset_history(bpm_sampler* s) {
 
 extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
 extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
+extern "C" int bpm_device_count(int32_t* out) {
+    if (!out) return fail("bpm_device_count: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *out = n;
+    return 0;
+}
 
 extern "C" int bpm_get_unique_id(char out[BPM_UID_BYTES]) {
     CK(load_rccl());
@@ -463,7 +488,13 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     } while (0)
     HIPCKD(hipSetDevice(cfg->device));
     HIPCKD(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIPCKD(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    // Where the per-generation tables are built.  Default: on the update stream itself, ONE WINDOW AHEAD (on entering window W
+    // the build of W + 1 is enqueued in front of W's first update kernel): 23 us per 64 generations at cfg2, and no bpm_step
+    // call ever starts with a table build.  BPM_TAB_AUX=1 builds on a second stream beside the update kernels instead --
+    // measured SLOWER on MI355X: 13.7 vs 12.3 us per generation at cfg2 (~90 us per window: the cross-queue dependencies and
+    // the concurrent build cost the latency-bound update kernels far more than the 23 us they hide;
+    // profiles/r02_table_build_modes.txt), lowest stream priority no different.
+    if (getenv("BPM_TAB_AUX") != nullptr) HIPCKD(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
     HIPCKD(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
@@ -636,8 +667,12 @@ extern "C" int bpm_set_loglike(bpm_handle_t s, const double* ll_local) {
     CK(set_device(s));
     if (!ll_local) return fail("bpm_set_loglike: null argument");
     HIPCK(hipMemcpyAsync(s->ll, ll_local, s->n_local * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    if (s->hist_rows >= 1 && s->rows_logical == 1)   // initial row of the log-like history
-        HIPCK(hipMemcpyAsync(s->llhist, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    // the log-like history row of the current state: row 0 after (re)initialisation, the LAST row after a warm start
+    // (bpm_set_history with a host-callback target could only leave NaN there; older rows stay NaN: the reference's
+    // checkpoint does not store log-likes, chain.py:59-70)
+    if (s->hist_rows >= 1 && s->hist_rows == s->rows_logical)
+        HIPCK(hipMemcpyAsync(s->llhist + (size_t)(s->hist_rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double),
+                             hipMemcpyDeviceToDevice, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -688,28 +723,31 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     bpm_sampler::TabBuf& B = s->tb[b];
     const int K = s->win_K;
     const int64_t t0 = W * K;
-    // the update stream may still read what this buffer holds (an older window): the build starts behind everything enqueued there so far
-    HIPCK(hipEventRecord(s->ev_main, s->stream));
-    HIPCK(hipStreamWaitEvent(s->aux, s->ev_main, 0));
+    hipStream_t bs = s->aux ? s->aux : s->stream;
+    if (s->aux) {
+        // the update stream may still read what this buffer holds (an older window): the build starts behind everything enqueued there so far
+        HIPCK(hipEventRecord(s->ev_main, s->stream));
+        HIPCK(hipStreamWaitEvent(s->aux, s->ev_main, 0));
+    }
     PermKeys keys;
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
     const uint64_t n = (uint64_t)K * s->N;
-    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->aux, keys, (uint32_t)K, s->N, B.perm, B.inv);
+    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
     if (B.plan) {
         PlanParams pp{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
                       (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->aux, pp, B.perm, B.plan);
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, pp, B.perm, B.plan);
         HIPCK(hipGetLastError());
         if (B.plan_local) {        // this rank's records, compacted; the counts size the launches of the window
-            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, s->aux, B.plan, s->N, s->lo,
+            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, bs, B.plan, s->N, s->lo,
                                s->n_local, B.plan_local, B.plan_count);
             HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->aux));
+            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
         }
     }
-    HIPCK(hipEventRecord(B.built, s->aux));
+    HIPCK(hipEventRecord(B.built, bs));
     B.W = W;
     B.shuffle = shuffle;
     return 0;
@@ -726,7 +764,7 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
     const int b = (int)(W & 1);
     bpm_sampler::TabBuf& B = s->tb[b];
     if (B.W != W || B.shuffle != shuffle) CK(build_window(s, b, W, shuffle));
-    HIPCK(hipStreamWaitEvent(s->stream, B.built, 0));
+    if (s->aux) HIPCK(hipStreamWaitEvent(s->stream, B.built, 0));
     if (B.plan_local) HIPCK(hipEventSynchronize(B.built));        // the window's launch sizes (count_h)
     s->cur = b;
     s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_local = B.plan_local; s->plan_count_h = B.count_h;
@@ -1059,7 +1097,15 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
     } else {
         for (int ph = 0; ph < 2; ++ph) {
             for (int r = 0; r < g.R; ++r) {
-                if (g.h[r]->cur_args[ph].n_items > 0) fn(g.h[r]->cur_args[ph], g.h[r]->stream);
+                bpm_sampler* s = g.h[r];
+                if (s->cur_args[ph].n_items > 0) {
+                    if (s->timed_want_first) {
+                        s->timed_want_first = false; g_stop_event = s->ev0; s->timed_l0 = g_timed_launches;
+                    } else if (s->timed_last_gen == s->t_abs && (ph == 1 || s->cur_args[1].n_items == 0)) {
+                        g_stop_event = s->ev1; s->timed_l1 = g_timed_launches;
+                    }
+                    fn(s->cur_args[ph], s->stream);
+                }
                 if (local_serial(g)) HIPCK(hipStreamSynchronize(g.h[r]->stream));
             }
             HIPCK(hipGetLastError());
@@ -1264,17 +1310,28 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     return 0;
 }
 
-extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms) {
+extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms, int64_t* n_launches) {
     CK(check_handle(s));
     CK(set_device(s));
+    if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_timed: not available for the synchronous DE-MC mode");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
-    HIPCK(hipEventRecord(s->ev0, s->stream));
-    CK(bpm_step(s, n_gens));
-    HIPCK(hipEventRecord(s->ev1, s->stream));
-    HIPCK(hipEventSynchronize(s->ev1));
-    float ms = 0.f;
-    HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    if (elapsed_ms) *elapsed_ms = ms;
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (n_launches) *n_launches = 0;
+    s->timed_want_first = n_gens > 0;
+    s->timed_last_gen = n_gens > 0 ? s->t_abs + n_gens - 1 : -1;
+    s->timed_l0 = s->timed_l1 = -1;
+    const int rc = bpm_step(s, n_gens);
+    s->timed_want_first = false;
+    s->timed_last_gen = -1;
+    g_stop_event = nullptr;
+    CK(rc);
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        if (elapsed_ms) *elapsed_ms = ms;
+        if (n_launches) *n_launches = s->timed_l1 - s->timed_l0;
+    }
     return 0;
 }
 
@@ -1343,10 +1400,11 @@ extern "C" int bpm_set_history(bpm_handle_t s, int64_t rows, const double* hist_
             }
             HIPCK(hipGetLastError());
         } else {
-            std::vector<double> nanv((size_t)(rows - 1) * s->n_local, std::nan(""));
+            // host-callback target: the caller supplies the current ln-likes next (bpm_set_loglike fills the last row);
+            // the older rows are unknown -- NaN, which the outlier check skips
+            std::vector<double> nanv((size_t)rows * s->n_local, std::nan(""));
             HIPCK(hipMemcpyAsync(s->llhist, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
             HIPCK(hipStreamSynchronize(s->stream));
-            HIPCK(hipMemcpyAsync(s->llhist + (size_t)(rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         }
         s->hist_rows = rows;
         s->rows_logical = rows;

@@ -26,6 +26,19 @@ from .chain import DetachedChain, McmcChain
 from .utils import _target
 
 
+def _visible_device_count():
+    """hipGetDeviceCount without creating a context (bpm_device_count)."""
+    try:
+        return int(L.device_count())
+    except Exception:
+        return 0
+
+
+def _hostname():
+    import socket
+    return socket.gethostname()
+
+
 def _default_engine_factory(**kw):
     from .engine import HipEngine
     return HipEngine(**kw)
@@ -96,8 +109,29 @@ class DeMcMpi(object):
         return {}
 
     def _default_device(self):
+        """One process per GPU: the node-local rank as the launcher exports it (torchrun: LOCAL_RANK; Open MPI, MVAPICH,
+        Slurm), else rank modulo the number of visible devices.  A launcher that already narrowed the visible devices to
+        one per process (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) gets device 0."""
         import os
-        return int(os.environ.get("LOCAL_RANK", "0")) if self.comm.size > 1 else 0
+        if self.comm.size == 1:
+            return 0
+        local = None
+        for var in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+            if os.environ.get(var, "") != "":
+                local = int(os.environ[var])
+                break
+        ndev = _visible_device_count()
+        if local is None:
+            local = self.comm.rank % max(ndev, 1)
+        if ndev <= 1:          # one device exposed per process (or none at all: bpm_create will say so)
+            return 0
+        if local >= ndev:
+            raise RuntimeError("local rank %d but only %d visible GPU(s): launch one process per GPU" % (local, ndev))
+        # two ranks of one node on the same device would deadlock in ncclCommInitRank: say so instead
+        taken = self.comm.allgather((_hostname(), local))
+        if taken.count((_hostname(), local)) > 1:
+            raise RuntimeError("several ranks of host %s resolved to GPU %d; set LOCAL_RANK (or pass device=)" % (_hostname(), local))
+        return local
 
     # ---- samplers.py:36-47 -----------------------------------------------
     def _freeze_ln_like_fn(self, **kwargs):
@@ -276,10 +310,15 @@ class DeMcMpi(object):
                 yield None
 
     def get_chain(self, c_id, collection_rank=0, verbose=0):
+        """demc.py:296-325.  Which branch is taken depends only on (c_id, collection_rank), never on the calling rank: either
+        nobody communicates (the owner IS the collection rank: it returns its own chain, everyone else None) or every rank
+        enters the same collective."""
         assert 0 <= c_id < self.n_chains
         r = self.get_chain_rank(c_id)
-        if self.comm.size == 1 or (r == collection_rank and self.comm.rank == r):
-            return self.am_chains[c_id - self.comm.rank * self.n_local]
+        if self.comm.size == 1:
+            return self.am_chains[c_id]
+        if r == collection_rank:                                   # demc.py:301-304: no communication at all
+            return self.am_chains[c_id - r * self.n_local] if self.comm.rank == r else None
         parts = self.comm.allgather(self._local_history()[:, c_id - r * self.n_local, :]
                                     if self.comm.rank == r else None)
         if self.comm.rank == collection_rank:

@@ -124,9 +124,11 @@ class HipEngine(object):
         L.check(self.lib.bpm_step(self._h, int(n_gens)))
 
     def step_timed(self, n_gens):
+        """-> (ms from the end of the first update launch to the end of the last, launches in that interval); synchronous"""
         ms = C.c_float(0.0)
-        L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms)))
-        return float(ms.value)
+        n = C.c_int64(0)
+        L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def step_profiled(self, n_gens):
         """-> (summed update-kernel time in ms, number of launches)"""

@@ -109,6 +109,9 @@ typedef struct bpm_stats {
 
 const char* bpm_last_error(void);
 int bpm_abi_version(void);
+/* GPUs visible to this process (hipGetDeviceCount): what one rank per GPU needs to pick its device where the reference
+ * picks nothing (mpi4py ranks share the host's cores, demc.py:15). */
+int bpm_device_count(int32_t* out);
 
 /* rank 0 calls this and ships the bytes to the other ranks (mpi4py bcast / torch.distributed). */
 int bpm_get_unique_id(char out[BPM_UID_BYTES]);
@@ -133,8 +136,11 @@ int bpm_get_loglike(bpm_handle_t h, double* ll_local);
 int bpm_begin_run(bpm_handle_t h, const bpm_run_opts_t* opts);
 /* n_gens iterations of the while loop of demc.py:79-140, entirely on the device. Asynchronous. */
 int bpm_step(bpm_handle_t h, int64_t n_gens);
-/* same, bracketed by HIP events on the sampler's stream; returns elapsed device time. */
-int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms);
+/* same, synchronous, timed on the device with two HIP events BOUND TO UPDATE-KERNEL DISPATCHES of the sampler's stream (no
+ * marker packets: an event-record pair alone costs ~17 us here, 7 % of a 20-generation window): elapsed_ms = end of the
+ * first update launch -> end of the last one, n_launches = the launches that interval covers (2 n_gens - 1 for the
+ * two-phase samplers).  Average launch period = elapsed_ms / n_launches. */
+int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms, int64_t* n_launches);
 /* same again with a HIP event pair around every update-kernel launch: summed kernel time and launch
  * count (bench.py prices the roofline with it). n_gens <= 4096. */
 int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);

@@ -44,6 +44,25 @@ def run(rank, world, port, out_dir, case):
         c = s.get_chain(s.n_chains - 1, 0)          # a chain owned by the last rank, fetched to rank 0
         if rank == 0:
             res["last_chain"] = c.chain
+        else:
+            assert c is None
+        # owner == collection rank: nobody communicates (demc.py:301-304); the other ranks get None and the next
+        # collective still pairs up on every rank
+        c0 = s.get_chain(0, 0)
+        assert (c0 is not None) == (rank == 0)
+        if rank == 0:
+            assert c0.global_id == 0
+        own_last = s.get_chain(s.n_chains - 1, world - 1)
+        assert (own_last is not None) == (rank == world - 1)
+        # every chain to every collection rank, in the same order on all ranks
+        for coll in range(world):
+            for c_id in range(s.n_chains):
+                ch = s.get_chain(c_id, coll)
+                assert (ch is not None) == (rank == coll), (c_id, coll, rank)
+                if ch is not None:
+                    assert ch.chain.shape == (s.am_chains[0].chain.shape[0], s.dim)
+        got = [ch for ch in s.iter_all_chains(0)]
+        assert len(got) == s.n_chains and all((g is not None) == (rank == 0) for g in got)
         np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (case, rank)), **res)
     finally:
         dist.barrier()
