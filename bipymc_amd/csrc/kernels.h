@@ -1269,7 +1269,6 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
     inv[(uint64_t)g * N + c] = k;
 }
 
-// Outlier-chain reset (Vrugt et al. 2009, DREAM; NOT in the reference -- extension).
 // Records of K consecutive generations in one launch, one thread per (generation, position in shuffle order):
 // everything of an update that depends only on (seed, generation, chain id) -- never on chain states -- so it can
 // be drawn ahead of time: the chain id at that position, its header block and its partner chains (dream.py:62-66;
@@ -1366,32 +1365,176 @@ __global__ __launch_bounds__(PLAN_LOCAL_THREADS) void plan_local_kernel(const ui
     if (tid == 0) count[g * 2u + grp] = s_running;
 }
 
-// omega_i = mean ln_like of chain i over the history rows [r0, rows).
-__global__ void omega_kernel(const double* llhist, uint32_t n_local, uint32_t r0, uint32_t rows, double* omega) {
+// ---------------------------------------------------------------------------------
+// DREAM outlier-chain reset (Vrugt et al. 2009; NOT in the reference -- extension), entirely on the device:
+//   outlier_omega_kernel   omega_i = mean ln_like of chain i over the last half of its history, this rank's chains
+//   [all-gather of the (omega | ln_like) blocks when world > 1]
+//   outlier_select_kernel  Q1 / Q3 order statistics of omega over all N chains (radix select), first maximum
+//   outlier_reset_kernel   chains with omega < Q1 - 2 IQR restart from the best chain's state
+// No host round trip: round 1 copied omega to the host, selected the quartiles there (4.6 ms per check at N = 262144)
+// and synchronised the stream three times per check.
+// OM layout: rank r's block at OM + r * 2 * n_local = [omega (n_local) | ln_like (n_local)].
+// ---------------------------------------------------------------------------------
+__global__ void outlier_omega_kernel(const double* llhist, const double* ll, uint32_t n_local, uint32_t r0, uint32_t rows, double* om_block) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
     double acc = 0.0;
-    for (uint32_t g = r0; g < rows; ++g) acc += llhist[(uint64_t)g * n_local + i];
-    omega[i] = acc / (double)(rows - r0);
-}
-// Every rank copies the best chain's state over each outlier chain in its replica of the state matrix;
-// the owner of an outlier also fixes its ln_like cache and the last history row (= current state).
-__global__ void outlier_reset_kernel(Layout L, uint32_t lo, const int32_t* ids, uint32_t n_out, uint32_t best, double* ll,
-                                     double ll_best, double* hist_last, double* llhist_last) {
-    const uint32_t o = blockIdx.x;
-    if (o >= n_out) return;
-    const uint32_t c = (uint32_t)ids[o];
-    const double* src = row_ptr(L, best);
-    double* dst = row_ptr(L, c);
-    const bool mine = c >= lo && c < lo + L.n_local;
-    for (uint32_t j = threadIdx.x; j < L.ld; j += blockDim.x) {
-        const double v = src[j];
-        dst[j] = v;
-        if (mine && hist_last) hist_last[(uint64_t)(c - lo) * L.ld + j] = v;
+    uint32_t cnt = 0;
+    for (uint32_t g = r0; g < rows; ++g) {          // rows whose ln_like is unknown (NaN: warm start with a host callback) do not count
+        const double v = llhist[(uint64_t)g * n_local + i];
+        if (v == v) { acc += v; ++cnt; }
     }
-    if (mine && threadIdx.x == 0) {
-        ll[c - lo] = ll_best;
-        if (llhist_last) llhist_last[c - lo] = ll_best;
+    om_block[i] = cnt ? acc / (double)cnt : acc / 0.0;
+    om_block[n_local + i] = ll[i];
+}
+
+__device__ __forceinline__ double om_at(const double* OM, uint32_t n_local, uint32_t e) {      // omega of global chain e
+    const uint32_t r = e / n_local;
+    return OM[(uint64_t)r * 2u * n_local + (e - r * n_local)];
+}
+// order-preserving map double -> uint64 (ascending)
+__device__ __forceinline__ unsigned long long f64_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+constexpr int SEL_THREADS = 1024;
+struct SelRanks { uint32_t k[4]; };      // 0-based order statistics: floor / ceil positions of the 25th and 75th percentile
+// blocks 0..3: sel[b] = the k[b]-th smallest omega (8 passes of an 8-bit radix select, LDS histogram, one workgroup each);
+// block 4: sel[4] = index of the FIRST maximum of omega (np.argmax), as a double
+__global__ __launch_bounds__(SEL_THREADS) void outlier_select_kernel(const double* OM, uint32_t n_local, uint32_t N, SelRanks R, double* sel) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t s_k;
+    __shared__ double s_v[SEL_THREADS];
+    __shared__ uint32_t s_i[SEL_THREADS];
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 4) {
+        double best = 0.0;
+        uint32_t bi = 0xFFFFFFFFu;
+        for (uint32_t e = tid; e < N; e += SEL_THREADS) {
+            const double v = om_at(OM, n_local, e);
+            if (bi == 0xFFFFFFFFu || v > best) { best = v; bi = e; }      // ascending e per thread: keeps the first maximum
+        }
+        s_v[tid] = best; s_i[tid] = bi;
+        __syncthreads();
+        for (uint32_t o = SEL_THREADS / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                const double vb = s_v[tid + o];
+                const uint32_t ib = s_i[tid + o];
+                const double va = s_v[tid];
+                const uint32_t ia = s_i[tid];
+                const bool take = ib != 0xFFFFFFFFu && (ia == 0xFFFFFFFFu || vb > va || (vb == va && ib < ia));
+                if (take) { s_v[tid] = vb; s_i[tid] = ib; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) sel[4] = (double)s_i[0];
+        return;
+    }
+    if (tid == 0) { s_prefix = 0ull; s_k = R.k[blockIdx.x]; }
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        for (uint32_t base = 0; base < N; base += SEL_THREADS) {       // uniform trip count: the ballots below need whole wavefronts
+            const uint32_t e = base + tid;
+            unsigned long long key = 0ull;
+            if (e < N) key = f64_key(om_at(OM, n_local, e));
+            bool todo = e < N && (key & himask) == prefix;
+            const uint32_t digit = (uint32_t)(key >> shift) & 0xFFu;
+            // LDS atomics of one wavefront on ONE address retire one lane at a time, and the leading bytes of a population's
+            // values are nearly all equal: up to four rounds of "first pending lane's digit, counted by a ballot" take the
+            // dominant digits out with one atomic each; what is left is spread over many bins
+#pragma unroll 1
+            for (int round = 0; round < 4; ++round) {
+                const unsigned long long pend = __ballot(todo);
+                if (pend == 0ull) break;
+                const int first = __ffsll((long long)pend) - 1;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
+                const unsigned long long same = __ballot(todo && digit == d0);
+                if ((int)(tid & (WAVE - 1)) == first) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+                if (digit == d0) todo = false;
+            }
+            if (todo) atomicAdd(&hist[digit], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t k = s_k, b = 0;
+            for (; b < 255u; ++b) {
+                if (k < hist[b]) break;
+                k -= hist[b];
+            }
+            s_k = k;
+            s_prefix = prefix | ((unsigned long long)b << shift);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) sel[blockIdx.x] = key_f64(s_prefix);
+}
+
+// np.percentile's linear interpolation between the order statistics a <= b at fraction t (NumPy's _lerp)
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {
+    const double d = b - a;
+    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+// One wavefront tests 64 chains (lane = chain); for each outlier among them (rare) the whole wavefront copies the best chain's
+// row into the replica -- every rank does, for all N chains -- and the chain's OWNER also fixes the ln_like cache, the last
+// history row (= current state) and the chain's Welford moments, rebuilt over its rows in history order: the very operations
+// the running update applied, so the chains that were not reset keep moments that equal a full rebuild bit for bit.
+__global__ __launch_bounds__(WAVE) void outlier_reset_kernel(Layout L, uint32_t N, uint32_t lo, const double* OM, const double* sel, double t1, double t3,
+                                                             double* ll, double* hist, double* llhist, uint32_t rows, double* w_mean, double* w_m2,
+                                                             unsigned long long* n_resets) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c0 = blockIdx.x * WAVE + lane;
+    const double q1 = np_lerp(sel[0], sel[1], t1), q3 = np_lerp(sel[2], sel[3], t3);
+    const double cut = q1 - 2.0 * (q3 - q1);
+    const uint32_t best = (uint32_t)sel[4];
+    const bool out = c0 < N && om_at(OM, L.n_local, c0) < cut;
+    unsigned long long m = __ballot(out);
+    if (m == 0ull) return;
+    const uint32_t rb = best / L.n_local;
+    const double ll_best = OM[(uint64_t)rb * 2u * L.n_local + L.n_local + (best - rb * L.n_local)];
+    const double* src = row_ptr(L, best);
+    while (m) {
+        const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+        m &= m - 1ull;
+        const uint32_t c = blockIdx.x * WAVE + b;
+        double* dst = row_ptr(L, c);
+        const bool mine = (c - lo) < L.n_local;
+        const uint32_t li = c - lo;
+        for (uint32_t j = lane; j < L.ld; j += WAVE) {
+            const double v = src[j];
+            dst[j] = v;
+            if (mine && hist) {
+                const uint64_t stride = (uint64_t)L.n_local * L.ld;
+                double* col = hist + (uint64_t)li * L.ld + j;
+                col[(uint64_t)(rows - 1) * stride] = v;
+                if (w_mean) {                                   // this chain's moments over its rows [0, rows), last row = v
+                    double mean = 0.0, m2 = 0.0;
+                    for (uint32_t g = 0; g < rows; ++g) {
+                        const double x = g + 1 == rows ? v : col[(uint64_t)g * stride];
+                        const double d1 = x - mean;
+                        mean = mean + d1 / (double)(g + 1);
+                        m2 = m2 + d1 * (x - mean);
+                    }
+                    w_mean[(uint64_t)li * L.ld + j] = mean;
+                    w_m2[(uint64_t)li * L.ld + j] = m2;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (mine) {
+                ll[li] = ll_best;
+                if (llhist) llhist[(uint64_t)(rows - 1) * L.n_local + li] = ll_best;
+            }
+            atomicAdd(n_resets, 1ull);
+        }
     }
 }
 

@@ -296,7 +296,9 @@ struct bpm_sampler {
     int64_t phase_a_updates = 0; // host-callback: local chains already updated in an open generation
     bool proposed = false;
     bool state_set = false;
-    int64_t n_outlier_resets = 0;
+    double* om = nullptr;        // outlier check: world x [omega (n_local) | ln_like (n_local)], all-gathered in place
+    double* sel = nullptr;       // outlier check: [0..3] order statistics around Q1 / Q3, [4] first argmax of omega
+    bool outlier_due = false;    // set by finish_generation, served by the group driver (all ranks take part)
     // per-generation cache (host-callback path keeps it between propose and commit)
     PhaseArgs cur_args[2];
     bool gen_adapt_on = false;
@@ -411,7 +413,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
-    void* ptrs[] = {s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->om, s->sel, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].plan_local, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].plan_local, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
@@ -518,10 +520,14 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipMemcpyAsync(s->cr_state, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
         HIPCKD(hipStreamSynchronize(s->stream));
     }
-    CKD(dev_alloc(&s->counters, 4));
+    CKD(dev_alloc(&s->counters, 8));      // [2] NaN ratios of this run; [4] outlier resets since creation
     CKD(dev_alloc(&s->acc_count, s->n_local));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
-    HIPCKD(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
+    HIPCKD(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
+    if (cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0) {
+        CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
+        CKD(dev_alloc(&s->sel, 8));
+    }
     // update records drawn ahead (plan_kernel) for the fused device kernels, while a launch is latency bound.  Measured
     // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
     // 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the shorter critical
@@ -891,71 +897,6 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     return 0;
 }
 
-// np.percentile(v, q) with the default linear interpolation (NumPy's _lerp).  Selection, not a sort: the two order
-// statistics around the quantile position by std::nth_element + the minimum of what lies above (v is permuted).
-// A full sort of cfg5's 262144 values cost ~20 ms per check, four times the 50 generations between two checks.
-static double percentile_select(std::vector<double>& v, double q) {
-    const double pos = q / 100.0 * (double)(v.size() - 1);
-    const size_t lo = (size_t)std::floor(pos);
-    const size_t hi = std::min(lo + 1, v.size() - 1);
-    std::nth_element(v.begin(), v.begin() + (ptrdiff_t)lo, v.end());
-    const double a = v[lo];
-    const double b = hi == lo ? a : *std::min_element(v.begin() + (ptrdiff_t)hi, v.end());
-    const double t = pos - (double)lo, d = b - a;
-    return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
-}
-
-// DREAM outlier-chain reset (Vrugt et al. 2009): chains whose mean ln_like over the last half of their
-// history lies below Q1 - 2 IQR (quartiles over all N chains) restart from the best chain's state.
-static int outlier_check(bpm_sampler* s) {
-    if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
-    const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
-    double* d_omega = nullptr;
-    CK(dev_alloc(&d_omega, (size_t)s->N));
-    double* mine = d_omega + (size_t)s->rank * s->n_local;
-    hipLaunchKernelGGL(omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->n_local, r0, rows, mine);
-    HIPCK(hipGetLastError());
-    if (s->comm) NCCLCK(g_rccl.AllGather(mine, d_omega, (size_t)s->n_local, ncclDouble, s->comm, s->stream));
-    std::vector<double> omega(s->N);
-    HIPCK(hipMemcpyAsync(omega.data(), d_omega, (size_t)s->N * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipStreamSynchronize(s->stream));
-    HIPCK(hipFree(d_omega));
-    std::vector<double> work(omega);
-    const double q1 = percentile_select(work, 25.0), q3 = percentile_select(work, 75.0);
-    const double cut = q1 - 2.0 * (q3 - q1);
-    uint32_t best = 0;
-    for (uint32_t i = 1; i < s->N; ++i) if (omega[i] > omega[best]) best = i;       // first maximum
-    std::vector<int32_t> ids;
-    for (uint32_t i = 0; i < s->N; ++i) if (omega[i] < cut) ids.push_back((int32_t)i);
-    if (ids.empty()) return 0;
-    // ln_like of the best chain's current state: its owner has it cached; every rank needs the value
-    double ll_best = 0.0;
-    {
-        double* d_ll = nullptr;
-        CK(dev_alloc(&d_ll, (size_t)s->world));
-        const uint32_t owner = best / s->n_local;
-        if (owner == s->rank) HIPCK(hipMemcpyAsync(d_ll + s->rank, s->ll + (best - s->lo), sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-        else HIPCK(hipMemsetAsync(d_ll + s->rank, 0, sizeof(double), s->stream));
-        if (s->comm) NCCLCK(g_rccl.AllGather(d_ll + s->rank, d_ll, 1, ncclDouble, s->comm, s->stream));
-        HIPCK(hipMemcpyAsync(&ll_best, d_ll + owner, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIPCK(hipStreamSynchronize(s->stream));
-        HIPCK(hipFree(d_ll));
-    }
-    int32_t* d_ids = nullptr;
-    CK(dev_alloc(&d_ids, ids.size()));
-    HIPCK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    double* hist_last = s->hist + (uint64_t)(s->hist_rows - 1) * s->n_local * s->ld;
-    double* llhist_last = s->llhist + (uint64_t)(s->hist_rows - 1) * s->n_local;
-    hipLaunchKernelGGL(outlier_reset_kernel, dim3((unsigned)ids.size()), dim3(64), 0, s->stream, s->L, s->lo, d_ids,
-                       (uint32_t)ids.size(), best, s->ll, ll_best, hist_last, llhist_last);
-    HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(s->stream));
-    HIPCK(hipFree(d_ids));
-    s->n_outlier_resets += (int64_t)ids.size();
-    s->w_rows = 0;       // the last history row of the reset chains changed: moments are rebuilt on demand
-    return 0;
-}
-
 static int finish_generation(bpm_sampler* s) {
     if (s->gen_adapt_on) {
         if (s->N <= 2 * ADAPT_SPAN) {
@@ -975,9 +916,8 @@ static int finish_generation(bpm_sampler* s) {
     s->rows_logical += 1;
     s->k_gen += 1;      // demc.py:134
     s->t_abs += 1;
-    if (s->cfg.algo == BPM_ALGO_DREAM && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen &&
-        s->k_gen % s->cfg.outlier_every == 0)
-        CK(outlier_check(s));
+    s->outlier_due = s->cfg.algo == BPM_ALGO_DREAM && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen &&
+                     s->k_gen % s->cfg.outlier_every == 0;
     return 0;
 }
 
@@ -1001,6 +941,57 @@ static bool local_serial(const Group& g) {
 
 static int group_sync(const Group& g) {
     for (int r = 0; r < g.R; ++r) HIPCK(hipStreamSynchronize(g.h[r]->stream));
+    return 0;
+}
+
+// DREAM outlier-chain reset (Vrugt et al. 2009; extension): chains whose mean ln_like over the last half of their history
+// lies below Q1 - 2 IQR (quartiles over all N chains, np.percentile's interpolation) restart from the best chain's state.
+// Everything stays on the device and on the samplers' streams: omega of the local chains, all-gather of the (omega | ln_like)
+// blocks (RCCL, or device copies in a local group), radix select of the four order statistics + first argmax, reset.
+static int group_outlier_check(const Group& g) {
+    bpm_sampler* s0 = g.h[0];
+    const uint32_t N = s0->N;
+    for (int r = 0; r < g.R; ++r) {
+        bpm_sampler* s = g.h[r];
+        s->outlier_due = false;
+        if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
+        const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
+        hipLaunchKernelGGL(outlier_omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->ll, s->n_local, r0, rows,
+                           s->om + (size_t)s->rank * 2 * s->n_local);
+        HIPCK(hipGetLastError());
+    }
+    if (g.rccl) {
+        if (s0->world > 1 || s0->comm)
+            NCCLCK(g_rccl.AllGather(s0->om + (size_t)s0->rank * 2 * s0->n_local, s0->om, (size_t)2 * s0->n_local, ncclDouble, s0->comm, s0->stream));
+    } else if (g.R > 1) {
+        CK(group_sync(g));
+        const size_t blk = (size_t)2 * s0->n_local;
+        for (int r = 0; r < g.R; ++r)
+            for (int o = 0; o < g.R; ++o)
+                if (o != r)
+                    HIPCK(hipMemcpyAsync(g.h[o]->om + (size_t)r * blk, g.h[r]->om + (size_t)r * blk, blk * sizeof(double), hipMemcpyDeviceToDevice,
+                                         g.h[r]->stream));
+        CK(group_sync(g));
+    }
+    // np.percentile(omega, [25, 75]): position q (N - 1) / 100, the two order statistics around it and the fraction between them
+    SelRanks R;
+    double tq[2];
+    for (int i = 0; i < 2; ++i) {
+        const double pos = (i == 0 ? 25.0 : 75.0) / 100.0 * (double)(N - 1);
+        const uint32_t lo = (uint32_t)std::floor(pos);
+        R.k[2 * i] = lo;
+        R.k[2 * i + 1] = std::min(lo + 1u, N - 1u);
+        tq[i] = pos - (double)lo;
+    }
+    for (int r = 0; r < g.R; ++r) {
+        bpm_sampler* s = g.h[r];
+        hipLaunchKernelGGL(outlier_select_kernel, dim3(5), dim3(SEL_THREADS), 0, s->stream, s->om, s->n_local, N, R, s->sel);
+        hipLaunchKernelGGL(outlier_reset_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, s->stream, s->L, N, s->lo, s->om, s->sel, tq[0], tq[1],
+                           s->ll, s->hist, s->llhist, (uint32_t)s->hist_rows, s->w_rows == s->rows_logical ? s->w_mean : (double*)nullptr,
+                           s->w_m2, s->counters + 4);
+        HIPCK(hipGetLastError());
+        if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
+    }
     return 0;
 }
 
@@ -1113,6 +1104,7 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
         }
     }
     for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
+    if (g.h[0]->outlier_due) CK(group_outlier_check(g));
     return 0;
 }
 
@@ -1263,7 +1255,6 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
         CK(check_handle(s));
         if (!s->local_group || (int)s->world != R || (int)s->rank != r) return fail("bpm_local_group_step: handles are not ranks 0..R-1 of one local group");
         if (!s->run_open) return fail("bpm_local_group_step: call bpm_begin_run on every rank first");
-        if (s->cfg.outlier_every > 0) return fail("bpm_local_group_step: outlier detection is not emulated");
         if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     }
     CK(set_device(handles[0]));
@@ -1363,6 +1354,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
         }
         HIPCK(hipGetLastError());
         CK(finish_generation(s));
+        if (s->outlier_due) { bpm_sampler* one[1] = {s}; CK(group_outlier_check(Group{one, 1, s->comm != nullptr})); }
     }
     HIPCK(hipStreamSynchronize(s->stream));
     double tot = 0.0;
@@ -1515,7 +1507,7 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
         CK(allgather_state(s));
         HIPCK(hipStreamSynchronize(s->stream));
         s->proposed = false;
-        return finish_generation(s);
+        return finish_generation(s);       // (synchronous DE-MC: never DREAM, no outlier check)
     }
     CK(allgather_state(s));
     HIPCK(hipStreamSynchronize(s->stream));
@@ -1526,6 +1518,7 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
     } else {
         s->phase = 0;
         CK(finish_generation(s));
+        if (s->outlier_due) { bpm_sampler* one[1] = {s}; CK(group_outlier_check(Group{one, 1, s->comm != nullptr})); }
     }
     return 0;
 }
@@ -1626,7 +1619,7 @@ extern "C" int bpm_get_stats(bpm_handle_t s, bpm_stats_t* out) {
     CK(check_handle(s));
     CK(set_device(s));
     if (!out) return fail("bpm_get_stats: null argument");
-    unsigned long long c[4];
+    unsigned long long c[8];
     double cr[3 * MAX_CR];
     std::vector<uint32_t> acc(s->n_local);
     HIPCK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
@@ -1644,7 +1637,7 @@ extern "C" int bpm_get_stats(bpm_handle_t s, bpm_stats_t* out) {
     out->k_gen = s->k_gen;
     out->t_abs = s->t_abs;
     out->history_rows = s->hist_rows;
-    out->n_outlier_resets = s->n_outlier_resets;
+    out->n_outlier_resets = (int64_t)c[4];
     out->n_cr = s->cfg.n_cr;
     for (int m = 0; m < MAX_CR; ++m) {
         out->p_cr[m] = cr[m];

@@ -459,9 +459,14 @@ class OracleSampler(object):
         mean ln_like over the last half of their history is below Q1 - 2 IQR restart from the best chain."""
         rows = len(self.ll_history)
         omega = np.zeros(self.n_local)
-        for g in range(rows // 2, rows):            # sequential accumulation, as the kernel does
-            omega = omega + self.ll_history[g]
-        omega = omega / float(rows - rows // 2)
+        cnt = np.zeros(self.n_local)
+        for g in range(rows // 2, rows):            # sequential accumulation, as the kernel does; rows of unknown ln_like (NaN) do not count
+            v = self.ll_history[g]
+            ok = ~np.isnan(v)
+            omega = np.where(ok, omega + np.where(ok, v, 0.0), omega)
+            cnt = cnt + ok
+        with np.errstate(divide="ignore", invalid="ignore"):
+            omega = omega / cnt
         ll_all = self.ll[self.lo:self.hi].copy()
         if self.world > 1:
             omega = self.allgather(omega.reshape(-1, 1)).reshape(-1)

@@ -595,3 +595,97 @@ def test_config4_shape_eight_ranks_equal_single_rank():
     assert sum(e.stats()["local_n_accepted"] for e in ranks) == st1["local_n_accepted"]
     for e in ranks:
         e.close()
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_outlier_reset_multi_rank_equals_single_rank(R):
+    """The outlier-chain reset with world_size > 1 -- omega of the local chains, all-gather of the (omega | ln_like) blocks,
+    quartiles / best chain / reset on every rank's replica -- emulated with R handles on one GPU: histories, p_cr and the
+    number of resets equal the single-rank run bit for bit (the reset also repairs the owner's last history row, ln_like
+    cache and Welford moments, which the following CR statistics depend on)."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import mixture_nd
+    m = mixture_nd.BimodeGauss_ND(8)
+    tid, tp, d = m._bpm_target_spec()
+    N, G = 64, 34
+    kw = dict(burnin_gen=30, n_cr_gen=3, outlier_every=5)
+    np.random.seed(12)
+    x0 = m.rvs(N)
+    x0[[3, 17, 40, 63]] = 30.0                      # parked in the far tail, on different ranks
+    one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=6, **kw)
+    one.set_state(x0)
+    one.begin_run()
+    one.step(G)
+    st1 = one.stats()
+    assert st1["n_outlier_resets"] >= 4
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=6, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run()
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    HR = np.concatenate([e.get_history() for e in ranks], axis=1)
+    assert np.array_equal(HR, one.get_history())
+    assert np.array_equal(np.concatenate([e.get_loglike_history() for e in ranks], axis=1), one.get_loglike_history())
+    for e in ranks:
+        st = e.stats()
+        assert np.array_equal(e.get_state(), one.get_state())
+        assert st["n_outlier_resets"] == st1["n_outlier_resets"]
+        np.testing.assert_array_equal(st["p_cr"], st1["p_cr"])
+        np.testing.assert_array_equal(st["delta_m"], st1["delta_m"])
+
+
+def test_config5_as_stated_full_size():
+    """BASELINE config 5 as it is written: DREAM, 8-D bimodal mixture, 262144 chains as 8 ranks of 32768, CR adaptation and
+    outlier-chain detection ON.  (a) the 8-rank world, emulated on one GPU, ends exactly where the single-rank run of
+    262144 chains ends (state, p_cr, resets, accept counts); (b) size-independent properties of that run: every parked
+    chain was reset, everybody sits in one of the two modes, mode weights and within-mode variances are the target's."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import mixture_nd
+    m = mixture_nd.BimodeGauss_ND(8)
+    tid, tp, d = m._bpm_target_spec()
+    R, N, G = 8, 262144, 260
+    kw = dict(burnin_gen=110, n_cr_gen=20, outlier_every=50)
+    np.random.seed(15)
+    x0 = m.rvs(N)
+    parked = np.arange(0, N, 4099)                  # 64 chains spread over all ranks, far in the tail
+    x0[parked] = 25.0
+    one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=31, **kw)
+    one.set_state(x0)
+    one.begin_run()
+    one.step(G)
+    X1, st1 = one.get_state(), one.stats()
+    assert st1["history_rows"] == G + 1 and st1["local_n_accepted"] + st1["local_n_rejected"] == N * G + 1
+    assert st1["n_outlier_resets"] >= parked.size
+    assert abs(st1["p_cr"].sum() - 1.0) < 1e-12 and np.all(st1["n_cr_updates"] > 0)
+    in0 = np.all(np.abs(X1) < 1.6, axis=1)
+    in2 = np.all(np.abs(X1 - 2.0) < 1.6, axis=1) & ~in0
+    assert in0.sum() + in2.sum() == N
+    assert abs(in0.mean() - 0.25) < 0.01
+    # (the reset rule moves low-density chains to the best chain ON PURPOSE -- it is a burn-in device and not reversible: with
+    # it the within-mode variance sits ~2 % low at the end of burn-in, in the oracle too, and relaxes afterwards; 3 % here)
+    assert abs(X1[in2].var(axis=0).mean() / 0.0625 - 1) < 0.03 and abs(X1[in0].var(axis=0).mean() / 0.0625 - 1) < 0.03
+    assert np.array_equal(one.get_history(G, G + 1)[0], X1)
+    one.close()
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=31, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run()
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    for e in ranks:
+        st = e.stats()
+        assert np.array_equal(e.get_state(), X1)
+        assert st["n_outlier_resets"] == st1["n_outlier_resets"]
+        np.testing.assert_array_equal(st["p_cr"], st1["p_cr"])
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == st1["local_n_accepted"]
+    for e in ranks:
+        e.close()

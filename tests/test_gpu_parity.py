@@ -439,3 +439,53 @@ def test_gpu_reproduces_committed_engine_fixture(golden_dir):
     e.begin_run(epsilon=1e-3); e.step(12)
     np.testing.assert_allclose(e.get_state(), g["sync_state"], rtol=1e-9, atol=1e-8)
     assert e.stats()["local_n_accepted"] == int(g["sync_acc"][0])
+
+
+# ------------------------------------------------------------------ host-callback path against the oracle itself
+@pytest.mark.parametrize("algo,d,N,kw", [
+    (R.ALGO_DREAM, 10, 16, dict(burnin_gen=6, n_cr_gen=2)),
+    (R.ALGO_DREAM, 7, 12, dict(burnin_gen=0, del_pairs=2)),
+    (R.ALGO_DREAM, 100, 64, dict(burnin_gen=5, n_cr_gen=1)),
+    (R.ALGO_DEMC, 2, 24, dict(p_snooker=0.3)),
+    (R.ALGO_DEMC, 3, 10, dict()),
+])
+def test_propose_commit_path_against_oracle(algo, d, N, kw):
+    """The propose / commit kernels (arbitrary Python ln_like_fn: samplers.py:36-43) compared with OracleSampler(ll_fn=...)
+    DIRECTLY -- not through the fused kernels: same callable on both sides, so every accept decision is bit-exact and the
+    state differs only by the proposal arithmetic's rounding (1e-12)."""
+    params = _gauss_params(d, rho=0.4)
+
+    def py_ll(theta):
+        return float(R.ll_gauss_equicorr(theta, params))
+
+    eng = _engine(algo=algo, n_chains=N, dim=d, target_id=R.TARGET_HOST, target_params=None, seed=77, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("del_pairs", "burnin_gen", "n_cr_gen", "p_snooker")}
+    ora = R.OracleSampler(algo, N, d, R.TARGET_HOST, None, 77, ll_fn=py_ll, **okw)
+    X0 = np.random.RandomState(4).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    eng.set_state(X0)
+    eng.set_loglike(np.array([py_ll(x) for x in X0]))
+    ora.set_state(X0)
+    eng.begin_run()
+    n_gens = 9
+    for g in range(n_gens):
+        ora.trace = []
+        for ph in range(2):
+            props, ids = eng.propose()
+            eng.commit(np.array([py_ll(p) for p in props]))
+        # the oracle's generation g of the same run (k restarts at 0 in run(): drive _generation directly)
+        ora._generation(g, 0.5, True, 1e-12 if algo == R.ALGO_DREAM else 1e-15, 1e-2, None)
+        tr = ora.trace[0]
+        acc_o = np.zeros(N, dtype=bool)
+        for phn in ("phase0", "phase1"):
+            acc_o[tr[phn]["ids"]] = tr[phn]["accepted"]
+        changed = np.any(eng.get_state() != (ora.history[-2] if g else X0), axis=1)
+        # a chain moved iff the oracle accepted it (proposals differ from the current state with probability 1)
+        assert np.array_equal(changed, acc_o), g
+        np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=1e-11, atol=1e-12)
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+    if algo == R.ALGO_DREAM:
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+        np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
+    np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-11, atol=1e-13)
