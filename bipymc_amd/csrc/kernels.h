@@ -1154,10 +1154,11 @@ __device__ __forceinline__ void cr_apply(const double* tot_d, const double* tot_
 }
 
 // part == nullptr: ONE workgroup walks all N slots and applies the update (N <= 16384: one or two rounds of loads).
-// part != nullptr: workgroup b sums the slots of chains [b, b + 1) * ADAPT_SPAN in one round and leaves its sums in
-// part[b] = (delta sums[MAX_CR] | counts[MAX_CR]); cr_final_kernel adds the workgroups' sums in index order and applies
-// the update.  (One workgroup for everything took 170 us per generation at N = 262144: a serial chain of 32 rounds.)
-__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state, double* part) {
+// part != nullptr: workgroup b sums the slots of chains [b, b + 1) * span and leaves its sums in
+// part[b] = (delta sums[MAX_CR] | counts[MAX_CR]); the last workgroup to finish adds the workgroups' sums in index order
+// and applies the update.  (One workgroup for everything took 170 us per generation at N = 262144: a serial chain of 32 rounds.)
+__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state, double* part, uint32_t* ticket,
+                                                                 uint32_t span) {
     __shared__ double s_d[ADAPT_THREADS / WAVE][MAX_CR], s_n[ADAPT_THREADS / WAVE][MAX_CR];
     __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
     const int tid = threadIdx.x;
@@ -1170,8 +1171,8 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
     constexpr int UNR = ADAPT_UNR;
-    const uint32_t lo = part ? blockIdx.x * ADAPT_SPAN : 0u;
-    const uint32_t hi = part ? (lo + ADAPT_SPAN < N ? lo + ADAPT_SPAN : N) : N;
+    const uint32_t lo = part ? blockIdx.x * span : 0u;            // span: chains per workgroup (a multiple of ADAPT_THREADS)
+    const uint32_t hi = part ? (lo + span < N ? lo + span : N) : N;
     for (uint32_t base = lo + tid; base < hi; base += ADAPT_THREADS * UNR) {
         int idx[UNR];
         double dl[UNR];
@@ -1202,31 +1203,48 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
         double d = 0.0, n = 0.0;
         for (int w = 0; w < ADAPT_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
         if (part) {
-            part[(uint64_t)blockIdx.x * 2 * MAX_CR + tid] = d;
-            part[(uint64_t)blockIdx.x * 2 * MAX_CR + MAX_CR + tid] = n;
+            __hip_atomic_store(&part[(uint64_t)blockIdx.x * 2 * MAX_CR + tid], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part[(uint64_t)blockIdx.x * 2 * MAX_CR + MAX_CR + tid], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket (the barrier does not wait for it)
         }
         tot_d[tid] = d; tot_n[tid] = n;
     }
     __syncthreads();
-    if (tid == 0 && !part) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
-}
-
-__global__ __launch_bounds__(WAVE) void cr_final_kernel(const double* part, uint32_t n_blocks, uint32_t n_cr, double* cr_state) {
-    __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
-    const int tid = threadIdx.x;
-    double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
+    if (!part) {
+        if (tid == 0) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
+        return;
+    }
+    // Several workgroups: the LAST one to finish (a ticket per launch; the partial sums are published with agent-scope
+    // release / acquire around it -- a few dozen workgroups, not thousands) adds the workgroups' sums IN INDEX ORDER and
+    // applies the update: the same arithmetic on every rank and in every run, and no second launch (cr_final_kernel cost
+    // another 11 us per burn-in generation at N = 262144).
+    __shared__ uint32_t s_last;
+    // (the sums travel in agent-scope atomic stores / loads, which go to the memory side; the barrier above has waited for
+    // them -- an agent-scope release FENCE here writes back the XCD's whole L2 once per workgroup: 29 us with 256 workgroups)
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // every workgroup's sums in ONE round of loads (thread = workgroup x slot, gridDim.x <= 64), then added in index order
+    __shared__ double s_part[64 * 2 * MAX_CR];
+    for (uint32_t i = tid; i < gridDim.x * 2u * MAX_CR; i += ADAPT_THREADS)
+        s_part[i] = __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (tid < (int)n_cr) {
         double d = 0.0, n = 0.0;
-        for (uint32_t b = 0; b < n_blocks; ++b) {           // workgroups in index order: the same sum on every rank, every run
-            d += part[(uint64_t)b * 2 * MAX_CR + tid];
-            n += part[(uint64_t)b * 2 * MAX_CR + MAX_CR + tid];
+        for (uint32_t b = 0; b < gridDim.x; ++b) {
+            d += s_part[b * 2u * MAX_CR + tid];
+            n += s_part[b * 2u * MAX_CR + MAX_CR + tid];
         }
         tot_d[tid] = d; tot_n[tid] = n;
     }
     __syncthreads();
-    if (tid == 0) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
+    if (tid == 0) {
+        cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // armed for the next generation
+    }
 }
 
 // Sparse exchange, receiving side: after the all-gather of the packed blocks PK[r] = [count | pad | ids[cap] | rows[cap][ld]]
@@ -1402,22 +1420,45 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 constexpr int SEL_THREADS = 1024;
+constexpr int SEL_UNR = 4;              // elements per thread and pass
 struct SelRanks { uint32_t k[4]; };      // 0-based order statistics: floor / ceil positions of the 25th and 75th percentile
-// blocks 0..3: sel[b] = the k[b]-th smallest omega (8 passes of an 8-bit radix select, LDS histogram, one workgroup each);
-// block 4: sel[4] = index of the FIRST maximum of omega (np.argmax), as a double
-__global__ __launch_bounds__(SEL_THREADS) void outlier_select_kernel(const double* OM, uint32_t n_local, uint32_t N, SelRanks R, double* sel) {
-    __shared__ uint32_t hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ uint32_t s_k;
+// Radix-select state in global memory: per target the key prefix fixed so far and the rank left inside it; the histogram of
+// the pass in flight ([4][256], zero between passes) and the launch's ticket follow it.
+struct SelState {
+    unsigned long long prefix[4];
+    uint32_t krem[4];
+    uint32_t ticket, pad;
+    uint32_t ghist[4 * 256];
+};
+// One PASS (8 bits of the 64-bit keys, most significant first) of the radix select of the four order statistics, as one launch
+// of N / (1024 * SEL_UNR) workgroups: each histograms its slice in LDS (targets whose prefixes still coincide share one
+// histogram) and adds the non-empty bins to the global histogram; the LAST workgroup to finish (ticket) picks every
+// target's bin, extends its prefix, and clears histogram and ticket for the next pass.  After pass 7 sel[b] is the value.
+// The extra workgroup blockIdx.x == gridDim.x - 1 of pass 0 finds the first maximum (np.argmax) -> sel[4].
+// (Round 2's first version ran all eight passes in ONE workgroup per target: 1.26 ms per check at N = 262144, five CUs busy.)
+__global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const double* OM, uint32_t n_local, uint32_t N, int pass, SelRanks R,
+                                                                         SelState* st, double* sel) {
+    __shared__ uint32_t hist[4][256];
+    __shared__ uint32_t s_last;
     __shared__ double s_v[SEL_THREADS];
     __shared__ uint32_t s_i[SEL_THREADS];
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x == 4) {
+    const uint32_t n_hist_blocks = pass == 0 ? gridDim.x - 1u : gridDim.x;
+    if (pass == 0 && blockIdx.x == gridDim.x - 1u) {
         double best = 0.0;
         uint32_t bi = 0xFFFFFFFFu;
-        for (uint32_t e = tid; e < N; e += SEL_THREADS) {
-            const double v = om_at(OM, n_local, e);
-            if (bi == 0xFFFFFFFFu || v > best) { best = v; bi = e; }      // ascending e per thread: keeps the first maximum
+        for (uint32_t e0 = 0; e0 < N; e0 += SEL_THREADS * 8u) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t e = e0 + (uint32_t)u * SEL_THREADS + tid;
+                v[u] = e < N ? om_at(OM, n_local, e) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t e = e0 + (uint32_t)u * SEL_THREADS + tid;
+                if (e < N && (bi == 0xFFFFFFFFu || v[u] > best)) { best = v[u]; bi = e; }      // ascending e per thread: keeps the first maximum
+            }
         }
         s_v[tid] = best; s_i[tid] = bi;
         __syncthreads();
@@ -1435,19 +1476,36 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_kernel(const doubl
         if (tid == 0) sel[4] = (double)s_i[0];
         return;
     }
-    if (tid == 0) { s_prefix = 0ull; s_k = R.k[blockIdx.x]; }
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix;
-        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-        for (uint32_t base = 0; base < N; base += SEL_THREADS) {       // uniform trip count: the ballots below need whole wavefronts
-            const uint32_t e = base + tid;
-            unsigned long long key = 0ull;
-            if (e < N) key = f64_key(om_at(OM, n_local, e));
-            bool todo = e < N && (key & himask) == prefix;
-            const uint32_t digit = (uint32_t)(key >> shift) & 0xFFu;
+    const int shift = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    unsigned long long prefix[4];
+    int grp[4];                       // target b counts in histogram grp[b] (the first target with the same prefix)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) prefix[b] = pass == 0 ? 0ull : st->prefix[b];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        grp[b] = b;
+#pragma unroll
+        for (int a = b - 1; a >= 0; --a) if (prefix[a] == prefix[b]) grp[b] = a;
+    }
+    for (uint32_t i = tid; i < 4u * 256u; i += SEL_THREADS) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (SEL_THREADS * SEL_UNR);
+    unsigned long long keys[SEL_UNR];
+#pragma unroll
+    for (int u = 0; u < SEL_UNR; ++u) {
+        const uint32_t e = base + (uint32_t)u * SEL_THREADS + tid;
+        keys[u] = e < N ? f64_key(om_at(OM, n_local, e)) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < SEL_UNR; ++u) {
+        const uint32_t e = base + (uint32_t)u * SEL_THREADS + tid;
+        const unsigned long long key = keys[u];
+        const uint32_t digit = (uint32_t)(key >> shift) & 0xFFu;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (grp[b] != b) continue;                                   // uniform: shares an earlier target's histogram
+            bool todo = e < N && (key & himask) == prefix[b];
             // LDS atomics of one wavefront on ONE address retire one lane at a time, and the leading bytes of a population's
             // values are nearly all equal: up to four rounds of "first pending lane's digit, counted by a ballot" take the
             // dominant digits out with one atomic each; what is left is spread over many bins
@@ -1458,24 +1516,66 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_kernel(const doubl
                 const int first = __ffsll((long long)pend) - 1;
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
                 const unsigned long long same = __ballot(todo && digit == d0);
-                if ((int)(tid & (WAVE - 1)) == first) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+                if ((int)(tid & (WAVE - 1)) == first) atomicAdd(&hist[b][d0], (uint32_t)__popcll(same));
                 if (digit == d0) todo = false;
             }
-            if (todo) atomicAdd(&hist[digit], 1u);
+            if (todo) atomicAdd(&hist[b][digit], 1u);
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t k = s_k, b = 0;
-            for (; b < 255u; ++b) {
-                if (k < hist[b]) break;
-                k -= hist[b];
-            }
-            s_k = k;
-            s_prefix = prefix | ((unsigned long long)b << shift);
-        }
-        __syncthreads();
     }
-    if (tid == 0) sel[blockIdx.x] = key_f64(s_prefix);
+    __syncthreads();
+    {   // non-empty bins to the global histogram (thread = bin, four histograms)
+        const uint32_t b = tid >> 8, bin = tid & 255u;
+        const uint32_t c = hist[b][bin];
+        if (c) __hip_atomic_fetch_add(&st->ghist[b * 256u + bin], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every wavefront waits for ITS atomics to be performed before the barrier: __syncthreads() alone is a workgroup-scope
+    // fence and leaves them in flight (seen: the ticket passed them, the last workgroup read an incomplete histogram)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {       // (agent-scope atomics are performed at the memory side: no cache-wide fence needed)
+        const uint32_t t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == n_hist_blocks - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup: every thread fetches its bin of all four global histograms; threads 0..3 then walk one target each
+    {
+        const uint32_t b = tid >> 8, bin = tid & 255u;
+        hist[b][bin] = __hip_atomic_load(&st->ghist[b * 256u + bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->ghist[b * 256u + bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < 4u * WAVE) {
+        // wavefront b walks target b's histogram: lane l owns bins 4l .. 4l+3, an inclusive scan over the lanes finds the lane,
+        // then the bin, that holds rank k (a serial walk of 256 LDS reads by one thread cost 10 us per pass)
+        const int b = (int)(tid / WAVE), lane = (int)(tid % WAVE);
+        uint32_t k = pass == 0 ? R.k[b] : st->krem[b];
+        int g = b;
+        unsigned long long pf = 0ull;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) if (a == b) { g = grp[a]; pf = prefix[a]; }
+        const uint32_t* h = hist[g];
+        const uint32_t c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+        uint32_t incl = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+        // first lane whose inclusive count exceeds k (k is below the total, so there is one; the last lane otherwise)
+        const unsigned long long over = __ballot(k < incl);
+        const int owner = over ? __ffsll((long long)over) - 1 : WAVE - 1;
+        if (lane == owner) {
+            uint32_t kk = k - excl, bin = 4u * (uint32_t)lane;
+            if (kk >= c0) { kk -= c0; ++bin; if (kk >= c1) { kk -= c1; ++bin; if (kk >= c2) { kk -= c2; ++bin; } } }
+            const unsigned long long np = pf | ((unsigned long long)bin << shift);
+            st->prefix[b] = np;
+            st->krem[b] = kk;
+            if (pass == 7) sel[b] = key_f64(np);
+        }
+    }
+    if (tid == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // np.percentile's linear interpolation between the order statistics a <= b at fraction t (NumPy's _lerp)
@@ -1517,11 +1617,19 @@ __global__ __launch_bounds__(WAVE) void outlier_reset_kernel(Layout L, uint32_t 
                 col[(uint64_t)(rows - 1) * stride] = v;
                 if (w_mean) {                                   // this chain's moments over its rows [0, rows), last row = v
                     double mean = 0.0, m2 = 0.0;
-                    for (uint32_t g = 0; g < rows; ++g) {
-                        const double x = g + 1 == rows ? v : col[(uint64_t)g * stride];
-                        const double d1 = x - mean;
-                        mean = mean + d1 / (double)(g + 1);
-                        m2 = m2 + d1 * (x - mean);
+                    constexpr int UNR = 8;                      // the loads of 8 rows in flight, then their 8 sequential updates
+                    for (uint32_t g0 = 0; g0 < rows; g0 += UNR) {
+                        double x[UNR];
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) x[u] = (g0 + u + 1 < rows) ? col[(uint64_t)(g0 + u) * stride] : v;
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            if (g0 + u < rows) {
+                                const double d1 = x[u] - mean;
+                                mean = mean + d1 / (double)(g0 + u + 1);
+                                m2 = m2 + d1 * (x[u] - mean);
+                            }
+                        }
                     }
                     w_mean[(uint64_t)li * L.ld + j] = mean;
                     w_m2[(uint64_t)li * L.ld + j] = m2;
@@ -1590,38 +1698,52 @@ __global__ __launch_bounds__(block_for(LPC)) void eval_ll_kernel(const double* X
 // over the flat history rows [m_lo, m_hi) of the (rows x ld) matrix H.  Deterministic two-stage
 // reduction: per-block partials, then a fixed-order sum over blocks.
 constexpr int MOM_THREADS = 256;
+constexpr int MOM_UNR = 8;              // independent 16-byte loads in flight per thread
+// A thread owns one coordinate PAIR (columns 2p, 2p + 1; ld is even, rows are 16-byte aligned) of every rpi-th row of its
+// block's slice: one 16-byte load per row, a row's ld / 2 loads contiguous across the threads (round 1 had 8-byte loads, one
+// column per thread, at most 1024 blocks: 3.2 TB/s on cfg2's 6.8 GB history).  Per-block partial sums, then
+// moments_final_kernel adds the blocks in a fixed order: deterministic for a given grid.
 __global__ __launch_bounds__(MOM_THREADS) void moments_partial_kernel(const double* H, uint64_t m_lo, uint64_t m_hi,
                                                                     uint32_t ld, const double* shift, double* part) {
-    __shared__ double s_a[MOM_THREADS], s_b[MOM_THREADS];
-    const uint32_t cpb = ld <= MOM_THREADS ? ld : MOM_THREADS;   // columns per pass
-    const uint32_t rpi = MOM_THREADS / cpb;                      // rows per iteration
+    __shared__ double s_a[2 * MOM_THREADS], s_b[2 * MOM_THREADS];
+    const uint32_t np = ld / 2u;                                  // pairs per row
+    const uint32_t ppp = np <= MOM_THREADS ? np : MOM_THREADS;   // pairs per pass over the columns
+    const uint32_t rpi = MOM_THREADS / ppp;                      // rows per iteration
     const uint64_t M = m_hi - m_lo;
     const uint64_t rpb = (M + gridDim.x - 1) / gridDim.x;
     const uint64_t b0 = m_lo + (uint64_t)blockIdx.x * rpb;
     const uint64_t b1 = b0 + rpb < m_hi ? b0 + rpb : m_hi;
-    for (uint32_t c0 = 0; c0 < ld; c0 += cpb) {
-        const uint32_t j = c0 + threadIdx.x % cpb, r = threadIdx.x / cpb;
-        double sa = 0.0, sb = 0.0;
-        if (r < rpi && j < ld) {
-            const double sh = shift[j];
-            constexpr int UNR = 8;                      // 8 independent row loads in flight per thread
-            for (uint64_t m = b0 + r; m < b1; m += (uint64_t)rpi * UNR) {
-                double v[UNR];
+    for (uint32_t p0 = 0; p0 < np; p0 += ppp) {
+        const uint32_t p = p0 + threadIdx.x % ppp, r = threadIdx.x / ppp;
+        double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0;
+        if (r < rpi && p < np) {
+            const double2 sh = reinterpret_cast<const double2*>(shift)[p];
+            for (uint64_t m = b0 + r; m < b1; m += (uint64_t)rpi * MOM_UNR) {
+                double2 v[MOM_UNR];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
+                for (int u = 0; u < MOM_UNR; ++u) {
                     const uint64_t mm = m + (uint64_t)u * rpi;
-                    v[u] = mm < b1 ? H[mm * ld + j] - sh : 0.0;
+                    v[u] = mm < b1 ? reinterpret_cast<const double2*>(H + mm * ld)[p] : sh;
                 }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) { sa += v[u]; sb += v[u] * v[u]; }
+                for (int u = 0; u < MOM_UNR; ++u) {
+                    const double d0 = v[u].x - sh.x, d1 = v[u].y - sh.y;
+                    sa0 += d0; sb0 += d0 * d0;
+                    sa1 += d1; sb1 += d1 * d1;
+                }
             }
         }
-        s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
+        s_a[2 * threadIdx.x] = sa0; s_a[2 * threadIdx.x + 1] = sa1;
+        s_b[2 * threadIdx.x] = sb0; s_b[2 * threadIdx.x + 1] = sb1;
         __syncthreads();
-        if (r == 0 && j < ld) {
-            for (uint32_t rr = 1; rr < rpi; ++rr) { sa += s_a[rr * cpb + threadIdx.x]; sb += s_b[rr * cpb + threadIdx.x]; }
-            part[((uint64_t)blockIdx.x * 2 + 0) * ld + j] = sa;
-            part[((uint64_t)blockIdx.x * 2 + 1) * ld + j] = sb;
+        if (r == 0 && p < np) {
+            for (uint32_t rr = 1; rr < rpi; ++rr) {              // the block's row slots in order
+                const uint32_t o = 2u * (rr * ppp + threadIdx.x);
+                sa0 += s_a[o]; sa1 += s_a[o + 1]; sb0 += s_b[o]; sb1 += s_b[o + 1];
+            }
+            double* pa = part + ((uint64_t)blockIdx.x * 2 + 0) * ld + 2u * p;
+            double* pb = part + ((uint64_t)blockIdx.x * 2 + 1) * ld + 2u * p;
+            pa[0] = sa0; pa[1] = sa1; pb[0] = sb0; pb[1] = sb1;
         }
         __syncthreads();
     }

@@ -298,6 +298,7 @@ struct bpm_sampler {
     bool state_set = false;
     double* om = nullptr;        // outlier check: world x [omega (n_local) | ln_like (n_local)], all-gathered in place
     double* sel = nullptr;       // outlier check: [0..3] order statistics around Q1 / Q3, [4] first argmax of omega
+    unsigned char* sel_state = nullptr;   // radix-select state between the passes (SelState)
     bool outlier_due = false;    // set by finish_generation, served by the group driver (all ranks take part)
     // per-generation cache (host-callback path keeps it between propose and commit)
     PhaseArgs cur_args[2];
@@ -413,7 +414,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
-    void* ptrs[] = {s->om, s->sel, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].plan_local, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].plan_local, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
@@ -527,6 +528,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0) {
         CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
         CKD(dev_alloc(&s->sel, 8));
+        CKD(dev_alloc(&s->sel_state, sizeof(SelState)));
+        HIPCKD(hipMemsetAsync(s->sel_state, 0, sizeof(SelState), s->stream));
     }
     // update records drawn ahead (plan_kernel) for the fused device kernels, while a launch is latency bound.  Measured
     // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
@@ -901,13 +904,17 @@ static int finish_generation(bpm_sampler* s) {
     if (s->gen_adapt_on) {
         if (s->N <= 2 * ADAPT_SPAN) {
             hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
-                               s->cr_state, (double*)nullptr);
-        } else {            // one round of loads per workgroup, then the workgroups' sums in index order
-            const uint32_t nb = (s->N + ADAPT_SPAN - 1) / ADAPT_SPAN;
-            if (!s->cr_part) CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR));
+                               s->cr_state, (double*)nullptr, (uint32_t*)nullptr, 0u);
+        } else {            // up to 64 workgroups (their tickets are same-address atomics: ~28 ns each), a few chains per thread; the last
+                            // workgroup to finish adds their sums in index order
+            uint32_t span = ((s->N + 63u) / 64u + ADAPT_THREADS - 1u) / ADAPT_THREADS * ADAPT_THREADS;
+            const uint32_t nb = (s->N + span - 1) / span;
+            if (!s->cr_part) {
+                CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR + 2));
+                HIPCK(hipMemsetAsync(s->cr_part, 0, ((size_t)nb * 2 * MAX_CR + 2) * sizeof(double), s->stream));    // (the ticket lives behind the sums)
+            }
             hipLaunchKernelGGL(cr_adapt_kernel, dim3(nb), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
-                               s->cr_state, s->cr_part);
-            hipLaunchKernelGGL(cr_final_kernel, dim3(1), dim3(WAVE), 0, s->stream, s->cr_part, nb, (uint32_t)s->cfg.n_cr, s->cr_state);
+                               s->cr_state, s->cr_part, reinterpret_cast<uint32_t*>(s->cr_part + (size_t)nb * 2 * MAX_CR), span);
         }
         HIPCK(hipGetLastError());
         s->w_rows += 1;
@@ -985,7 +992,10 @@ static int group_outlier_check(const Group& g) {
     }
     for (int r = 0; r < g.R; ++r) {
         bpm_sampler* s = g.h[r];
-        hipLaunchKernelGGL(outlier_select_kernel, dim3(5), dim3(SEL_THREADS), 0, s->stream, s->om, s->n_local, N, R, s->sel);
+        const uint32_t nblk = (N + SEL_THREADS * SEL_UNR - 1) / (SEL_THREADS * SEL_UNR);
+        for (int pass = 0; pass < 8; ++pass)      // (+ 1 workgroup in pass 0: the first maximum)
+            hipLaunchKernelGGL(outlier_select_pass_kernel, dim3(nblk + (pass == 0 ? 1u : 0u)), dim3(SEL_THREADS), 0, s->stream, s->om,
+                               s->n_local, N, pass, R, reinterpret_cast<SelState*>(s->sel_state), s->sel);
         hipLaunchKernelGGL(outlier_reset_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, s->stream, s->L, N, s->lo, s->om, s->sel, tq[0], tq[1],
                            s->ll, s->hist, s->llhist, (uint32_t)s->hist_rows, s->w_rows == s->rows_logical ? s->w_mean : (double*)nullptr,
                            s->w_m2, s->counters + 4);
@@ -1425,7 +1435,8 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
     HIPCK(hipMemcpyAsync(h.data() + 2 * s->ld, s->G, s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     *count = (int64_t)(m_hi > m_lo ? m_hi - m_lo : 0);
     if (m_hi > m_lo) {
-        const uint32_t nb = (uint32_t)std::min<uint64_t>(1024, (m_hi - m_lo + 63) / 64);
+        // enough blocks for ~8 per CU (each thread keeps MOM_UNR 16-byte loads in flight), at least 64 rows each
+        const uint32_t nb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2048, (m_hi - m_lo + 63) / 64));
         double* part = nullptr;
         double* out = nullptr;
         CK(dev_alloc(&part, (size_t)nb * 2 * s->ld));
