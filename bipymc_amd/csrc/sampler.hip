@@ -179,6 +179,8 @@ static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1
 static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
 template <int ALGO, int NP, int LPC, int DPL>
 static void launch_replay(const PhaseArgs& a, hipStream_t s) {
+    // (a workgroup per 64 positions that compacts the remote accepted chains in LDS and rebuilds only those -- 8192 wavefronts
+    // launched instead of 32768 -- measured no faster: 11.5 vs 11.3 us at 8 ranks, 6.9 vs 5.2 at 2; profiles/r02_replay_variants.txt)
     hipLaunchKernelGGL((phase_replay_kernel<ALGO, LPC, DPL, NP>), dim3(grid_for(a.n_upd, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
 // [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][shape]: the same pair-count variants as the update kernels (no target: no ln-like)
@@ -1759,6 +1761,42 @@ extern "C" int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uin
     for (int i = 0; i < n; ++i) {
         std::memcpy(out_mine + 4 * (size_t)i, h.data() + 8 * (size_t)i, 16);
         std::memcpy(out_rocrand + 4 * (size_t)i, h.data() + 8 * (size_t)i + 4, 16);
+    }
+    return 0;
+}
+
+// Diagnostic (tools/emulate_ranks.py): the update kernel and the replay kernel of this handle's LAST half generation launched
+// `reps` times back to back and timed with an event pair -- DESTRUCTIVE (the replica is advanced again and again), for timing
+// only.  Why: R ranks emulated on one GPU share ONE Infinity Cache, so kernel times read from a trace of the lock-step run are
+// those of a GPU whose cache holds eight replicas; re-launching one rank's kernels alone shows them with that rank's data warm.
+extern "C" int bpm_debug_time_kernels(bpm_handle_t s, int32_t reps, float* update_us, float* replay_us) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (reps < 1 || !update_us || !replay_us) return fail("bpm_debug_time_kernels: bad argument");
+    PhaseLaunch fn = pick_fused(s);
+    if (!fn) return fail("bpm_debug_time_kernels: device targets only");
+    const PhaseArgs& a = s->cur_args[1];
+    if (a.n_items == 0) return fail("bpm_debug_time_kernels: run at least one generation first");
+    HIPCK(hipStreamSynchronize(s->stream));
+    *update_us = 0.f; *replay_us = 0.f;
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && (!s->accbits_all || s->world == 1 || a.accbits == nullptr)) break;     // no replay exchange on this handle
+        PhaseArgs r = a;
+        if (which == 1) {
+            r.replay = 1u; r.accbits = nullptr; r.accbits_all = s->accbits_all;
+            r.trace_i32 = nullptr; r.trace_f64 = nullptr; r.trace_mask = nullptr; r.pack = nullptr; r.hist_row = nullptr; r.llhist_row = nullptr;
+            r.adapt_on = 0u;
+        }
+        const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
+        for (int i = 0; i < 3; ++i) { if (which == 0) fn(r, s->stream); else g_replay[v][s->shape.idx](r, s->stream); }
+        HIPCK(hipEventRecord(s->ev0, s->stream));
+        for (int i = 0; i < reps; ++i) { if (which == 0) fn(r, s->stream); else g_replay[v][s->shape.idx](r, s->stream); }
+        HIPCK(hipEventRecord(s->ev1, s->stream));
+        HIPCK(hipEventSynchronize(s->ev1));
+        HIPCK(hipGetLastError());
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        (which == 0 ? *update_us : *replay_us) = ms * 1e3f / (float)reps;
     }
     return 0;
 }

@@ -187,7 +187,10 @@ int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_
                         int64_t t_abs);
 
 /* test hooks (no sampler state involved) */
-int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* device target on n points */
+int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* diagnostic: the update and the replay kernel of the handle's last half generation re-launched `reps` times and timed
+ * (destructive; tools/emulate_ranks.py).  No reference counterpart. */
+int bpm_debug_time_kernels(bpm_handle_t h, int32_t reps, float* update_us, float* replay_us);
+/* device target on n points */
 int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uint32_t* out_mine, uint32_t* out_rocrand);
 /* per-generation host decisions (flip, shuffle order and its inverse) for generation t */
 int bpm_debug_perm(bpm_handle_t h, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,

@@ -40,3 +40,9 @@ dt = time.perf_counter() - t0
 acc = sum(e.stats()["local_n_accepted"] for e in ranks) / float(N * (G + 5))
 print("R=%d mode=%s N=%d: %d generations, %.1f us per generation for ALL ranks serialised on one GPU (acceptance %.3f); %s"
       % (R, mode, N, G, dt / G * 1e6, acc, ranks[0].exchange_stats()))
+
+# one rank's kernels alone, its own data warm in the Infinity Cache (the lock-step run above interleaves R replicas on ONE GPU):
+# the update kernel and the replay kernel of rank 0's last half generation, re-launched back to back (destructive)
+upd, rep = C.c_float(0.0), C.c_float(0.0)
+L.check(ranks[0].lib.bpm_debug_time_kernels(ranks[0]._h, 200, C.byref(upd), C.byref(rep)))
+print("rank 0 alone, 200 launches each: update kernel %.2f us, replay kernel %.2f us per half generation" % (upd.value, rep.value))
