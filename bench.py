@@ -184,8 +184,12 @@ def main():
     eng.step(BURNIN_GEN)
     fence()
     burn_s = time.perf_counter() - t0
-    # ---- warm-up
-    eng.step(args.warmup)
+    # ---- warm-up: W generations, the last of them through the same timed entry point as the timed region (the first
+    # event-bound dispatch of a process sets up profiling signals: 10-30 us of host time, once)
+    if args.warmup > 1:
+        eng.step(args.warmup - 1)
+    if args.warmup > 0:
+        eng.step_timed(1)
     fence()
     # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two HIP events
     # bound to the first and the last update-kernel dispatch of the same K generations on the sampler's own stream

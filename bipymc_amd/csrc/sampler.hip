@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,25 @@ static int fail(const std::string& m) {
         int _r = (expr);         \
         if (_r != 0) return _r;  \
     } while (0)
+
+// Wait for a stream by POLLING it (up to spin_ms, then a blocking wait).  hipStreamSynchronize parks the calling thread; on
+// this class of host the core then drops to its base clock and the launch calls that follow take ~4.7 us instead of ~2.4 us
+// for the first few hundred microseconds -- longer than the 6 us the GPU needs per update kernel, so a short bpm_step call
+// issued right after a wait ran HOST-paced (profiles/r02_host_launch_pacing.txt).  A polling wait keeps the core clocked up.
+static int wait_stream(hipStream_t st, double spin_ms = 2000.0) {
+    static const bool no_spin = getenv("BPM_NO_SPIN_WAIT") != nullptr;
+    if (!no_spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms) break;
+        }
+    }
+    HIPCK(hipStreamSynchronize(st));
+    return 0;
+}
 
 // ---- RCCL, loaded on demand (single-GPU use needs no communicator library) -------
 struct Rccl {
@@ -390,6 +410,12 @@ static int reset_history(bpm_sampler* s) {
     return 0;
 }
 
+// BPM_HOST_TIMING=1 (diagnostic): host nanoseconds spent preparing generations and inside the launch calls, printed by bpm_destroy
+static bool g_host_timing = getenv("BPM_HOST_TIMING") != nullptr;
+static long long g_ns_prepare = 0, g_ns_launch = 0, g_n_launch = 0;
+static std::vector<long long> g_launch_log;       // (start, end) of every launch call of the current bpm_step_timed
+static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
 extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
 extern "C" int bpm_device_count(int32_t* out) {
@@ -411,6 +437,11 @@ extern "C" int bpm_get_unique_id(char out[BPM_UID_BYTES]) {
 
 extern "C" int bpm_destroy(bpm_handle_t s) {
     if (!s) return 0;
+    if (g_host_timing && g_n_launch > 0) {
+        fprintf(stderr, "[bpm host timing] %lld launches: %.2f us per launch call, %.2f us per generation in prepare_generation\n", g_n_launch,
+                g_ns_launch * 1e-3 / g_n_launch, g_ns_prepare * 2e-3 / g_n_launch);
+        g_ns_prepare = g_ns_launch = g_n_launch = 0;
+    }
     (void)hipSetDevice(s->cfg.device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->aux) (void)hipStreamSynchronize(s->aux);
@@ -1083,11 +1114,13 @@ static int exchange_replay(const Group& g, int ph) {
 
 // xmode: how the half generations' updates reach the other ranks: 0 dense all-gather, 1 accepted rows, 2 accept bytes + replay
 static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLaunch fn) {
+    const long long tp0 = g_host_timing ? now_ns() : 0;
     for (int r = 0; r < g.R; ++r) {
         g.h[r]->sparse_active = xmode == 1;
         g.h[r]->replay_active = xmode == 2;
         CK(prepare_generation(g.h[r], n_ahead));
     }
+    if (g_host_timing) g_ns_prepare += now_ns() - tp0;
     if (g.h[0]->cfg.algo == BPM_ALGO_DEMC_SYNC) {
         for (int r = 0; r < g.R; ++r) {
             bpm_sampler* s = g.h[r];
@@ -1107,7 +1140,9 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
                     } else if (s->timed_last_gen == s->t_abs && (ph == 1 || s->cur_args[1].n_items == 0)) {
                         g_stop_event = s->ev1; s->timed_l1 = g_timed_launches;
                     }
+                    const long long tl0 = g_host_timing ? now_ns() : 0;
                     fn(s->cur_args[ph], s->stream);
+                    if (g_host_timing) { const long long tl1 = now_ns(); g_ns_launch += tl1 - tl0; ++g_n_launch; if (s->timed_last_gen >= 0) { g_launch_log.push_back(tl0); g_launch_log.push_back(tl1); } }
                 }
                 if (local_serial(g)) HIPCK(hipStreamSynchronize(g.h[r]->stream));
             }
@@ -1130,8 +1165,9 @@ constexpr int64_t GRAPH_MIN_GENS = 4;
 static int graph_chunk(bpm_sampler* s, int64_t n_left, PhaseLaunch fn, int64_t* done_gens) {
     *done_gens = 0;
     CK(ensure_perm_table(s, s->t_abs, n_left));                       // table / record kernels run outside the capture
-    const int64_t K = std::min<int64_t>(n_left, s->tab_t0 + s->tab_K - s->t_abs);
-    if (K < GRAPH_MIN_GENS) return 0;
+    static const int64_t chunk_cap = getenv("BPM_GRAPH_CHUNK") ? std::max(1, atoi(getenv("BPM_GRAPH_CHUNK"))) : PERM_CHUNK;
+    const int64_t K = std::min<int64_t>(std::min<int64_t>(n_left, chunk_cap), s->tab_t0 + s->tab_K - s->t_abs);
+    if (K < std::min<int64_t>(GRAPH_MIN_GENS, chunk_cap)) return 0;
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + K));  // (a reallocation cannot be captured)
     hipGraph_t graph = nullptr;
     HIPCK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -1323,12 +1359,24 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
     s->timed_want_first = n_gens > 0;
     s->timed_last_gen = n_gens > 0 ? s->t_abs + n_gens - 1 : -1;
     s->timed_l0 = s->timed_l1 = -1;
+    g_launch_log.clear();
+    const long long tt0 = g_host_timing ? now_ns() : 0;
+    static const bool graph_mode = getenv("BPM_GRAPH") != nullptr;      // (graph replay: the launches are not ours to tag -- a classic event pair)
+    if (graph_mode && n_gens > 0) HIPCK(hipEventRecord(s->ev0, s->stream));
     const int rc = bpm_step(s, n_gens);
+    if (graph_mode && n_gens > 0 && rc == 0) { HIPCK(hipEventRecord(s->ev1, s->stream)); s->timed_l0 = 0; s->timed_l1 = 2 * n_gens; }
     s->timed_want_first = false;
     s->timed_last_gen = -1;
     g_stop_event = nullptr;
     CK(rc);
-    HIPCK(hipStreamSynchronize(s->stream));
+    CK(wait_stream(s->stream));
+    if (g_host_timing && !g_launch_log.empty() && g_launch_log.size() <= 400) {
+        const long long tt1 = now_ns();
+        fprintf(stderr, "[bpm host timing] bpm_step_timed(%lld): entry -> drained %.1f us; launch calls (start offset us : duration us):", (long long)n_gens, (tt1 - tt0) * 1e-3);
+        for (size_t i = 0; i + 1 < g_launch_log.size(); i += 2)
+            fprintf(stderr, " %.1f:%.1f", (g_launch_log[i] - tt0) * 1e-3, (g_launch_log[i + 1] - g_launch_log[i]) * 1e-3);
+        fprintf(stderr, "\n");
+    }
     if (s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
         float ms = 0.f;
         HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -1461,8 +1509,7 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
 extern "C" int bpm_synchronize(bpm_handle_t s) {
     CK(check_handle(s));
     CK(set_device(s));
-    HIPCK(hipStreamSynchronize(s->stream));
-    return 0;
+    return wait_stream(s->stream);
 }
 
 extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, int32_t* n_out) {

@@ -1,0 +1,41 @@
+#!/bin/bash
+# The round's measurement set for bench.py (run on the GPU box: gpurun -- 'bash tools/profile_bench.sh r02'):
+#   the driver's invocation un-profiled (x3) and the default invocation, then rocprofv3 passes of the driver's invocation:
+#   kernel trace + stats, FETCH_SIZE, WRITE_SIZE, SQ counters (separate passes, as MI355X_MICROARCH.md prescribes).
+# Summaries land in profiles/<tag>_*; the rocpd databases stay in gpurun_out/.
+set -u
+TAG=${1:-r02}
+R=$PWD; O=$R/gpurun_out/prof_$TAG; P=$R/profiles; mkdir -p $O
+ARGS="--steps 20 --warmup 5"
+for i in 1 2 3; do python bench.py $ARGS 2>/dev/null | tail -1 >> $O/bench_driver.jsonl; done
+python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
+cd $R
+K="phase_fused_kernel<1, 1, 64, 2, 3, 1>"
+python tools/rocpd_summary.py stats $(find $O/kt -name "*.db" | head -1) > $P/${TAG}_kernel_stats_bench_driver.csv
+{
+  echo "# rocprofv3 --pmc passes of: python bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0   (kernel $K, the timed + untimed steady-state launches)"
+  python tools/rocpd_summary.py pmc $(find $O/f -name "*.db" | head -1) FETCH_SIZE "$K" 40
+  python tools/rocpd_summary.py pmc $(find $O/w -name "*.db" | head -1) WRITE_SIZE "$K" 40
+  for k in SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY; do
+    python tools/rocpd_summary.py pmc $(find $O/sq -name "*.db" | head -1) $k "$K" 40
+  done
+} > $P/${TAG}_pmc_bench_driver.txt
+cp $O/bench_driver.jsonl $P/${TAG}_bench_lines_driver_invocation.jsonl
+cp $O/bench_default.jsonl $P/${TAG}_bench_line_default.json
+# HBM bytes per launch for bench.py's roofline.traffic: FETCH_SIZE (KB) x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE (KB)
+python - <<PY
+import json, re
+t = open("$P/${TAG}_pmc_bench_driver.txt").read()
+f = float(re.search(r"FETCH_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
+w = float(re.search(r"WRITE_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
+json.dump({"hbm_bytes_per_launch": (2 * f + w) * 1024.0, "fetch_size_kb_uncorrected": f, "write_size_kb": w,
+           "source": "profiles/${TAG}_pmc_bench_driver.txt", "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section)"},
+          open("$P/traffic_cfg2.json", "w"), indent=1)
+PY
+find $O -name "*.db" -size +20M -delete
+cat $P/${TAG}_bench_lines_driver_invocation.jsonl | cut -c1-250; cut -c1-250 $P/${TAG}_bench_line_default.json; head -5 $P/${TAG}_kernel_stats_bench_driver.csv | cut -c1-200; cat $P/${TAG}_pmc_bench_driver.txt; cat $P/traffic_cfg2.json
