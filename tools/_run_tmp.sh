@@ -1,2 +1,5 @@
-for c in 2 4 8 64; do echo "== BPM_GRAPH=1 chunk $c"; BPM_GRAPH=1 BPM_GRAPH_CHUNK=$c python tools/window_anatomy.py 5 2>&1 | grep -v amdgpu | grep -A12 "^K "; done
-echo "== stream launches"; python tools/window_anatomy.py 5 2>&1 | grep -v amdgpu | grep -A12 "^K "
+O=gpurun_out/r2o; mkdir -p $O
+python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -4 $O/gpu_tests.log
+python tools/profile_config.py cfg3 400 2>&1 | grep -v amdgpu
+BPM_DEMC_LPC1=1 python tools/profile_config.py cfg3 400 2>&1 | grep -v amdgpu | sed "s/^/LPC1 /"
+BPM_FORCE_MODE1=1 python tools/profile_config.py cfg3 400 2>&1 | grep -v amdgpu | sed "s/^/MODE1 /"
