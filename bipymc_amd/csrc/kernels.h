@@ -89,6 +89,7 @@ __device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
 }
 
 constexpr int PLAN_WORDS = 16;    // chain id | header block (4 words) | up to 10 partner ids | pad
+constexpr int MAX_SEG = 16;       // ranks the owner-sorted record table serves (more: records by position, a wavefront per position replays)
 struct PhaseArgs {
     Layout L;
     double* ll;            // [n_local] cached ln_like of the local chains (samplers.py:330 re-evaluates it)
@@ -125,6 +126,14 @@ struct PhaseArgs {
     uint8_t* accbits;           // this rank's [n_local] accept bytes, written by the update kernel (or nullptr)
     const uint8_t* accbits_all; // replay kernel: the gathered [N] bytes, by global chain id
     uint32_t replay;            // 1 in phase_replay_kernel: the chain is remote -- nothing indexed by (chain - lo) may be touched
+    // world > 1 with update records SORTED BY OWNER (plan_slot_kernel): a half generation's records are stored rank segment by rank
+    // segment, positions in order inside a segment; rank r's k-th update of the half generation is record seg_off[r] + k of
+    // `rec_sorted`, and its accept byte is byte k of rank r's block of the gathered bytes (acc_by_item) -- so a replay wavefront
+    // finds the byte and the record of "rank r's k-th update" at addresses it can compute: ONE round trip decides whether it works
+    const uint32_t* rec_sorted; // the half generation's sorted records (replay kernel), or nullptr
+    uint32_t seg_off[MAX_SEG + 1];
+    uint32_t n_seg, seg_me;     // number of ranks, this rank
+    uint32_t acc_by_item;       // accept bytes indexed by the owner's item number (sorted records) instead of its local chain index
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
@@ -301,6 +310,7 @@ struct Work {
     double log_corr;   // snooker Jacobian term
     double gamma;
     uint32_t acc_hi, acc_lo;   // words of the accept uniform
+    uint32_t item;             // work-item number of this update (index of its accept byte when acc_by_item)
     double ll_cur;             // cached ln_like of the current state, fetched early
     uint32_t acc_prev;         // this chain's accept counter, fetched early
     double w_mean[DPL], w_m2[DPL];   // burn-in only: Welford moments of this chain's own history, fetched early
@@ -803,7 +813,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     if (q == 0) {
         if (accepted) a.acc_count[li] = wk.acc_prev + 1u;
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
-        if (a.accbits) a.accbits[li] = accepted ? (uint8_t)1 : (uint8_t)0;
+        if (a.accbits) a.accbits[a.acc_by_item ? wk.item : li] = accepted ? (uint8_t)1 : (uint8_t)0;
     }
     double nv[DPL];
 #pragma unroll
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
         a_hot = a_in;
         a_hot.mode = 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
         a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
-        if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; }
+        if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; a_hot.acc_by_item = 0u; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
         if (NOPLAN) { a_hot.plan = nullptr; a_hot.rec_tab = nullptr; }
     }
@@ -990,6 +1000,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
+    wk.item = w;
 #ifdef BPM_STAMPS
     bpm_stamp[1] = 0; BPM_STAMP(1);
     make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp);
@@ -1053,6 +1064,42 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const Phas
     if (active) store_row<LPC, DPL>(row_ptr(a.L, c), q, a.L.ld, wk.p);
 }
 
+// Replay with owner-sorted records (one wavefront per chain): one work item per update of the OTHER ranks (the host knows every
+// rank's count).  Item (r, k) = rank r's k-th update, its record at segment offset + k, its accept byte at byte k of rank r's block:
+// both sit at addresses the wavefront computes from the argument block, both loads leave together: a wavefront
+// whose update was rejected is gone after ONE round trip (round 1: record -> chain id -> accept byte, two), an accepted one has the
+// record's partner ids when it learns so.  11.3 -> x us per half generation at 8 ranks (profiles/r02_replay_variants.txt).
+#ifndef BPM_REPLAY_WG
+#define BPM_REPLAY_WG 256
+#endif
+constexpr int REPLAY_WG = BPM_REPLAY_WG;     // 4 independent wavefronts per workgroup: the kernel is bound by the DISPATCH of mostly idle workgroups
+                                   // (~0.35 ns each: 32768 one-wavefront workgroups = 11 us, what round 1's replay kernel measured)
+template <int ALGO, int DPL, int NP>
+__global__ __launch_bounds__(REPLAY_WG) void phase_replay_sorted_kernel(const PhaseArgs a_in) {
+    constexpr int LPC = WAVE;
+    PhaseArgs a_rep = a_in;
+    a_rep.replay = 1u; a_rep.adapt_on = 0u; a_rep.trace_i32 = nullptr; a_rep.trace_f64 = nullptr; a_rep.trace_mask = nullptr;
+    a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u; a_rep.accbits = nullptr;
+    const PhaseArgs& a = a_rep;
+    __shared__ uint32_t s_part[(REPLAY_WG / WAVE) * MAX_PARTNERS];
+    const int lane = threadIdx.x % WAVE, wv = threadIdx.x / WAVE;
+    // grid (largest count of another rank / 4, ranks): wavefront wv of block (b, r) = rank r's (4 b + wv)-th update.  The two segment offsets come out of the
+    // argument block by r (a scalar load with a register offset); a search through all offsets cost every wavefront ~150 scalar
+    // instructions, and most wavefronts do nothing else (15.1 us per half generation at 8 ranks, against 11.3 for round 1's kernel)
+    const uint32_t r = blockIdx.y, k = blockIdx.x * (REPLAY_WG / WAVE) + (uint32_t)__builtin_amdgcn_readfirstlane(wv);
+    const uint32_t lo = a_in.seg_off[r], hi = a_in.seg_off[r + 1];
+    if (r == a_in.seg_me || k >= hi - lo) return;                  // own segment: rows are in place
+    const uint32_t e = lo + k;
+    const uint32_t* rec = a.rec_sorted + (uint32_t)(e * PLAN_WORDS);
+    const uint32_t acc = a.accbits_all[(uint64_t)r * a.L.n_local + k];     // rank r's k-th update of this half generation
+    uint32_t c = rec[0];
+    if (acc == 0u) return;
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    Work<DPL> wk;
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, true, lane, wv, s_part, wk, rec);
+    store_row<LPC, DPL>(row_ptr(a.L, c), lane, a.L.ld, wk.p);
+}
+
 // Host-callback ln_like_fn: proposals out ...
 template <int ALGO, int LPC, int DPL>
 __global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const PhaseArgs a) {
@@ -1104,7 +1151,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
-    wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0;
+    wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0; wk.item = w;
     // finish_update rewrites the CR slots: carry the values written by the propose kernel
     if (ALGO == ALGO_DREAM && active) {
         wk.delta = *delta_ptr(a.L, c);
@@ -1296,7 +1343,7 @@ struct PlanParams {
     uint64_t seed, t0;
     uint32_t n_gens, N, np, snooker;     // np pairs (<= 5); snooker: also the three snooker partners (DE-MC, pools of >= 3)
 };
-__global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan) {
+__global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan, const uint32_t* sidx) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)P.n_gens * P.N) return;
     const uint32_t g = (uint32_t)(e / P.N), pos = (uint32_t)(e % P.N);
@@ -1329,58 +1376,72 @@ __global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* p
         r[8] = tg[pool_off + i1];
         r[9] = tg[pool_off + i2];
     }
-    uint4* out = reinterpret_cast<uint4*>(plan + e * PLAN_WORDS);
+    // where the record goes: by position, or (world > 1) to its slot in the owner-sorted order of its generation
+    const uint64_t oe = sidx ? (uint64_t)g * P.N + sidx[e] : e;
+    uint4* out = reinterpret_cast<uint4*>(plan + oe * PLAN_WORDS);
 #pragma unroll
     for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
-// A rank's own records of K generations, compacted: block (group, generation) walks the positions of that group in
-// order and copies the records whose chain lives on this rank to local[(g * 2 + group) * n_local + k], k counting up;
-// count[g * 2 + group] = how many.  The update kernel of a multi-GPU rank then runs exactly like the single-GPU one
-// (item k -> record k, no idle items, no position lookup); the host reads the counts once per table window to size the
-// launches.  Fixed-order block scan: the same list on every run.
+// Owner-sorted order of the update records (world > 1): block (group, generation) walks the group's positions in order and gives
+// each one its slot in a STABLE PARTITION BY OWNER RANK (owner = chain id / n_local): sidx[g * N + pos] = group offset + (records of
+// lower ranks) + (earlier positions of the same rank); count[(g * 2 + group) * n_rank + r] = how many updates rank r has in that half
+// generation.  plan_kernel then writes every record straight to its slot.  Rank r's updates of a half generation are then a
+// contiguous run of records (its own update kernel's work list: item k -> record k of the run, no idle items) and "rank r's k-th
+// update" names the same chain on every rank (what the replay kernel and the accept bytes are indexed by).  Fixed-order scans: the
+// same table on every rank and in every run.  The host reads the counts once per window, one window ahead.
 constexpr int PLAN_LOCAL_THREADS = 1024;
-__global__ __launch_bounds__(PLAN_LOCAL_THREADS) void plan_local_kernel(const uint32_t* plan, uint32_t N, uint32_t lo, uint32_t n_local,
-                                                                        uint32_t* local, uint32_t* count) {
-    __shared__ uint32_t s_wave[PLAN_LOCAL_THREADS / WAVE];
-    __shared__ uint32_t s_running;
+__global__ __launch_bounds__(PLAN_LOCAL_THREADS) void plan_slot_kernel(const uint32_t* tab, uint32_t N, uint32_t n_local, uint32_t n_rank,
+                                                                       uint32_t* sidx, uint32_t* count) {
+    __shared__ uint32_t s_wave[PLAN_LOCAL_THREADS / WAVE][MAX_SEG];
+    __shared__ uint32_t s_base[MAX_SEG], s_run[MAX_SEG];
     const uint32_t grp = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const uint32_t lane = tid & (WAVE - 1), wv = tid / WAVE;
     const uint32_t n_first = (N + 1u) / 2u;
     const uint32_t off = grp ? n_first : 0u, n = grp ? N - n_first : n_first;
-    const uint4* src = reinterpret_cast<const uint4*>(plan + (uint64_t)g * N * PLAN_WORDS);
-    uint4* dst = reinterpret_cast<uint4*>(local + ((uint64_t)g * 2 + grp) * n_local * PLAN_WORDS);
-    if (tid == 0) s_running = 0u;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n; t0 += PLAN_LOCAL_THREADS) {
-        const uint32_t i = t0 + tid;
-        const bool valid = i < n;
-        uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
-        if (valid) r0 = src[(uint64_t)(off + i) * (PLAN_WORDS / 4)];
-        const bool mine = valid && (r0.x - lo) < n_local;                    // word 0 of a record = the chain id
-        const unsigned long long b = __ballot(mine);
-        const uint32_t lane = tid & (WAVE - 1), wv = tid / WAVE;
-        const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
+    const uint32_t* tg = tab + (uint64_t)g * N + off;
+    const uint32_t magic = (uint32_t)((1ull << 32) / n_local) + 1u;
+    for (int pass = 0; pass < 2; ++pass) {                         // pass 0 counts per rank, pass 1 assigns the slots
+        if (tid < MAX_SEG) s_run[tid] = 0u;
         __syncthreads();
-        uint32_t wave_off = 0, total = 0;
-        for (uint32_t k = 0; k < PLAN_LOCAL_THREADS / WAVE; ++k) {
-            const uint32_t v = s_wave[k];
-            if (k < wv) wave_off += v;
-            total += v;
+        for (uint32_t t0 = 0; t0 < n; t0 += PLAN_LOCAL_THREADS) {
+            const uint32_t i = t0 + tid;
+            const bool valid = i < n;
+            uint32_t r = 0xFFFFFFFFu;
+            if (valid) {
+                const uint32_t c = tg[i];
+                r = __umulhi(c, magic);
+                r -= (r * n_local > c) ? 1u : 0u;
+            }
+            uint32_t before = 0;
+            for (uint32_t q = 0; q < n_rank; ++q) {
+                const unsigned long long b = __ballot(r == q);
+                if (r == q) before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wave[wv][q] = (uint32_t)__popcll(b);
+            }
+            __syncthreads();
+            if (pass == 1 && valid) {
+                uint32_t wave_off = 0;
+                for (uint32_t k = 0; k < wv; ++k) wave_off += s_wave[k][r];
+                sidx[(uint64_t)g * N + off + i] = off + s_base[r] + s_run[r] + wave_off + before;
+            }
+            __syncthreads();
+            if (tid < n_rank) {
+                uint32_t tot = 0;
+                for (uint32_t k = 0; k < PLAN_LOCAL_THREADS / WAVE; ++k) tot += s_wave[k][tid];
+                s_run[tid] += tot;
+            }
+            __syncthreads();
         }
-        const uint32_t base = s_running;
-        if (mine) {
-            const uint64_t o = (uint64_t)(base + wave_off + before) * (PLAN_WORDS / 4);
-            const uint64_t s = (uint64_t)(off + i) * (PLAN_WORDS / 4);
-            dst[o] = r0;
-#pragma unroll
-            for (int q = 1; q < PLAN_WORDS / 4; ++q) dst[o + q] = src[s + q];
+        if (pass == 0) {
+            if (tid == 0) {
+                uint32_t acc = 0;
+                for (uint32_t q = 0; q < n_rank; ++q) { s_base[q] = acc; acc += s_run[q]; }
+            }
+            if (tid < n_rank) count[((uint64_t)g * 2u + grp) * n_rank + tid] = s_run[tid];
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) s_running = base + total;
-        __syncthreads();
     }
-    if (tid == 0) count[g * 2u + grp] = s_running;
 }
 
 // ---------------------------------------------------------------------------------

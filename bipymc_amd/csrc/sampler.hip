@@ -203,6 +203,20 @@ static void launch_replay(const PhaseArgs& a, hipStream_t s) {
     // launched instead of 32768 -- measured no faster: 11.5 vs 11.3 us at 8 ranks, 6.9 vs 5.2 at 2; profiles/r02_replay_variants.txt)
     hipLaunchKernelGGL((phase_replay_kernel<ALGO, LPC, DPL, NP>), dim3(grid_for(a.n_upd, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
+template <int ALGO, int NP, int DPL>
+static void launch_replay_sorted(const PhaseArgs& a, hipStream_t s) {
+    uint32_t max_cnt = 0;                                     // the largest count among the OTHER ranks' updates of this half generation
+    for (uint32_t r = 0; r < a.n_seg; ++r)
+        if (r != a.seg_me) max_cnt = std::max(max_cnt, a.seg_off[r + 1] - a.seg_off[r]);
+    if (max_cnt == 0) return;
+    hipLaunchKernelGGL((phase_replay_sorted_kernel<ALGO, DPL, NP>), dim3((max_cnt + REPLAY_WG / WAVE - 1) / (REPLAY_WG / WAVE), a.n_seg), dim3(REPLAY_WG),
+                       0, s, a);
+}
+// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][dims per lane 2 / 4 / 8]: owner-sorted records exist for one wavefront per chain only
+static PhaseLaunch g_replay_sorted[3][3] = {
+    {launch_replay_sorted<ALGO_DEMC, 1, 2>, launch_replay_sorted<ALGO_DEMC, 1, 4>, launch_replay_sorted<ALGO_DEMC, 1, 8>},
+    {launch_replay_sorted<ALGO_DREAM, 3, 2>, launch_replay_sorted<ALGO_DREAM, 3, 4>, launch_replay_sorted<ALGO_DREAM, 3, 8>},
+    {launch_replay_sorted<ALGO_DREAM, 0, 2>, launch_replay_sorted<ALGO_DREAM, 0, 4>, launch_replay_sorted<ALGO_DREAM, 0, 8>}};
 // [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][shape]: the same pair-count variants as the update kernels (no target: no ln-like)
 static PhaseLaunch g_replay[3][6] = {SHAPE_TABLE(launch_replay, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 3 COMMA),
                                      SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 0 COMMA)};
@@ -255,9 +269,10 @@ struct bpm_sampler {
         uint32_t* perm = nullptr;       // [win_K * N] shuffle orders, position -> chain id
         uint32_t* inv = nullptr;        // [win_K * N] chain id -> position
         uint32_t* plan = nullptr;       // [win_K * N * PLAN_WORDS] update records (plan_kernel) or nullptr
-        uint32_t* plan_local = nullptr; // world > 1: [win_K * 2 * n_local * PLAN_WORDS] this rank's own records of each half generation, compacted
-        uint32_t* plan_count = nullptr; // device [win_K * 2]: how many
-        uint32_t* count_h = nullptr;    // the same in pinned host memory, copied by the build stream
+        uint32_t* sidx = nullptr;       // world > 1: [win_K * N] slot of every position in the owner-sorted order of its generation (plan_slot_kernel);
+                                        // `plan` then holds the records in THAT order (rank segment by rank segment inside each group)
+        uint32_t* plan_count = nullptr; // device [win_K * 2 * world]: updates of every rank in every half generation
+        uint32_t* count_h = nullptr;    // the same in pinned host memory, copied behind the build
         int64_t W = -1;                 // window held (or being built)
         int shuffle = -1;
         hipEvent_t built = nullptr;     // recorded on the build stream behind the window's last kernel / copy
@@ -265,14 +280,13 @@ struct bpm_sampler {
     TabBuf tb[2];
     int cur = -1;                       // buffer the update stream is using
     int win_K = 0;                      // generations per window (<= PERM_CHUNK)
-    bool plan_on = false, plan_local_on = false;
+    bool plan_on = false, sorted_on = false;   // sorted_on: world > 1 with owner-sorted records
     hipStream_t aux = nullptr;          // optional second build stream (BPM_TAB_AUX=1); default: the update stream builds, one window ahead
     hipEvent_t ev_main = nullptr;       // "everything enqueued on the update stream so far": a build may not overwrite a buffer before it
     // the current window (aliases into tb[cur])
     uint32_t* perm_tab = nullptr;
     uint32_t* inv_tab = nullptr;
     uint32_t* plan_tab = nullptr;
-    uint32_t* plan_local = nullptr;
     const uint32_t* plan_count_h = nullptr;
     int64_t tab_t0 = -1;
     int tab_K = 0;
@@ -448,8 +462,8 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
-                    s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].plan_local, s->tb[0].plan_count,
-                    s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].plan_local, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
+                    s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
+                    s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& B : s->tb) {
@@ -576,16 +590,16 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (s->plan_on) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
         s->win_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
-        s->plan_local_on = s->world > 1 && getenv("BPM_NO_PLAN_LOCAL") == nullptr;
+        s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG && getenv("BPM_NO_PLAN_LOCAL") == nullptr;
     }
     for (auto& B : s->tb) {
         CKD(dev_alloc(&B.perm, (size_t)s->win_K * s->N));
         CKD(dev_alloc(&B.inv, (size_t)s->win_K * s->N));
         if (s->plan_on) CKD(dev_alloc(&B.plan, (size_t)s->win_K * s->N * PLAN_WORDS));
-        if (s->plan_local_on) {
-            CKD(dev_alloc(&B.plan_local, (size_t)s->win_K * 2 * s->n_local * PLAN_WORDS));
-            CKD(dev_alloc(&B.plan_count, (size_t)s->win_K * 2));
-            HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&B.count_h), (size_t)s->win_K * 2 * sizeof(uint32_t), hipHostMallocDefault));
+        if (s->sorted_on) {
+            CKD(dev_alloc(&B.sidx, (size_t)s->win_K * s->N));
+            CKD(dev_alloc(&B.plan_count, (size_t)s->win_K * 2 * s->world));
+            HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&B.count_h), (size_t)s->win_K * 2 * s->world * sizeof(uint32_t), hipHostMallocDefault));
         }
     }
     if (s->plan_on) s->plan_tab = s->tb[0].plan;       // (non-null from here on: "this sampler launches with records")
@@ -778,16 +792,16 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
     if (B.plan) {
+        if (B.sidx) {              // world > 1: every position's slot in the owner-sorted order, every rank's counts (they size the launches)
+            hipLaunchKernelGGL(plan_slot_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, bs, B.perm, s->N, s->n_local, s->world,
+                               B.sidx, B.plan_count);
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * s->world * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+        }
         PlanParams pp{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
                       (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, pp, B.perm, B.plan);
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, pp, B.perm, B.plan, B.sidx);
         HIPCK(hipGetLastError());
-        if (B.plan_local) {        // this rank's records, compacted; the counts size the launches of the window
-            hipLaunchKernelGGL(plan_local_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, bs, B.plan, s->N, s->lo,
-                               s->n_local, B.plan_local, B.plan_count);
-            HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
-        }
     }
     HIPCK(hipEventRecord(B.built, bs));
     B.W = W;
@@ -807,9 +821,9 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
     bpm_sampler::TabBuf& B = s->tb[b];
     if (B.W != W || B.shuffle != shuffle) CK(build_window(s, b, W, shuffle));
     if (s->aux) HIPCK(hipStreamWaitEvent(s->stream, B.built, 0));
-    if (B.plan_local) HIPCK(hipEventSynchronize(B.built));        // the window's launch sizes (count_h)
+    if (B.sidx) HIPCK(hipEventSynchronize(B.built));              // the window's launch sizes (count_h)
     s->cur = b;
-    s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_local = B.plan_local; s->plan_count_h = B.count_h;
+    s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_count_h = B.count_h;
     s->tab_t0 = W * K;
     s->tab_K = K;
     s->tab_shuffle = shuffle;
@@ -870,7 +884,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.pk = pk;
         a.perm_tab = s->perm_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
-        a.plan = s->plan_tab ? s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS : nullptr;
+        a.plan = (s->plan_tab && !s->sorted_on) ? s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS : nullptr;   // records BY POSITION
         a.rec_tab = a.plan;
         { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
           if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
@@ -894,13 +908,21 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.mode = by_chain ? 1u : 0u;
         a.n_items = by_chain ? s->n_local : a.n_upd;
         a.rec_off = a.upd_off;
-        if (by_chain && s->plan_local) {
-            // a rank of a world with its compacted records: item k -> its k-th local update of this half generation,
-            // exactly the single-GPU launch shape (no idle items, no position lookup)
-            const uint64_t slot = (uint64_t)(s->t_abs - s->tab_t0) * 2 + (a.upd_off == 0 ? 0u : 1u);
-            a.rec_tab = s->plan_local + slot * s->n_local * PLAN_WORDS;
+        if (s->sorted_on && s->plan_tab) {
+            // a rank of a world with owner-sorted records: its updates of this half generation are one contiguous run of records --
+            // item k -> its k-th update: the single-GPU launch shape (no idle items, no position lookup); the other ranks' runs are
+            // what the replay kernel walks
+            const uint32_t grp = a.upd_off == 0 ? 0u : 1u;
+            const uint32_t* cnt = s->plan_count_h + ((uint64_t)(s->t_abs - s->tab_t0) * 2 + grp) * s->world;   // (pinned copy, complete:
+                                                                                                          // ensure_perm_table waited for the build)
+            uint32_t acc = a.upd_off;
+            for (uint32_t r = 0; r < s->world; ++r) { a.seg_off[r] = acc; acc += cnt[r]; }
+            for (uint32_t r = s->world; r <= (uint32_t)MAX_SEG; ++r) a.seg_off[r] = acc;
+            a.n_seg = s->world; a.seg_me = s->rank; a.acc_by_item = 1u;
+            a.rec_sorted = s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS;
+            a.rec_tab = a.rec_sorted + (uint64_t)a.seg_off[s->rank] * PLAN_WORDS;
             a.rec_off = 0u;
-            a.n_items = s->plan_count_h[(size_t)slot];      // (pinned host copy, complete: ensure_perm_table waited for the window's build)
+            a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
         a.algo = (uint32_t)s->cfg.algo;
@@ -1078,6 +1100,12 @@ static int exchange_sparse(const Group& g) {
     return 0;
 }
 
+static void launch_replay_any(bpm_sampler* s, const PhaseArgs& a) {
+    const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
+    if (a.rec_sorted && s->shape.idx >= 3) g_replay_sorted[v][s->shape.idx - 3](a, s->stream);
+    else g_replay[v][s->shape.idx](a, s->stream);
+}
+
 // demc.py:93-94,116-117 with one byte per local chain on the wire: all-gather of the accept bytes, then every rank
 // recomputes the accepted updates of the other ranks' chains of this half generation into its replica
 static int exchange_replay(const Group& g, int ph) {
@@ -1104,8 +1132,7 @@ static int exchange_replay(const Group& g, int ph) {
         a.accbits_all = s->accbits_all;
         a.trace_i32 = nullptr; a.trace_f64 = nullptr; a.trace_mask = nullptr;
         a.pack = nullptr; a.hist_row = nullptr; a.llhist_row = nullptr; a.adapt_on = 0u;
-        const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
-        g_replay[v][s->shape.idx](a, s->stream);
+        launch_replay_any(s, a);
         if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
     }
     HIPCK(hipGetLastError());
@@ -1834,10 +1861,9 @@ extern "C" int bpm_debug_time_kernels(bpm_handle_t s, int32_t reps, float* updat
             r.trace_i32 = nullptr; r.trace_f64 = nullptr; r.trace_mask = nullptr; r.pack = nullptr; r.hist_row = nullptr; r.llhist_row = nullptr;
             r.adapt_on = 0u;
         }
-        const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
-        for (int i = 0; i < 3; ++i) { if (which == 0) fn(r, s->stream); else g_replay[v][s->shape.idx](r, s->stream); }
+        for (int i = 0; i < 3; ++i) { if (which == 0) fn(r, s->stream); else launch_replay_any(s, r); }
         HIPCK(hipEventRecord(s->ev0, s->stream));
-        for (int i = 0; i < reps; ++i) { if (which == 0) fn(r, s->stream); else g_replay[v][s->shape.idx](r, s->stream); }
+        for (int i = 0; i < reps; ++i) { if (which == 0) fn(r, s->stream); else launch_replay_any(s, r); }
         HIPCK(hipEventRecord(s->ev1, s->stream));
         HIPCK(hipEventSynchronize(s->ev1));
         HIPCK(hipGetLastError());
