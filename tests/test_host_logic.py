@@ -130,6 +130,54 @@ def test_checkpoint_round_trip(tmp_path):
     assert np.array_equal(s2.param_est(0)[2][:8 * 13], full)
 
 
+def test_checkpoint_format_is_decided_by_the_file(tmp_path):
+    """`read()` must pick the format from what is on disk.  An HDF5 file (the reference's write_chain_h5 layout,
+    chain.py:59-70) without h5py in the interpreter is an explicit error, not a silent look for the .npz twin; a missing file
+    names both candidates."""
+    from bipymc_amd import checkpoint
+    hist = np.random.RandomState(0).normal(size=(5, 4, 3))
+    f = str(tmp_path / "state.h5")
+    written = checkpoint.write(f, hist, {"t_abs": 4})
+    if not checkpoint._have_h5py():
+        assert written == f + ".npz"                               # the NumPy twin of the layout
+        back, adapt = checkpoint.read(f, 4, 3)                     # found through the twin
+        assert np.array_equal(back, hist) and int(adapt["t_abs"]) == 4
+        with np.load(written) as z:
+            assert sorted(k for k in z.files if k.startswith("chains/")) == ["chains/chain_id_%d" % i for i in range(4)]
+            assert z["chains/chain_id_2"].shape == (5, 3)          # (T, dim) per chain, as chain.py:64-66 writes
+        with open(str(tmp_path / "real.h5"), "wb") as fh:          # something that IS an HDF5 file by its signature
+            fh.write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+        with pytest.raises(IOError, match="h5py"):
+            checkpoint.read(str(tmp_path / "real.h5"), 4, 3)
+    with pytest.raises(IOError, match="neither"):
+        checkpoint.read(str(tmp_path / "absent.h5"), 4, 3)
+
+
+def test_checkpoint_hdf5_layout_of_the_reference(tmp_path):
+    """The reference's on-disk format itself: HDF5, one gzip dataset /chains/chain_id_<i> of shape (T, dim) per chain
+    (chain.py:59-93; reader mc_plot/vis_mcmc_chains.py:16-41).  Needs h5py, which this image does not have and cannot install
+    (no network): the HDF5 branch of bipymc_amd/checkpoint.py has therefore never executed -- DESIGN.md section 9 says so."""
+    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (no network): the HDF5 form of the checkpoint layout cannot run here")
+    from bipymc_amd import checkpoint
+    hist = np.random.RandomState(1).normal(size=(6, 5, 2))
+    f = str(tmp_path / "state.h5")
+    assert checkpoint.write(f, hist, {"t_abs": 5, "p_cr": np.array([0.2, 0.3, 0.5])}) == f
+    with h5py.File(f, "r") as h:                                   # exactly what the reference's reader expects
+        assert sorted(h["chains"].keys()) == sorted("chain_id_%d" % i for i in range(5))
+        d = h["/chains/chain_id_3"]
+        assert d.shape == (6, 2) and d.dtype == np.float64 and d.compression == "gzip"
+        assert np.array_equal(d[:], hist[:, 3, :])
+    back, adapt = checkpoint.read(f, 5, 2)
+    assert np.array_equal(back, hist) and int(adapt["t_abs"]) == 5
+    # a file laid out by the reference's own writer (chain.py:64-66: create_dataset(name, data=chain, compression="gzip"))
+    g = str(tmp_path / "ref_style.h5")
+    with h5py.File(g, "w") as h:
+        for i in range(5):
+            h.create_dataset("/chains/chain_id_" + str(i), data=hist[:, i, :], compression="gzip")
+    back2, adapt2 = checkpoint.read(g, 5, 2)
+    assert np.array_equal(back2, hist) and adapt2 == {}
+
+
 def test_statistical_cfg1_shape_on_oracle():
     """BASELINE config 1 plumbing (shortened): DREAM N=10 on the bimodal target through the public API."""
     t = dblgauss_rv.BimodeGauss_2D()
