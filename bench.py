@@ -189,18 +189,19 @@ def main():
     if args.warmup > 1:
         eng.step(args.warmup - 1)
     if args.warmup > 0:
-        eng.step_timed(1)
+        eng.step_timed(1)          # (reads the events too: every host-side path of the timed call has run once)
     fence()
     # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two HIP events
     # bound to the first and the last update-kernel dispatch of the same K generations on the sampler's own stream
     # (bpm_step_timed: end of launch 1 -> end of launch 2K, i.e. 2K - 1 back-to-back launch periods; it returns with the
     # sampler's stream drained).
     t0 = time.perf_counter()
-    ev_ms, ev_launches = eng.step_timed(args.steps)
+    eng.step_timed(args.steps, read=False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     el = time.perf_counter() - t0
+    ev_ms, ev_launches = eng.last_step_time()
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "bpm_begin_run": (C.c_int, [_H, _P(BpmRunOpts)]),
     "bpm_step": (C.c_int, [_H, C.c_int64]),
     "bpm_step_timed": (C.c_int, [_H, C.c_int64, _P(C.c_float), _P(C.c_int64)]),
+    "bpm_get_step_time": (C.c_int, [_H, _P(C.c_float), _P(C.c_int64)]),
     "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
     "bpm_synchronize": (C.c_int, [_H]),
     "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),

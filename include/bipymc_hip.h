@@ -141,6 +141,9 @@ int bpm_step(bpm_handle_t h, int64_t n_gens);
  * first update launch -> end of the last one, n_launches = the launches that interval covers (2 n_gens - 1 for the
  * two-phase samplers).  Average launch period = elapsed_ms / n_launches. */
 int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms, int64_t* n_launches);
+/* the figures of the last bpm_step_timed call (which may be given NULL, NULL: reading the events costs tens of microseconds of
+ * host time that a caller timing the call with its own clock does not want inside) */
+int bpm_get_step_time(bpm_handle_t h, float* elapsed_ms, int64_t* n_launches);
 /* same again with a HIP event pair around every update-kernel launch: summed kernel time and launch
  * count (bench.py prices the roofline with it). n_gens <= 4096. */
 int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);
