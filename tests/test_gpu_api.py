@@ -689,3 +689,36 @@ def test_config5_as_stated_full_size():
     assert sum(e.stats()["local_n_accepted"] for e in ranks) == st1["local_n_accepted"]
     for e in ranks:
         e.close()
+
+
+def test_warm_start_with_host_callback_and_outlier_check(tmp_path):
+    """after a warm start with a Python ln_like_fn the ln-like history of the loaded rows is unknown (the reference's
+    checkpoint stores no log-likes, chain.py:59-70).  Those rows are NaN on the device, the row of the current state is filled
+    by bpm_set_loglike, and the outlier check averages over the rows it knows: a chain parked in the tail is still found and
+    reset, nothing turns NaN."""
+    from bipymc_amd import DreamMpi
+    f = str(tmp_path / "ck.npz")
+
+    def ll(theta):
+        return float(-0.5 * np.sum(theta ** 2))
+
+    a = DreamMpi(ll, np.zeros(3), n_chains=16, seed=8, burnin_gen=400, n_cr_gen=5, h5_file=f)
+    a.run_mcmc(16 * 21)
+    a.save_state(f)
+    rows = a.param_est(0)[2].shape[0]
+    # corrupt one chain of the checkpoint: far in the tail at the last row
+    with np.load(f) as z:
+        arrays = {k: z[k] for k in z.files}
+    arrays["chains/chain_id_5"] = arrays["chains/chain_id_5"].copy()
+    arrays["chains/chain_id_5"][-1] = 40.0
+    np.savez_compressed(f, **arrays)
+    b = DreamMpi(ll, None, n_chains=16, dim=3, seed=8, burnin_gen=400, n_cr_gen=5, h5_file=f, warm_start=True, outlier_every=4)
+    assert not b.uses_device_target
+    assert np.allclose(b.am_chains[5].current_pos, 40.0)
+    b.run_mcmc(16 * 13)                                   # 12 generations: outlier checks at 4, 8, 12
+    st = b._engine.stats()
+    assert st["n_outlier_resets"] >= 1
+    full = b.param_est(0)[2]
+    assert full.shape[0] == rows + 16 * 12 and np.all(np.isfinite(full))
+    assert np.all(np.abs(b._engine.get_state()) < 10.0)   # the parked chain restarted from the best one
+    assert np.all(np.isfinite(b._engine.get_loglike()))
