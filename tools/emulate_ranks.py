@@ -3,7 +3,8 @@
 multi-GPU run, the all-gathers done by device copies) at BASELINE config 4's per-rank shape (8192 chains of the 100-D
 Gaussian per rank).  Run under `rocprofv3 --kernel-trace --stats` to read the per-rank kernel times of an R-GPU run --
 update kernel in the sharded mode, replay / scatter kernels -- which is everything but the RCCL transfer.
-usage: emulate_ranks.py R [replay|rows|dense] [generations]"""
+usage: emulate_ranks.py R [replay|rows|dense] [generations] [cfg4|cfg5]
+cfg5: BASELINE config 5's per-rank shape instead (32768 chains of the 8-D mixture per rank, 4 lanes per chain, steady state)."""
 import ctypes as C
 import os
 import sys
@@ -15,14 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bipymc_amd import _lib as L          # noqa: E402
 from bipymc_amd.engine import HipEngine   # noqa: E402
-from bipymc_amd.utils import d100_gauss   # noqa: E402
+from bipymc_amd.utils import d100_gauss, mixture_nd   # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 mode = sys.argv[2] if len(sys.argv) > 2 else "replay"
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-g = d100_gauss.Gauss_100D()
+cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg4"
+g = d100_gauss.Gauss_100D() if cfg == "cfg4" else mixture_nd.BimodeGauss_ND(8)
 tid, tp, d = g._bpm_target_spec()
-N = 8192 * R
+N = (8192 if cfg == "cfg4" else 32768) * R
 np.random.seed(3)
 x0 = g.rvs(N)
 uid = b"BPMLOCAL" + bytes(120)
