@@ -722,3 +722,37 @@ def test_warm_start_with_host_callback_and_outlier_check(tmp_path):
     assert full.shape[0] == rows + 16 * 12 and np.all(np.isfinite(full))
     assert np.all(np.abs(b._engine.get_state()) < 10.0)   # the parked chain restarted from the best one
     assert np.all(np.isfinite(b._engine.get_loglike()))
+
+
+@pytest.mark.parametrize("R", [16, 24])
+def test_many_ranks_sorted_records_and_fallback(R):
+    """16 ranks is the most the owner-sorted record table serves (MAX_SEG); with more the records stay by position, the ranks launch
+    one item per local chain and a replay wavefront per position (round 1's path).  Both equal the single-rank run bit for bit."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    N, G = 24 * 16, 70                                   # crosses a table window (64 generations)
+    kw = dict(burnin_gen=6, n_cr_gen=2)
+    np.random.seed(2)
+    x0 = g.rvs(N)
+    one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=3, **kw)
+    one.set_state(x0)
+    one.begin_run()
+    one.step(G)
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=3, rank=r, world_size=R,
+                       nccl_uid=uid, **kw) for r in range(R)]
+    for e in ranks:
+        e.set_state(x0)
+        e.begin_run()
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    assert np.array_equal(np.concatenate([e.get_history() for e in ranks], axis=1), one.get_history())
+    for e in ranks:
+        assert np.array_equal(e.get_state(), one.get_state())
+        np.testing.assert_array_equal(e.stats()["p_cr"], one.stats()["p_cr"])
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == one.stats()["local_n_accepted"]
+    assert ranks[0].exchange_stats()["replay_gens"] == G - 6
