@@ -115,11 +115,16 @@ def test_nan_ratio_raises_like_numpy():
         s.run_mcmc(8 * 3)
 
 
-def test_checkpoint_warm_start_gpu(tmp_path):
-    from bipymc_amd import DreamMpi
+@pytest.mark.parametrize("ext", [".npz", ".h5"])
+def test_checkpoint_warm_start_gpu(tmp_path, ext):
+    """demc.py:198-233 through the device engine: the NumPy twin of the layout, and the reference's own HDF5 layout (h5py, or the
+    HDF5 C library through ctypes)."""
+    from bipymc_amd import DreamMpi, checkpoint
     from bipymc_amd.utils import dblgauss_rv
+    if ext == ".h5" and checkpoint.hdf5_backend() is None:
+        pytest.skip("neither h5py nor libhdf5 can be loaded on this machine")
     t = dblgauss_rv.BimodeGauss_2D()
-    f = str(tmp_path / "ck.npz")
+    f = str(tmp_path / ("ck" + ext))
     s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, seed=5, h5_file=f, checkpoint=4)
     s.run_mcmc(8 * 13)
     full = s.param_est(0)[2]

@@ -2,6 +2,8 @@
 for the device engine (tests only): constructor/kwargs surface, generation count, result
 assembly and row order, counters, checkpoint round trip -- mirroring how the reference's own
 tests drive the samplers (tests/test_dblgauss.py:43-62,130-140)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -132,50 +134,101 @@ def test_checkpoint_round_trip(tmp_path):
 
 def test_checkpoint_format_is_decided_by_the_file(tmp_path):
     """`read()` must pick the format from what is on disk.  An HDF5 file (the reference's write_chain_h5 layout,
-    chain.py:59-70) without h5py in the interpreter is an explicit error, not a silent look for the .npz twin; a missing file
-    names both candidates."""
+    chain.py:59-70) with neither h5py nor libhdf5 available is an explicit error, not a silent look for the .npz twin; a missing
+    file names both candidates; a path ending in .npz is always the NumPy twin."""
     from bipymc_amd import checkpoint
     hist = np.random.RandomState(0).normal(size=(5, 4, 3))
-    f = str(tmp_path / "state.h5")
-    written = checkpoint.write(f, hist, {"t_abs": 4})
-    if not checkpoint._have_h5py():
-        assert written == f + ".npz"                               # the NumPy twin of the layout
-        back, adapt = checkpoint.read(f, 4, 3)                     # found through the twin
-        assert np.array_equal(back, hist) and int(adapt["t_abs"]) == 4
-        with np.load(written) as z:
-            assert sorted(k for k in z.files if k.startswith("chains/")) == ["chains/chain_id_%d" % i for i in range(4)]
-            assert z["chains/chain_id_2"].shape == (5, 3)          # (T, dim) per chain, as chain.py:64-66 writes
+    f = str(tmp_path / "state.npz")
+    assert checkpoint.write(f, hist, {"t_abs": 4}) == f
+    back, adapt = checkpoint.read(f, 4, 3)
+    assert np.array_equal(back, hist) and int(adapt["t_abs"]) == 4
+    with np.load(f) as z:
+        assert sorted(k for k in z.files if k.startswith("chains/")) == ["chains/chain_id_%d" % i for i in range(4)]
+        assert z["chains/chain_id_2"].shape == (5, 3)              # (T, dim) per chain, as chain.py:64-66 writes
+    with pytest.raises(IOError, match="neither"):
+        checkpoint.read(str(tmp_path / "absent.h5"), 4, 3)
+    if checkpoint.hdf5_backend() is None:
+        assert checkpoint.write(str(tmp_path / "s.h5"), hist) == str(tmp_path / "s.h5") + ".npz"
         with open(str(tmp_path / "real.h5"), "wb") as fh:          # something that IS an HDF5 file by its signature
             fh.write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
         with pytest.raises(IOError, match="h5py"):
             checkpoint.read(str(tmp_path / "real.h5"), 4, 3)
-    with pytest.raises(IOError, match="neither"):
-        checkpoint.read(str(tmp_path / "absent.h5"), 4, 3)
+
+
+def _h5dump():
+    import shutil
+    for c in ("h5dump", "/opt/conda/bin/h5dump"):
+        p = shutil.which(c) or (c if os.path.exists(c) else None)
+        if p:
+            return p
+    return None
 
 
 def test_checkpoint_hdf5_layout_of_the_reference(tmp_path):
-    """The reference's on-disk format itself: HDF5, one gzip dataset /chains/chain_id_<i> of shape (T, dim) per chain
-    (chain.py:59-93; reader mc_plot/vis_mcmc_chains.py:16-41).  Needs h5py, which this image does not have and cannot install
-    (no network): the HDF5 branch of bipymc_amd/checkpoint.py has therefore never executed -- DESIGN.md section 9 says so."""
-    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (no network): the HDF5 form of the checkpoint layout cannot run here")
+    """The reference's on-disk format itself: HDF5, one gzip dataset /chains/chain_id_<i> of shape (T, dim) float64 per chain
+    (chain.py:59-93; reader mc_plot/vis_mcmc_chains.py:16-41).  Written and read with h5py when it is importable, else with the
+    HDF5 C library h5py itself wraps (bipymc_amd/_hdf5.py, ctypes); the file is inspected with the HDF5 project's own `h5dump`
+    when that tool is present: an independent reader sees the reference's layout."""
+    import subprocess
     from bipymc_amd import checkpoint
+    backend = checkpoint.hdf5_backend()
+    if backend is None:
+        pytest.skip("neither h5py nor libhdf5 can be loaded on this machine: the HDF5 form of the checkpoint layout cannot run here")
     hist = np.random.RandomState(1).normal(size=(6, 5, 2))
     f = str(tmp_path / "state.h5")
-    assert checkpoint.write(f, hist, {"t_abs": 5, "p_cr": np.array([0.2, 0.3, 0.5])}) == f
-    with h5py.File(f, "r") as h:                                   # exactly what the reference's reader expects
-        assert sorted(h["chains"].keys()) == sorted("chain_id_%d" % i for i in range(5))
-        d = h["/chains/chain_id_3"]
-        assert d.shape == (6, 2) and d.dtype == np.float64 and d.compression == "gzip"
-        assert np.array_equal(d[:], hist[:, 3, :])
+    assert checkpoint.write(f, hist, {"t_abs": 5, "seed": 2 ** 61 + 7, "p_cr": np.array([0.2, 0.3, 0.5]),
+                                      "delta_m": np.array([1.0, 2.0, 3.0]), "n_cr_updates": np.array([4.0, 5.0, 6.0])}) == f
+    assert checkpoint._is_hdf5(f)
     back, adapt = checkpoint.read(f, 5, 2)
-    assert np.array_equal(back, hist) and int(adapt["t_abs"]) == 5
-    # a file laid out by the reference's own writer (chain.py:64-66: create_dataset(name, data=chain, compression="gzip"))
-    g = str(tmp_path / "ref_style.h5")
-    with h5py.File(g, "w") as h:
+    assert np.array_equal(back, hist)
+    assert int(adapt["t_abs"]) == 5 and int(adapt["seed"]) == 2 ** 61 + 7
+    assert np.array_equal(adapt["p_cr"], [0.2, 0.3, 0.5]) and np.array_equal(adapt["n_cr_updates"], [4.0, 5.0, 6.0])
+    tool = _h5dump()
+    if tool:
+        hdr = subprocess.check_output([tool, "-H", "-p", f]).decode()
         for i in range(5):
-            h.create_dataset("/chains/chain_id_" + str(i), data=hist[:, i, :], compression="gzip")
+            assert 'DATASET "chain_id_%d"' % i in hdr
+        assert 'GROUP "chains"' in hdr
+        assert "H5T_IEEE_F64LE" in hdr and "( 6, 2 ) / ( 6, 2 )" in hdr
+        assert "COMPRESSION DEFLATE { LEVEL 4 }" in hdr and "CHUNKED" in hdr      # create_dataset(..., compression="gzip")
+        data = subprocess.check_output([tool, "-d", "/chains/chain_id_3", "-y", "-w", "0", "-m", "%.17g", f]).decode()
+        vals = [float(t) for t in data.split("DATA {")[1].split("}")[0].replace(",", " ").split()]
+        assert np.array_equal(np.array(vals).reshape(6, 2), hist[:, 3, :])          # an independent reader, bit for bit
+    # a file laid out the way the reference's own writer does (chain.py:64-66: create_dataset per chain, no side group)
+    g = str(tmp_path / "ref_style.h5")
+    if backend == "h5py":
+        import h5py
+        with h5py.File(g, "w") as h:
+            for i in range(5):
+                h.create_dataset("/chains/chain_id_" + str(i), data=hist[:, i, :], compression="gzip")
+    else:
+        from bipymc_amd import _hdf5
+        with _hdf5.File(g, "w") as h:
+            h.create_group("/chains")
+            for i in range(5):
+                h.write("/chains/chain_id_" + str(i), hist[:, i, :], gzip=True)
     back2, adapt2 = checkpoint.read(g, 5, 2)
     assert np.array_equal(back2, hist) and adapt2 == {}
+
+
+def test_checkpoint_round_trip_hdf5_through_the_sampler(tmp_path):
+    """save_state / warm start through an .h5 file (the reference's default h5_file name ends in .h5, demc.py:24)."""
+    from bipymc_amd import checkpoint
+    if checkpoint.hdf5_backend() is None:
+        pytest.skip("neither h5py nor libhdf5 can be loaded on this machine")
+    t = dblgauss_rv.BimodeGauss_2D()
+    f = str(tmp_path / "sampler_checkpoint.h5")
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+                 h5_file=f, checkpoint=4)
+    s.run_mcmc(8 * 13)
+    assert checkpoint._is_hdf5(f) and not os.path.exists(f + ".npz")
+    full = s.param_est(0)[2]
+    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+                  h5_file=f, warm_start=True)
+    assert np.array_equal(s2.param_est(0)[2], full)
+    np.testing.assert_allclose(s2.p_cr, s.p_cr)
+    s2.run_mcmc(8 * 3)
+    assert np.array_equal(s2.param_est(0)[2][:8 * 13], full)
 
 
 def test_statistical_cfg1_shape_on_oracle():
