@@ -114,7 +114,7 @@ struct PhaseArgs {
     const uint32_t* plan;       // [N * PLAN_WORDS] by position in shuffle order: chain id, header block, partner ids of
                                 // this generation, precomputed by plan_kernel (nullptr: drawn in the update kernel)
     const uint32_t* rec_tab;    // what the update kernel reads its records from: `plan` (item w -> record rec_off + w, rec_off =
-    uint32_t rec_off;           // upd_off), or this rank's compacted records of the half generation (plan_local_kernel, rec_off = 0)
+    uint32_t rec_off;           // upd_off), or this rank's own run of the owner-sorted records of the half generation (rec_off = 0)
     uint32_t thr[MAX_CR];       // mask thresholds floor(CR_m * 2^16) (dream.py:53,113)
     unsigned long long* stamps;  // diagnostic build only
     double* pack;               // sparse exchange (world > 1): this rank's block [count u32 | pad | ids[cap] | rows[cap][ld]] or nullptr
