@@ -81,6 +81,7 @@ SIGNATURES = {
     "bpm_eval_loglike": (C.c_int, [_H, _dp, C.c_int32, _dp]),
     "bpm_selftest_philox": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, _u32p, _u32p]),
     "bpm_debug_perm": (C.c_int, [_H, C.c_int64, C.c_int32, C.c_double, _ip, _ip, _ip]),
+    "bpm_debug_outlier_select": (C.c_int, [_H, _dp, _dp]),
     "bpm_debug_time_kernels": (C.c_int, [_H, C.c_int32, _P(C.c_float), _P(C.c_float)]),
     "bpm_set_trace": (C.c_int, [_H, C.c_int32]),
     "bpm_get_trace": (C.c_int, [_H, _ip, _dp, _u8p]),

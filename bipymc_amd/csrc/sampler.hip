@@ -1874,6 +1874,41 @@ extern "C" int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uin
     return 0;
 }
 
+// Test hook: the quartile / best-chain selection of the outlier check on caller-supplied omega values (world_size 1, sampler created
+// with outlier_every > 0): out = (sorted[k0], sorted[k0 + 1], sorted[k1], sorted[k1 + 1], first argmax, cut = Q1 - 2 IQR) with the
+// order statistics np.percentile(omega, [25, 75]) interpolates between.  tests/test_gpu_parity.py compares with NumPy on ties,
+// infinities, signed zeros and all-equal inputs.
+extern "C" int bpm_debug_outlier_select(bpm_handle_t s, const double* omega, double out[6]) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!omega || !out) return fail("bpm_debug_outlier_select: null argument");
+    if (!s->om || s->world != 1) return fail("bpm_debug_outlier_select: needs a single-rank sampler created with outlier_every > 0");
+    const uint32_t N = s->N;
+    HIPCK(hipMemcpyAsync(s->om, omega, (size_t)N * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    SelRanks R;
+    double tq[2];
+    for (int i = 0; i < 2; ++i) {
+        const double pos = (i == 0 ? 25.0 : 75.0) / 100.0 * (double)(N - 1);
+        const uint32_t lo = (uint32_t)std::floor(pos);
+        R.k[2 * i] = lo;
+        R.k[2 * i + 1] = std::min(lo + 1u, N - 1u);
+        tq[i] = pos - (double)lo;
+    }
+    const uint32_t nblk = (N + SEL_THREADS * SEL_UNR - 1) / (SEL_THREADS * SEL_UNR);
+    for (int pass = 0; pass < 8; ++pass)
+        hipLaunchKernelGGL(outlier_select_pass_kernel, dim3(nblk + (pass == 0 ? 1u : 0u)), dim3(SEL_THREADS), 0, s->stream, s->om, s->n_local, N, pass, R,
+                           reinterpret_cast<SelState*>(s->sel_state), s->sel);
+    HIPCK(hipGetLastError());
+    double h[5];
+    HIPCK(hipMemcpyAsync(h, s->sel, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < 5; ++i) out[i] = h[i];
+    auto lerp = [](double a, double b, double t) { const double d = b - a; return t >= 0.5 ? b - d * (1.0 - t) : a + d * t; };
+    const double q1 = lerp(h[0], h[1], tq[0]), q3 = lerp(h[2], h[3], tq[1]);
+    out[5] = q1 - 2.0 * (q3 - q1);
+    return 0;
+}
+
 // Diagnostic (tools/emulate_ranks.py): the update kernel and the replay kernel of this handle's LAST half generation launched
 // `reps` times back to back and timed with an event pair -- DESTRUCTIVE (the replica is advanced again and again), for timing
 // only.  Why: R ranks emulated on one GPU share ONE Infinity Cache, so kernel times read from a trace of the lock-step run are

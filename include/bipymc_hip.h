@@ -190,7 +190,9 @@ int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_
                         int64_t t_abs);
 
 /* test hooks (no sampler state involved) */
-int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* diagnostic: the update and the replay kernel of the handle's last half generation re-launched `reps` times and timed
+int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* test hook: the order statistics, first argmax and cut (Q1 - 2 IQR) the outlier check would select from `omega` (n_chains values) */
+int bpm_debug_outlier_select(bpm_handle_t h, const double* omega, double out[6]);
+/* diagnostic: the update and the replay kernel of the handle's last half generation re-launched `reps` times and timed
  * (destructive; tools/emulate_ranks.py).  No reference counterpart. */
 int bpm_debug_time_kernels(bpm_handle_t h, int32_t reps, float* update_us, float* replay_us);
 /* device target on n points */

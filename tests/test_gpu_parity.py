@@ -489,3 +489,35 @@ def test_propose_commit_path_against_oracle(algo, d, N, kw):
         np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
         np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
     np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-11, atol=1e-13)
+
+
+# ------------------------------------------------------------------ the outlier check's device-side selection
+@pytest.mark.parametrize("N", [4, 7, 100, 4097, 262144])
+def test_outlier_quartile_selection_equals_numpy(N):
+    """The multi-workgroup radix select + first-argmax of the outlier check against np.percentile / np.argmax on inputs a real run
+    can produce: ties, chains outside a prior's support (ln-like = -inf), signed zeros, all chains equal, a wide dynamic range."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    eng = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=2, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1,
+                  outlier_every=5)
+    rs = np.random.RandomState(N)
+    cases = [rs.normal(size=N) * 10 - 20,
+             np.round(rs.normal(size=N) * 3),                                   # many ties
+             np.where(rs.uniform(size=N) < 0.3, -np.inf, rs.normal(size=N)),    # a third of the chains at -inf
+             np.where(rs.uniform(size=N) < 0.5, 0.0, -0.0),                     # signed zeros
+             np.full(N, -3.25),                                                 # everybody equal
+             -np.exp(rs.uniform(-40, 40, size=N)),                              # 35 orders of magnitude
+             np.sort(rs.normal(size=N))[::-1].copy()]                           # descending
+    for om in cases:
+        om = np.ascontiguousarray(om, dtype=np.float64)
+        out = np.zeros(6)
+        L.check(eng.lib.bpm_debug_outlier_select(eng._h, om.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        srt = np.sort(om)
+        k0, k1 = int(np.floor(0.25 * (N - 1))), int(np.floor(0.75 * (N - 1)))
+        exp = [srt[k0], srt[min(k0 + 1, N - 1)], srt[k1], srt[min(k1 + 1, N - 1)]]
+        assert np.array_equal(out[:4], exp), (N, out[:4], exp)                   # (0.0 == -0.0: either sign is the same order statistic)
+        assert int(out[4]) == int(np.argmax(om))                                # the FIRST maximum
+        with np.errstate(invalid="ignore"):
+            q1, q3 = np.percentile(om, [25.0, 75.0])
+            cut = q1 - 2.0 * (q3 - q1)
+        assert (np.isnan(cut) and np.isnan(out[5])) or out[5] == cut, (N, out[5], cut)
