@@ -193,8 +193,9 @@ def main():
     fence()
     # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two HIP events
     # bound to the first and the last update-kernel dispatch of the same K generations on the sampler's own stream
-    # (bpm_step_timed: end of launch 1 -> end of launch 2K, i.e. 2K - 1 back-to-back launch periods; it returns with the
-    # sampler's stream drained).
+    # (bpm_step_timed: end of launch K/2 -> end of launch 2K, back-to-back launch periods of the last three quarters of the timed
+    # region -- binding an event to a dispatch costs the host 10-30 us, which would stall the GPU at the head of the region; it
+    # returns with the sampler's stream drained).
     t0 = time.perf_counter()
     eng.step_timed(args.steps, read=False)
     torch.cuda.synchronize()

@@ -137,9 +137,10 @@ int bpm_begin_run(bpm_handle_t h, const bpm_run_opts_t* opts);
 /* n_gens iterations of the while loop of demc.py:79-140, entirely on the device. Asynchronous. */
 int bpm_step(bpm_handle_t h, int64_t n_gens);
 /* same, synchronous, timed on the device with two HIP events BOUND TO UPDATE-KERNEL DISPATCHES of the sampler's stream (no
- * marker packets: an event-record pair alone costs ~17 us here, 7 % of a 20-generation window): elapsed_ms = end of the
- * first update launch -> end of the last one, n_launches = the launches that interval covers (2 n_gens - 1 for the
- * two-phase samplers).  Average launch period = elapsed_ms / n_launches. */
+ * marker packets: an event-record pair alone costs ~17 us here, 7 % of a 20-generation window): elapsed_ms = end of update
+ * launch number n/4 (the first one when n_gens < 8: binding an event costs the host 10-30 us, which a call starting from an
+ * idle GPU can only absorb once the host runs ahead) -> end of the last one, n_launches = the launches that interval covers.
+ * Average launch period = elapsed_ms / n_launches. */
 int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms, int64_t* n_launches);
 /* the figures of the last bpm_step_timed call (which may be given NULL, NULL: reading the events costs tens of microseconds of
  * host time that a caller timing the call with its own clock does not want inside) */
