@@ -2,10 +2,12 @@
 # The round's measurement set for bench.py (run on the GPU box: gpurun -- 'bash tools/profile_bench.sh r02'):
 #   the driver's invocation un-profiled (x3) and the default invocation, then rocprofv3 passes of the driver's invocation:
 #   kernel trace + stats, FETCH_SIZE, WRITE_SIZE, SQ counters (separate passes, as MI355X_MICROARCH.md prescribes).
-# Summaries land in profiles/<tag>_*; the rocpd databases stay in gpurun_out/.
+# Summaries land in gpurun_out/prof_<tag>/summary/ (only gpurun_out/ travels back from the GPU box): copy them to profiles/ afterwards
+#   cp gpurun_out/prof_<tag>/summary/* profiles/
+# the rocpd databases stay in gpurun_out/.
 set -u
 TAG=${1:-r02}
-R=$PWD; O=$R/gpurun_out/prof_$TAG; P=$R/profiles; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/prof_$TAG; P=$O/summary; mkdir -p $O $P
 ARGS="--steps 20 --warmup 5"
 for i in 1 2 3; do python bench.py $ARGS 2>/dev/null | tail -1 >> $O/bench_driver.jsonl; done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
