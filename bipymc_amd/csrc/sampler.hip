@@ -610,11 +610,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     static const bool no_plan = getenv("BPM_NO_PLAN") != nullptr || getenv("BPM_NO_PERM_TAB") != nullptr;
     const uint32_t plan_max_local = getenv("BPM_PLAN_MAX") ? (uint32_t)atoi(getenv("BPM_PLAN_MAX")) : 16384u;     // tuning switch
     s->win_K = PERM_CHUNK;
+    if (const char* e = getenv("BPM_WIN_K")) s->win_K = std::max(1, std::min(PERM_CHUNK, atoi(e)));     // tuning switch: generations per table window
     s->plan_on = !no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local &&
                  (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) && tid != BPM_TARGET_HOST_CALLBACK;
     if (s->plan_on) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
-        s->win_K = (int)std::max<size_t>(1, std::min<size_t>(PERM_CHUNK, ((size_t)512 << 20) / per_gen));
+        s->win_K = (int)std::max<size_t>(1, std::min<size_t>((size_t)s->win_K, ((size_t)512 << 20) / per_gen));
         s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG && getenv("BPM_NO_PLAN_LOCAL") == nullptr;
     }
     for (auto& B : s->tb) {
