@@ -32,6 +32,40 @@ __global__ void k(const uint32_t* __restrict__ tab, uint4* state, const uint32_t
     s1.x += s0.y + v; s1.y ^= v;
     state[i & mask] = s1;
 }
+// Variant "tickets": the producer kernel signals its own completion -- every wavefront, after its (write-through) stores have been
+// acknowledged, takes a ticket on one of 64 counters; the last of a counter's group takes a ticket on the second level; the last of
+// those stores the generation number into the flag the consumer polls.  Counters only ever grow (targets scale with the generation).
+__global__ void k2(const uint32_t* __restrict__ tab, uint4* state, const uint32_t* flag, uint32_t wait_target, uint32_t own_j, uint32_t* err,
+                   uint32_t mask, uint32_t* tickets, uint32_t* done, uint32_t waves) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t idx = (i * 2654435761u) & mask;
+    uint32_t v = tab[idx];
+    for (int r = 0; r < 40; ++r) v = v * 1664525u + 1013904223u;
+    if (flag) {
+        uint32_t seen = 0, spins = 0;
+        do {
+            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > 200000u) { if (threadIdx.x == 0) atomicOr(err, 1u); break; }
+        } while (seen < wait_target);
+    }
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4* sv = reinterpret_cast<u4*>(state);
+    const u4 a0 = __builtin_nontemporal_load(&sv[(v >> 3) & mask]);
+    u4 a1 = __builtin_nontemporal_load(&sv[(a0.x + v) & mask]);
+    a1.x += a0.y + v; a1.y ^= v;
+    __hip_atomic_store(&reinterpret_cast<uint32_t*>(state)[4 * (i & mask)], a1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+    __hip_atomic_store(&reinterpret_cast<uint32_t*>(state)[4 * (i & mask) + 1], a1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        const uint32_t grp = blockIdx.x & 63u, per = waves / 64u;
+        const uint32_t t1 = __hip_atomic_fetch_add(&tickets[grp * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t1 + 1u == (own_j + 1u) * per) {
+            const uint32_t t2 = __hip_atomic_fetch_add(&tickets[64u * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t2 + 1u == (own_j + 1u) * 64u) __hip_atomic_store(done, own_j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int main() {
     const uint32_t n = 1u << 16, mask = n - 1;
     std::vector<uint32_t> h(n);
@@ -77,6 +111,22 @@ int main() {
         printf("waves %5d: serial dependent launches %.2f us per kernel; overlapped (second stream + in-kernel flag wait) %.2f us per kernel; spin timeouts: %u\n",
                waves, serial, overlap, e);
         CK(hipMemset(err, 0, 4));
+        // tickets: kernel g on stream g % 2 waits for done[(g - 1) % 2] >= g; it signals done[g % 2] = g + 1 itself
+        uint32_t* tk; CK(hipMalloc(&tk, 2 * 65 * 16 * 4)); CK(hipMemset(tk, 0, 2 * 65 * 16 * 4)); CK(hipMemset(fl, 0, 64));
+        CK(hipDeviceSynchronize());
+        t0 = std::chrono::high_resolution_clock::now();
+        for (int g = 0; g < G; ++g) {
+            hipStream_t s = (g & 1) ? sB : sA;
+            const uint32_t* wait = g == 0 ? nullptr : fl + 8 * ((g - 1) & 1);
+            // per-stream generation counter: kernel g is the (g / 2)-th kernel of its stream
+            hipLaunchKernelGGL(k2, dim3(waves), dim3(64), 0, s, tab, st, wait, (uint32_t)(g == 0 ? 0 : (g - 1) / 2 + 1), (uint32_t)(g / 2), err, mask,
+                               tk + (g & 1) * 65 * 16, fl + 8 * (g & 1), (uint32_t)waves);
+        }
+        CK(hipStreamSynchronize(sA)); CK(hipStreamSynchronize(sB));
+        const double tick = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / G;
+        CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
+        printf("waves %5d: overlapped with in-kernel completion tickets %.2f us per kernel; spin timeouts: %u\n", waves, tick, e);
+        CK(hipMemset(err, 0, 4)); CK(hipFree(tk));
     }
     return 0;
 }
