@@ -708,10 +708,11 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             for (int s = 0; s < DPL; ++s) {
                 const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
                 if (j < dim) {
-                    double sd = sqrt(m2[s] / (double)a.hist_len);
-                    if (sd == 0.0) sd = 1e-12;
+                    // (x - x')^2 / std^2 with std^2 = m2 / n (std == 0 -> 1e-12, dream.py:129): ONE division instead of a division, a
+                    // square root and another division -- ~100 instructions per lane less in the burn-in kernel; the result differs
+                    // from sqrt-then-square by an ulp or two, far inside the 1e-12 the moments themselves are good for
                     const double df = wk.x[s] - wk.p[s];
-                    dl += (df * df) / (sd * sd);
+                    dl += m2[s] > 0.0 ? (df * df * (double)a.hist_len) / m2[s] : (df * df) / 1e-24;
                 }
             }
             wk.delta = gsum<LPC>(dl);
