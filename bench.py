@@ -39,7 +39,7 @@ N_CR_GEN = 50
 # 8*d*(1 own read + 2P partner reads + 1 state write + 1 history append) + 16 (cached ln_like r/w)
 BYTES_PER_UPDATE = 8 * DIM * (2 * DEL_PAIRS + 3) + 16          # 7216
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
-POSTERIOR_MIN_GENS = 500                                       # post-burn-in generations the moment gate is evaluated over
+POSTERIOR_MIN_GENS = 1200                                      # post-burn-in generations the moment gate is evaluated over
 
 
 def cpu_baseline(seconds_budget=15.0):
