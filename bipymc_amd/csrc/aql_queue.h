@@ -1,0 +1,290 @@
+// DirectQueue: the sampler's own user-mode AQL queue (host side only).
+//
+// Why: the steady state of a run is two DEPENDENT update kernels of ~6 us per generation.  A HIP launch call costs the host
+// 2.4-4.8 us (and now and then 10-30 us), so a call that starts from a drained queue -- the 20 generations the driver times --
+// runs host-paced.  Here the library writes the 64-byte AQL dispatch packets itself: kernel
+// arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, one doorbell per
+// generation.  ~0.3 us of host work per dispatch, nothing of the HIP runtime on the path (tools/micro/aql_direct.cpp measures
+// the pieces: a dependent empty dispatch costs 1.92 us this way against 2.62 us through hipLaunchKernelGGL; kernel arguments
+// in HOST memory cost 27 us per 4096-wavefront dispatch, hence the device ring).
+//
+// What it is not: a second code path for the kernels.  The kernel objects are the ones HIP loaded from this library's own fat
+// binary (found through the HSA loader's executable list), the packets carry the same barrier bit and agent-scope acquire /
+// release fences a HIP stream uses, and memory is HIP's.  Ordering against the sampler's HIP stream is by the host: the
+// sampler drains one before it uses the other (transitions happen at the end of burn-in and at the API boundary only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/hsa_ven_amd_loader.h>
+#include <x86intrin.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace bpm {
+
+struct DqKernel {
+    uint64_t object = 0;
+    uint32_t kernarg_size = 0, group = 0, priv = 0;
+    std::string name;
+};
+
+class DirectQueue {
+  public:
+    static constexpr uint32_t QUEUE_PACKETS = 1024, SLOT_BYTES = 3072, N_SLOTS = QUEUE_PACKETS;
+    enum : int { ACQUIRE = 1, RELEASE = 2, FENCED = 3 };
+
+    // one queue per HIP device of the process; nullptr when the queue cannot be had (reason in why())
+    static DirectQueue* for_device(int hip_dev) {
+        static std::mutex mu;
+        static std::map<int, DirectQueue*> all;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = all.find(hip_dev);
+        if (it != all.end()) return it->second;
+        DirectQueue* q = new DirectQueue();
+        if (!q->init(hip_dev)) {
+            static const bool verbose = getenv("BPM_VERBOSE") != nullptr;
+            if (verbose) fprintf(stderr, "[bipymc_amd] direct AQL queue not available on device %d (%s): HIP stream launches\n", hip_dev, q->why_.c_str());
+            last_reason() = q->why_;
+            delete q;
+            q = nullptr;
+        }
+        all[hip_dev] = q;
+        return q;
+    }
+    static std::string& last_reason() { static std::string r; return r; }
+
+    // the kernel HIP would launch for this host function, as the dispatch packet names it; nullptr if it cannot be located
+    const DqKernel* kernel(const void* host_fn) {
+        auto it = kernels_.find(host_fn);
+        if (it != kernels_.end()) return it->second.object ? &it->second : nullptr;
+        DqKernel k;
+        hipFunction_t fn = nullptr;
+        if (hipGetFuncBySymbol(&fn, host_fn) != hipSuccess) { (void)hipGetLastError(); }      // (makes HIP load the code object)
+        const char* nm = hipKernelNameRefByPtr(host_fn, nullptr);
+        if (fn && nm) {
+            k.name = nm;
+            Lookup lk{this, k.name + ".kd", &k, false};
+            (void)loader_.hsa_ven_amd_loader_iterate_executables(&DirectQueue::exe_cb, &lk);
+            if (!lk.found) k.object = 0;
+        }
+        auto& slot = kernels_[host_fn];
+        slot = k;
+        return slot.object ? &slot : nullptr;
+    }
+
+    // One dispatch.  `args` = the explicit kernel arguments laid out as the kernel's kernarg segment has them (natural
+    // alignment), `nbytes` their size; the hidden arguments a kernel that asks for blockDim / gridDim reads are appended here.
+    // fence: ACQUIRE | RELEASE at agent scope (what a HIP stream puts around every kernel).  sig: 0 / 1 = this dispatch
+    // carries timing signal 0 / 1 (see dispatch_end_ns), -1 = none.  The doorbell is rung by flush().
+    int launch(const DqKernel& k, uint32_t grid_x, uint32_t grid_y, uint32_t block, const void* args, size_t nbytes, int fence, int sig = -1) {
+        if (failed_) return -1;
+        const size_t hidden_at = (nbytes + 7) & ~size_t(7);
+        const bool hidden = k.kernarg_size >= hidden_at + 66;
+        if (nbytes > k.kernarg_size || k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
+        if (!wait_for_room()) return -1;
+        char* slot = kernarg_ + (size_t)(widx_ % N_SLOTS) * SLOT_BYTES;
+        std::memcpy(slot, args, nbytes);
+        size_t written = nbytes;
+        if (hidden) {
+            struct Hidden {
+                uint32_t block_count[3];
+                uint16_t group_size[3], remainder[3];
+                uint8_t reserved[16];
+                uint64_t global_offset[3];
+                uint16_t grid_dims;
+            } h;
+            static_assert(offsetof(Hidden, global_offset) == 40 && offsetof(Hidden, grid_dims) == 64, "implicit kernel argument layout (code object v5)");
+            std::memset(&h, 0, sizeof(h));
+            h.block_count[0] = grid_x; h.block_count[1] = grid_y; h.block_count[2] = 1;
+            h.group_size[0] = (uint16_t)block; h.group_size[1] = 1; h.group_size[2] = 1;
+            h.grid_dims = grid_y > 1 ? 2 : 1;
+            std::memcpy(slot + hidden_at, &h, 66);
+            written = hidden_at + 66;
+        }
+        last_written_ = reinterpret_cast<volatile uint32_t*>(slot + ((written - 1) & ~size_t(3)));
+        auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
+        p->workgroup_size_x = (uint16_t)block; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
+        p->grid_size_x = grid_x * block; p->grid_size_y = grid_y; p->grid_size_z = 1;
+        p->private_segment_size = k.priv; p->group_segment_size = k.group;
+        p->kernel_object = k.object; p->kernarg_address = slot; p->reserved2 = 0;
+        hsa_signal_t none{0};
+        if (sig == 0 || sig == 1) { hsa_signal_store_relaxed(tsig_[sig], 1); tsig_armed_[sig] = true; }
+        p->completion_signal = (sig == 0 || sig == 1) ? tsig_[sig] : none;
+        const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                        (((fence & ACQUIRE) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                        (((fence & RELEASE) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        pending_header_[n_unpublished_] = (uint32_t)hdr | ((uint32_t)(3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16);
+        pending_packet_[n_unpublished_] = reinterpret_cast<uint32_t*>(p);
+        // (the packet's first word still says INVALID: the packet processor stops in front of it until flush() publishes it)
+        ++n_unpublished_;
+        ++widx_;
+        busy_ = true;
+        if (n_unpublished_ == MAX_UNPUBLISHED) flush();
+        return 0;
+    }
+
+    // publish what launch() has written: arguments first (store fence + read-back through the BAR: the posted writes have
+    // reached device memory), then the packet headers, then the doorbell
+    void flush() {
+        if (n_unpublished_ == 0) return;
+        _mm_sfence();
+        if (last_written_) { const uint32_t sink = *last_written_; (void)sink; }
+        for (uint32_t i = 0; i < n_unpublished_; ++i) __atomic_store_n(pending_packet_[i], pending_header_[i], __ATOMIC_RELEASE);
+        n_unpublished_ = 0;
+        hsa_queue_store_write_index_screlease(q_, widx_);
+        hsa_signal_store_screlease(q_->doorbell_signal, (hsa_signal_value_t)(widx_ - 1));
+    }
+
+    // everything dispatched so far has finished and is visible to the host and to HIP streams (system-scope release)
+    int drain(double timeout_s = 120.0) {
+        if (!busy_) return 0;
+        if (failed_) return -1;
+        if (!wait_for_room()) return -1;
+        flush();
+        auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
+        std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
+        hsa_signal_store_relaxed(done_, 1);
+        b->completion_signal = done_;
+        const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                        (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                        (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        __atomic_store_n(reinterpret_cast<uint32_t*>(b), (uint32_t)hdr, __ATOMIC_RELEASE);
+        ++widx_;
+        hsa_queue_store_write_index_screlease(q_, widx_);
+        hsa_signal_store_screlease(q_->doorbell_signal, (hsa_signal_value_t)(widx_ - 1));
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hsa_signal_load_scacquire(done_) > 0) {                       // polling: a parked thread wakes up on a slow clock
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                why_ = "timeout waiting for the AQL queue to drain"; failed_ = true; return -1;
+            }
+        }
+        busy_ = false;
+        return 0;
+    }
+    bool busy() const { return busy_; }
+    bool failed() const { return failed_; }
+    const std::string& why() const { return why_; }
+
+    // end-of-kernel time stamps (ns, one clock) of the dispatches that carried timing signal 0 and 1; call after drain()
+    bool dispatch_end_ns(double* t0_ns, double* t1_ns) {
+        if (!tsig_armed_[0] || !tsig_armed_[1]) return false;
+        hsa_amd_profiling_dispatch_time_t a{}, b{};
+        if (hsa_amd_profiling_get_dispatch_time(agent_, tsig_[0], &a) != HSA_STATUS_SUCCESS) return false;
+        if (hsa_amd_profiling_get_dispatch_time(agent_, tsig_[1], &b) != HSA_STATUS_SUCCESS) return false;
+        *t0_ns = (double)a.end * tick_ns_;
+        *t1_ns = (double)b.end * tick_ns_;
+        return true;
+    }
+    void disarm_timing() { tsig_armed_[0] = tsig_armed_[1] = false; }
+
+  private:
+    static constexpr uint32_t MAX_UNPUBLISHED = 8;
+    struct Lookup { DirectQueue* self; std::string sym; DqKernel* out; bool found; };
+
+    static hsa_status_t exe_cb(hsa_executable_t exe, void* data) {
+        Lookup* lk = static_cast<Lookup*>(data);
+        hsa_executable_symbol_t sym;
+        if (hsa_executable_get_symbol_by_name(exe, lk->sym.c_str(), &lk->self->agent_, &sym) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        DqKernel& k = *lk->out;
+        if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object) != HSA_STATUS_SUCCESS || !k.object) return HSA_STATUS_SUCCESS;
+        hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_size);
+        hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group);
+        hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.priv);
+        lk->found = true;
+        return HSA_STATUS_INFO_BREAK;
+    }
+    struct AgentPick { uint32_t bdf; uint32_t domain; bool any_gpu_only; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; int n_gpu; };
+    static hsa_status_t agent_cb(hsa_agent_t a, void* data) {
+        AgentPick* p = static_cast<AgentPick*>(data);
+        hsa_device_type_t t;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (t == HSA_DEVICE_TYPE_CPU && !p->have_cpu) { p->cpu = a; p->have_cpu = true; }
+        if (t == HSA_DEVICE_TYPE_GPU) {
+            uint32_t bdf = 0, dom = 0;
+            hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+            hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+            ++p->n_gpu;
+            if (!p->have_gpu && bdf == p->bdf && dom == p->domain) { p->gpu = a; p->have_gpu = true; }
+        }
+        return HSA_STATUS_SUCCESS;
+    }
+    static hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void* data) {
+        hsa_amd_segment_t seg;
+        if (hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+        uint32_t fl = 0; bool alloc = false;
+        hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &fl);
+        hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+        hsa_amd_memory_pool_t* out = static_cast<hsa_amd_memory_pool_t*>(data);
+        if (alloc && (fl & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !out->handle) *out = pool;
+        return HSA_STATUS_SUCCESS;
+    }
+
+    bool init(int hip_dev) {
+        if (const char* e = getenv("BPM_DIRECT_QUEUE")) if (atoi(e) == 0) { why_ = "BPM_DIRECT_QUEUE=0"; return false; }
+        int bus = 0, dev = 0, dom = 0;
+        if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_dev) != hipSuccess || hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_dev) != hipSuccess ||
+            hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_dev) != hipSuccess) { (void)hipGetLastError(); why_ = "no PCI address of the HIP device"; return false; }
+        if (hsa_init() != HSA_STATUS_SUCCESS) { why_ = "hsa_init failed"; return false; }           // (reference counted: HIP holds the runtime open already)
+        hsa_inited_ = true;
+        AgentPick pick{};
+        pick.bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3); pick.domain = (uint32_t)dom;
+        if (hsa_iterate_agents(&DirectQueue::agent_cb, &pick) != HSA_STATUS_SUCCESS || !pick.have_gpu || !pick.have_cpu) { why_ = "HSA agent of the HIP device not found"; return false; }
+        agent_ = pick.gpu; cpu_ = pick.cpu;
+        if (hsa_system_get_major_extension_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof(loader_), &loader_) != HSA_STATUS_SUCCESS ||
+            !loader_.hsa_ven_amd_loader_iterate_executables) { why_ = "HSA loader extension 1.03 missing"; return false; }
+        hsa_amd_memory_pool_t pool{};
+        hsa_amd_agent_iterate_memory_pools(agent_, &DirectQueue::pool_cb, &pool);
+        if (!pool.handle) { why_ = "no device memory pool"; return false; }
+        hsa_amd_memory_pool_access_t acc = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+        hsa_amd_agent_memory_pool_get_info(cpu_, pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &acc);
+        if (acc == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED) { why_ = "device memory is not host-writable (no large BAR)"; return false; }
+        if (hsa_amd_memory_pool_allocate(pool, (size_t)N_SLOTS * SLOT_BYTES, 0, reinterpret_cast<void**>(&kernarg_)) != HSA_STATUS_SUCCESS) { why_ = "kernarg ring allocation failed"; return false; }
+        if (hsa_amd_agents_allow_access(1, &cpu_, nullptr, kernarg_) != HSA_STATUS_SUCCESS) { why_ = "host access to the kernarg ring refused"; return false; }
+        if (hsa_queue_create(agent_, QUEUE_PACKETS, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q_) != HSA_STATUS_SUCCESS) { why_ = "hsa_queue_create failed"; return false; }
+        (void)hsa_amd_profiling_set_profiler_enabled(q_, 1);
+        if (hsa_signal_create(0, 0, nullptr, &done_) != HSA_STATUS_SUCCESS || hsa_signal_create(0, 0, nullptr, &tsig_[0]) != HSA_STATUS_SUCCESS ||
+            hsa_signal_create(0, 0, nullptr, &tsig_[1]) != HSA_STATUS_SUCCESS) { why_ = "hsa_signal_create failed"; return false; }
+        uint64_t freq = 0;
+        hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq);
+        tick_ns_ = freq ? 1e9 / (double)freq : 10.0;
+        widx_ = hsa_queue_load_write_index_relaxed(q_);
+        return true;
+    }
+    // room for one more packet: its kernarg slot was last used by a packet that has finished (every packet carries the
+    // barrier bit, so a packet the processor has taken off the ring means all before it are done)
+    bool wait_for_room() {
+        if (widx_ - hsa_queue_load_read_index_scacquire(q_) < (uint64_t)N_SLOTS - 8) return true;
+        flush();
+        const auto t0 = std::chrono::steady_clock::now();
+        while (widx_ - hsa_queue_load_read_index_scacquire(q_) >= (uint64_t)N_SLOTS - 8) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) { why_ = "timeout waiting for room in the AQL queue"; failed_ = true; return false; }
+        }
+        return true;
+    }
+
+    hsa_agent_t agent_{}, cpu_{};
+    hsa_ven_amd_loader_1_03_pfn_t loader_{};
+    hsa_queue_t* q_ = nullptr;
+    char* kernarg_ = nullptr;
+    uint64_t widx_ = 0;
+    hsa_signal_t done_{}, tsig_[2]{};
+    bool tsig_armed_[2] = {false, false};
+    double tick_ns_ = 10.0;
+    bool busy_ = false, failed_ = false, hsa_inited_ = false;
+    uint32_t n_unpublished_ = 0;
+    uint32_t pending_header_[MAX_UNPUBLISHED]{};
+    uint32_t* pending_packet_[MAX_UNPUBLISHED]{};
+    volatile uint32_t* last_written_ = nullptr;
+    std::string why_;
+    std::map<const void*, DqKernel> kernels_;
+};
+
+}  // namespace bpm

@@ -27,6 +27,7 @@
 #include "../../include/bipymc_hip.h"
 #include "kernels.h"
 #include "rocrand_check.h"
+#include "aql_queue.h"
 
 using namespace bpm;
 
@@ -127,9 +128,26 @@ struct FusedKernarg {
     PhaseArgs a;
 };
 static_assert(offsetof(FusedKernarg, a) == 24 && sizeof(FusedKernarg) == 24 + sizeof(PhaseArgs), "kernarg layout of phase_fused_kernel");
+// Direct mode (aql_queue.h): while run_generations has the sampler in direct mode, g_dq names its queue and every kernel of the
+// generation loop -- update kernels here, table builds in build_window -- is dispatched by a packet this library writes itself.
+static thread_local bpm::DirectQueue* g_dq = nullptr;
+static thread_local int g_dq_sig = -1;            // the next update dispatch carries this timing signal (bpm_step_timed)
+static thread_local bool g_dq_error = false;      // a dispatch could not be made: run_generations reports it
+static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
 template <class K>
 static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a, unsigned grid, unsigned block, hipStream_t s) {
     static const bool lean = getenv("BPM_NO_LEAN_LAUNCH") == nullptr;
+    if (g_dq) {
+        FusedKernarg ka;
+        ka.pl_plan = a.rec_tab; ka.pl_upd_off = a.rec_off; ka.pl_n_items = a.n_items; ka.pl_mode = a.mode; ka._pad = 0u;
+        ka.a = a;
+        const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(kernel));
+        const int sig = g_dq_sig; g_dq_sig = -1;
+        if (!k || g_dq->launch(*k, grid, 1, block, &ka, sizeof(ka), bpm::DirectQueue::FENCED, sig) != 0) g_dq_error = true;
+        ++g_timed_launches; ++g_n_direct;
+        return;
+    }
+    ++g_n_stream;
     if (lean && !fn) { if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); fn = nullptr; } }
     if (lean && fn) {
         FusedKernarg ka;
@@ -170,8 +188,11 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
             return;
         }
     }
-    hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
-                          nullptr, take_stop_event(), 0, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+    {   // the general instantiation: same argument block, same two launch paths
+        static hipFunction_t fn = nullptr;
+        launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP>, fn, a, grid_for(a.n_items, LPC), (unsigned)block_for(LPC), s);
+        return;
+    }
 #else
     hipExtLaunchKernelGGL((phase_fused_kernel<ALGO, T, LPC, DPL, NP>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s,
                           nullptr, take_stop_event(), 0, a);
@@ -349,6 +370,12 @@ struct bpm_sampler {
     int64_t gexec_gens[GRAPH_RING] = {0, 0, 0};       // generations each instantiated graph holds
     int gexec_next = 0;
     int64_t n_graph_chunks = 0;
+    // direct mode: the generation loop's kernels go through the library's own AQL queue (aql_queue.h) instead of the HIP stream.
+    // dq_active: work may be in flight on that queue -- every entry point that uses the stream or reads device memory drains
+    // it first (check_handle); run_generations waits for the stream before it enters direct mode.
+    bpm::DirectQueue* dq = nullptr;
+    bool dq_active = false;
+    bool timed_direct = false;        // the last bpm_step_timed was timed by the queue's dispatch time stamps
     // run state
     bpm_run_opts_t opts{};
     bool run_open = false;
@@ -377,7 +404,18 @@ static PhaseLaunch pick_fused(const bpm_sampler* s) {
     }
 }
 
+// leave direct mode: everything dispatched on the library's own queue has finished and is visible to the HIP stream and the host
+static int leave_direct(bpm_sampler* s) {
+    if (!s->dq_active) return 0;
+    s->dq_active = false;
+    if (s->dq && s->dq->drain() != 0) return fail("direct AQL queue: " + s->dq->why());
+    return 0;
+}
 static int check_handle(bpm_handle_t h) {
+    if (!h) return fail("null handle");
+    return leave_direct(h);
+}
+static int check_handle_keep_direct(bpm_handle_t h) {      // (bpm_step and friends: consecutive calls stay on the queue)
     if (!h) return fail("null handle");
     return 0;
 }
@@ -393,9 +431,25 @@ static int dev_alloc(T** p, size_t n) {
     return 0;
 }
 
+// Buffers that one update kernel writes and the next one reads (state matrix, ln-like cache, accept counters, Welford moments).
+// hipDeviceMallocUncached is, on this runtime, the GPU's EXTENDED-SCOPE FINE-GRAINED pool: local HBM mapped with the cached-coherent
+// memory type, i.e. the XCDs' L2s stay coherent on these lines by themselves (tools/micro/aql_direct.cpp: a dependent chain of
+// kernels is correct on it with NO acquire / release fence between the dispatches, wrong on hipMalloc memory) and a kernel
+// leaves no dirty lines for the end-of-kernel release to write back (3.24 -> 2.34 us per dependent launch of a 2 MB
+// read-modify-write kernel).  Gathers from it cost 1-5 % more than from ordinary device memory.
+template <class T>
+static int dev_alloc_state(T** p, size_t n) {
+    static const bool coherent = getenv("BPM_COHERENT_STATE") != nullptr && atoi(getenv("BPM_COHERENT_STATE")) != 0;
+    if (!coherent) return dev_alloc(p, n);
+    HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T), hipDeviceMallocUncached));
+    return 0;
+}
+
 static int ensure_history(bpm_sampler* s, int64_t rows) {
     if (!s->cfg.keep_history) rows = std::min<int64_t>(rows, 1);
     if (rows <= s->hist_cap) return 0;
+    const bool was_direct = s->dq_active;
+    CK(leave_direct(s));              // (kernels in flight on the library's own queue still write the old buffers)
     int64_t cap = std::max<int64_t>(rows, s->hist_cap + s->hist_cap / 2);
     const size_t row_d = (size_t)s->n_local * s->ld;
     double* nh = nullptr;
@@ -412,6 +466,7 @@ static int ensure_history(bpm_sampler* s, int64_t rows) {
     s->hist = nh;
     s->llhist = nl;
     s->hist_cap = cap;
+    s->dq_active = was_direct && g_dq != nullptr;      // (inside a direct-mode generation: the stream is idle again, go on)
     return 0;
 }
 
@@ -482,6 +537,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
         g_ns_prepare = g_ns_launch = g_n_launch = 0;
     }
     (void)hipSetDevice(s->cfg.device);
+    (void)leave_direct(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
@@ -570,6 +626,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // the concurrent build cost the latency-bound update kernels far more than the 23 us they hide;
     // profiles/r02_table_build_modes.txt), lowest stream priority no different.
     if (getenv("BPM_TAB_AUX") != nullptr) HIPCKD(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    // the library's own AQL queue for the steady state of a single-GPU sampler (aql_queue.h); without it (no large BAR, a runtime
+    // without the loader extension, BPM_DIRECT_QUEUE=0) the same kernels are launched on the stream
+    if (s->world == 1 && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
+        s->dq = bpm::DirectQueue::for_device(cfg->device);
+        if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
+    }
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
     HIPCKD(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
@@ -578,12 +640,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
     s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
     const size_t row_d = (size_t)s->n_local * s->ld;
-    CKD(dev_alloc(&s->G, (size_t)s->world * s->L.blk));
+    CKD(dev_alloc_state(&s->G, (size_t)s->world * s->L.blk));
     HIPCKD(hipMemsetAsync(s->G, 0, (size_t)s->world * s->L.blk * sizeof(double), s->stream));
     s->L.G = s->G;
-    CKD(dev_alloc(&s->ll, s->n_local));
-    CKD(dev_alloc(&s->w_mean, row_d));
-    CKD(dev_alloc(&s->w_m2, row_d));
+    CKD(dev_alloc_state(&s->ll, s->n_local));
+    CKD(dev_alloc_state(&s->w_mean, row_d));
+    CKD(dev_alloc_state(&s->w_m2, row_d));
     CKD(dev_alloc(&s->tparams, (size_t)np));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
     CKD(dev_alloc(&s->cr_state, 3 * MAX_CR));
@@ -594,7 +656,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipStreamSynchronize(s->stream));
     }
     CKD(dev_alloc(&s->counters, 8));      // [2] NaN ratios of this run; [4] outlier resets since creation
-    CKD(dev_alloc(&s->acc_count, s->n_local));
+    CKD(dev_alloc_state(&s->acc_count, s->n_local));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
     if (cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0) {
@@ -815,6 +877,25 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
     const uint64_t n = (uint64_t)K * s->N;
+    if (g_dq) {
+        // direct mode (single GPU, no second build stream): the same two kernels as packets on the library's queue, in order with
+        // the update kernels around them
+        struct { PermKeys keys; uint32_t n_gens, N; uint32_t* tab; uint32_t* inv; } pa{keys, (uint32_t)K, s->N, B.perm, B.inv};
+        static_assert(offsetof(decltype(pa), tab) == sizeof(PermKeys) + 8, "kernarg layout of perm_table_kernel");
+        const bpm::DqKernel* kp = g_dq->kernel(reinterpret_cast<const void*>(perm_table_kernel));
+        if (!kp || g_dq->launch(*kp, (uint32_t)((n + 255) / 256), 1, 256, &pa, sizeof(pa), bpm::DirectQueue::FENCED) != 0) return fail("direct AQL queue: perm_table_kernel: " + g_dq->why());
+        if (B.plan) {
+            struct { PlanParams P; const uint32_t* tab; uint32_t* plan; const uint32_t* sidx; } qa{
+                PlanParams{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
+                           (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u},
+                B.perm, B.plan, B.sidx};
+            const bpm::DqKernel* kq = g_dq->kernel(reinterpret_cast<const void*>(plan_kernel));
+            if (!kq || g_dq->launch(*kq, (uint32_t)((n + 255) / 256), 1, 256, &qa, sizeof(qa), bpm::DirectQueue::FENCED) != 0) return fail("direct AQL queue: plan_kernel: " + g_dq->why());
+        }
+        B.W = W;
+        B.shuffle = shuffle;
+        return 0;
+    }
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
     if (B.plan) {
@@ -1188,7 +1269,11 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (s->cur_args[ph].n_items > 0) {
-                    if (s->timed_want_first && s->timed_skip > 0) {
+                    if (g_dq && s->timed_last_gen >= 0) {
+                        // direct mode: attaching a time stamp costs the host nothing -- the first and the last update dispatch of the call
+                        if (s->timed_want_first) { s->timed_want_first = false; g_dq_sig = 0; s->timed_l0 = g_timed_launches; }
+                        else if (s->timed_last_gen == s->t_abs && (ph == 1 || s->cur_args[1].n_items == 0)) { g_dq_sig = 1; s->timed_l1 = g_timed_launches; }
+                    } else if (s->timed_want_first && s->timed_skip > 0) {
                         --s->timed_skip;
                     } else if (s->timed_want_first) {
                         s->timed_want_first = false; g_stop_event = s->ev0; s->timed_l0 = g_timed_launches;
@@ -1290,7 +1375,26 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 if (Kg > 0) { done += Kg; continue; }
             }
             const bool replay = s0->replay_enabled && !adapting;       // burn-in: delta / cr_idx of every chain travel in the dense block
-            CK(group_generation(g, n_gens - done, replay ? 2 : 0, fn));
+            // Direct mode: a single GPU's steady state (nothing per generation but the two update kernels and, once per window, the
+            // table build) is dispatched through the library's own AQL queue.  Burn-in (cr_adapt, outlier check, moment rebuild), the
+            // synchronous mode, tracing and everything with an exchange stay on the HIP stream.
+            const bool direct = s0->dq && !use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group && !adapting && !s0->aux &&
+                                s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed();
+            if (direct && !s0->dq_active) {
+                CK(wait_stream(s0->stream));                            // what the stream still holds (burn-in, table builds) comes first
+                s0->dq_active = true;
+            } else if (!direct && s0->dq_active) {
+                CK(leave_direct(s0));
+            }
+            g_dq = direct ? s0->dq : nullptr;
+            g_dq_error = false;
+            const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
+            if (direct) {
+                s0->dq->flush();                                        // one doorbell per generation
+                g_dq = nullptr;
+                if (g_dq_error || s0->dq->failed()) return fail("direct AQL queue: " + (s0->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s0->dq->why()));
+            }
+            CK(rc_gen);
             if (replay) for (int r = 0; r < g.R; ++r) g.h[r]->n_replay_gens += 1;
             ++done;
             continue;
@@ -1367,7 +1471,7 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
 }
 
 extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
-    CK(check_handle(s));
+    CK(check_handle_keep_direct(s));
     CK(set_device(s));
     if (s->local_group) return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step");
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
@@ -1404,9 +1508,19 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     return 0;
 }
 
+extern "C" int bpm_get_launch_stats(bpm_handle_t s, int64_t* out) {
+    CK(check_handle_keep_direct(s));
+    if (!out) return fail("bpm_get_launch_stats: null argument");
+    out[0] = s->dq != nullptr ? 1 : 0;
+    out[1] = g_n_direct;
+    out[2] = g_n_stream;
+    out[3] = s->dq_active ? 1 : 0;
+    return 0;
+}
+
 extern "C" int bpm_get_step_time(bpm_handle_t s, float* elapsed_ms, int64_t* n_launches);
 extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms, int64_t* n_launches) {
-    CK(check_handle(s));
+    CK(check_handle_keep_direct(s));
     CK(set_device(s));
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_timed: not available for the synchronous DE-MC mode");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
@@ -1428,8 +1542,11 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
     s->timed_want_first = false;
     s->timed_last_gen = -1;
     g_stop_event = nullptr;
+    g_dq_sig = -1;
     CK(rc);
-    CK(wait_stream(s->stream));
+    s->timed_direct = s->dq_active;
+    if (s->dq_active) { if (s->dq->drain() != 0) return fail("direct AQL queue: " + s->dq->why()); }     // (the sampler stays in direct mode: the next call goes on)
+    else CK(wait_stream(s->stream));
     if (g_host_timing && !g_launch_log.empty() && g_launch_log.size() <= 400) {
         const long long tt1 = now_ns();
         fprintf(stderr, "[bpm host timing] bpm_step_timed(%lld): entry -> drained %.1f us; launch calls (start offset us : duration us):", (long long)n_gens, (tt1 - tt0) * 1e-3);
@@ -1443,11 +1560,16 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
 }
 
 extern "C" int bpm_get_step_time(bpm_handle_t s, float* elapsed_ms, int64_t* n_launches) {
-    CK(check_handle(s));
+    CK(check_handle_keep_direct(s));
     CK(set_device(s));
     if (elapsed_ms) *elapsed_ms = 0.f;
     if (n_launches) *n_launches = 0;
-    if (s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
+    if (s->timed_direct && s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
+        double t0 = 0.0, t1 = 0.0;                    // end-of-kernel time stamps of the two dispatches, written by the packet processor
+        if (!s->dq || !s->dq->dispatch_end_ns(&t0, &t1)) return fail("bpm_get_step_time: no dispatch time stamps");
+        if (elapsed_ms) *elapsed_ms = (float)((t1 - t0) * 1e-6);
+        if (n_launches) *n_launches = s->timed_l1 - s->timed_l0;
+    } else if (s->timed_l0 >= 0 && s->timed_l1 > s->timed_l0) {
         float ms = 0.f;
         HIPCK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         if (elapsed_ms) *elapsed_ms = ms;

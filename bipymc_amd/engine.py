@@ -189,6 +189,12 @@ class HipEngine(object):
         return dict(mode=["dense", "rows", "replay"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
                     replay_gens=int(out[4]))
 
+    def launch_stats(self):
+        """How the update kernels were dispatched: the library's own AQL queue or the HIP stream (bpm_get_launch_stats)."""
+        out = (C.c_int64 * 4)()
+        L.check(self.lib.bpm_get_launch_stats(self._h, out))
+        return dict(has_queue=bool(out[0]), direct=int(out[1]), stream=int(out[2]), queue_active=bool(out[3]))
+
     def history_rows(self):
         return int(self.stats()["history_rows"])
 

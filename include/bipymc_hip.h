@@ -167,6 +167,13 @@ int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
 /* out[5] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
  *           generations exchanged by replay} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
+/* How the generation loop's kernels reach the GPU (no counterpart in the reference: its loop is the Python interpreter,
+ * demc.py:79-140).  A single-GPU sampler with a device target dispatches its steady state through the library's own
+ * user-mode AQL queue (packets written by the library, bipymc_amd/csrc/aql_queue.h); burn-in, exchanges and every other
+ * entry point use the HIP stream.  out[4] = {1 if the sampler has such a queue, update-kernel dispatches of the calling
+ * thread through it, update-kernel launches of the calling thread through the HIP stream, 1 if work may be in flight on
+ * the queue}.  BPM_DIRECT_QUEUE=0 in the environment disables the queue. */
+int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop

@@ -1,0 +1,39 @@
+// Device side of tools/micro/aql_direct.cpp (built with --cuda-device-only --no-gpu-bundle-output into a plain code object
+// that the host program loads through the HSA loader).  No blockDim/gridDim use: the kernels need no hidden arguments.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+extern "C" __global__ void k_empty(int* p) {
+    if (p && threadIdx.x == 9999) *p = 1;
+}
+
+// Launch number `shift` lets workgroup b own the 64-element block (b + shift) mod nb: a block of x is touched by a different
+// workgroup -- hence a different XCD and a different L2 -- in every launch, so x[i] == number of launches afterwards only if
+// each launch saw what the previous one wrote (cross-XCD visibility at the kernel boundary).
+extern "C" __global__ void k_chain(double* x, uint32_t nb, uint32_t shift) {
+    const uint32_t b = (blockIdx.x + shift) % nb;
+    const uint32_t i = b * 64u + threadIdx.x;
+    x[i] += 1.0;
+}
+
+// The same with accesses the hardware keeps coherent across the XCDs by itself (agent-scope relaxed atomics: sc1 loads / stores
+// that do not rest in the non-coherent L2), for packets without acquire / release fences.
+extern "C" __global__ void k_chain_coherent(double* x, uint32_t nb, uint32_t shift) {
+    const uint32_t b = (blockIdx.x + shift) % nb;
+    const uint32_t i = b * 64u + threadIdx.x;
+    const double v = __hip_atomic_load(&x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&x[i], v + 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A gather kernel shaped like the update kernel's traffic: every lane reads `rows` random 16-byte pieces of a table that the
+// previous launch wrote, and writes one.
+extern "C" __global__ void k_gather(uint4* tab, uint32_t mask, uint32_t rows, uint32_t shift) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    uint32_t idx = (i * 2654435761u + shift * 40503u) & mask;
+    uint32_t acc = 0;
+    for (uint32_t r = 0; r < rows; ++r) {
+        const uint4 v = tab[(idx + r * 7919u) & mask];
+        acc += v.y;
+    }
+    tab[(i + shift * 64u) & mask].y = acc;
+}
