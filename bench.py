@@ -254,6 +254,9 @@ def main():
                      var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)),
                      acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
 
+    import hashlib
+    state_sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]   # (A/B of launch paths: same bits)
+    lstat = eng.launch_stats()
     if rank == 0:
         copy_gbs = measured_copy_bandwidth(torch, local_rank)
         out = {
@@ -270,7 +273,11 @@ def main():
                                    % (n_chains, CHAINS_PER_GPU, BURNIN_GEN, preheat["seconds"], preheat["generations"]),
                        "n_chains": n_chains, "dim": DIM, "parallelism": "chains sharded x%d" % world,
                        "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s,
-                       "exchange": eng.exchange_stats() if use_dist else None},
+                       "exchange": eng.exchange_stats() if use_dist else None,
+                       # how the update kernels were dispatched: packets written by the library into its own AQL queue
+                       # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (burn-in, multi-GPU, BPM_DIRECT_QUEUE=0)
+                       "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"]},
+                       "final_state_sha256_16": state_sha},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, %d> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation%s)" % ((5, " of the sharded launch mode") if world > 1 else (1, "")),

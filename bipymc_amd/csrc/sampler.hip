@@ -133,6 +133,12 @@ static_assert(offsetof(FusedKernarg, a) == 24 && sizeof(FusedKernarg) == 24 + si
 static thread_local bpm::DirectQueue* g_dq = nullptr;
 static thread_local int g_dq_sig = -1;            // the next update dispatch carries this timing signal (bpm_step_timed)
 static thread_local bool g_dq_error = false;      // a dispatch could not be made: run_generations reports it
+// Fences of an update-kernel packet.  Default: agent-scope acquire + release, what a HIP stream puts around every kernel.
+// With the state in cached-coherent memory (dev_alloc_state) an update kernel leaves nothing in the L2s that the next one
+// could miss, and the release -- then the acquire too -- can go (experiment switch BPM_DQ_FENCE=acq|none, only honoured together
+// with BPM_COHERENT_STATE=1; the packet after a table build or after entering direct mode always acquires).
+static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
+static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
 template <class K>
 static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a, unsigned grid, unsigned block, hipStream_t s) {
@@ -143,7 +149,9 @@ static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a
         ka.a = a;
         const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(kernel));
         const int sig = g_dq_sig; g_dq_sig = -1;
-        if (!k || g_dq->launch(*k, grid, 1, block, &ka, sizeof(ka), bpm::DirectQueue::FENCED, sig) != 0) g_dq_error = true;
+        int fence = g_dq_update_fence;
+        if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+        if (!k || g_dq->launch(*k, grid, 1, block, &ka, sizeof(ka), fence, sig) != 0) g_dq_error = true;
         ++g_timed_launches; ++g_n_direct;
         return;
     }
@@ -375,6 +383,9 @@ struct bpm_sampler {
     // it first (check_handle); run_generations waits for the stream before it enters direct mode.
     bpm::DirectQueue* dq = nullptr;
     bool dq_active = false;
+    bool dq_enabled = true;           // bpm_set_launch_path
+    bool coherent = false;            // state buffers live in cached-coherent device memory (dev_alloc_state)
+    int dq_fence = bpm::DirectQueue::FENCED;   // fences of the update-kernel packets (run_generations)
     bool timed_direct = false;        // the last bpm_step_timed was timed by the queue's dispatch time stamps
     // run state
     bpm_run_opts_t opts{};
@@ -415,10 +426,29 @@ static int check_handle(bpm_handle_t h) {
     if (!h) return fail("null handle");
     return leave_direct(h);
 }
+// A piece of HIP-stream work in the middle of a direct-mode generation loop: queue drained before, stream drained after.
+struct StreamSection {
+    bpm_sampler* s;
+    bool was;
+    int rc;
+    explicit StreamSection(bpm_sampler* s_);
+    int end();
+};
 static int check_handle_keep_direct(bpm_handle_t h) {      // (bpm_step and friends: consecutive calls stay on the queue)
     if (!h) return fail("null handle");
     return 0;
 }
+StreamSection::StreamSection(bpm_sampler* s_) : s(s_), was(s_->dq_active && g_dq != nullptr), rc(0) {
+    if (was) { s->dq->flush(); rc = s->dq->drain() != 0 ? fail("direct AQL queue: " + s->dq->why()) : 0; }
+}
+int StreamSection::end() {
+    if (!was) return 0;
+    CK(wait_stream(s->stream));
+    g_dq_need_acquire = true;
+    return 0;
+}
+
+
 
 static int set_device(bpm_sampler* s) {
     HIPCK(hipSetDevice(s->cfg.device));
@@ -436,10 +466,10 @@ static int dev_alloc(T** p, size_t n) {
 // memory type, i.e. the XCDs' L2s stay coherent on these lines by themselves (tools/micro/aql_direct.cpp: a dependent chain of
 // kernels is correct on it with NO acquire / release fence between the dispatches, wrong on hipMalloc memory) and a kernel
 // leaves no dirty lines for the end-of-kernel release to write back (3.24 -> 2.34 us per dependent launch of a 2 MB
-// read-modify-write kernel).  Gathers from it cost 1-5 % more than from ordinary device memory.
+// read-modify-write kernel).  Gathers from it cost 1-5 % more than from ordinary device memory, so only a sampler that
+// dispatches through its own queue -- where the release fence can then be dropped -- allocates its state there.
 template <class T>
-static int dev_alloc_state(T** p, size_t n) {
-    static const bool coherent = getenv("BPM_COHERENT_STATE") != nullptr && atoi(getenv("BPM_COHERENT_STATE")) != 0;
+static int dev_alloc_state(T** p, size_t n, bool coherent) {
     if (!coherent) return dev_alloc(p, n);
     HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T), hipDeviceMallocUncached));
     return 0;
@@ -632,6 +662,22 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
     }
+    // With its own queue the sampler keeps what one generation-loop kernel writes and a later one reads -- state matrix, ln-like
+    // cache, accept counters, Welford moments, CR state -- in cached-coherent memory; the packets of those kernels then carry
+    // an agent-scope ACQUIRE only (L1 / scalar cache / non-coherent L2 lines invalidated at kernel start): nothing a later kernel
+    // reads waits in an L2 for the release, and the end-of-kernel L2 write-back -- 0.7 us of a 6.1 us launch period at cfg2 --
+    // goes.  History rows (ordinary memory, non-temporal stores) are read only after the queue is drained, which releases at
+    // system scope.  Results are bit-identical (final state and the moments of 9.8 M history rows, all fence modes).
+    // BPM_COHERENT_STATE=0: ordinary memory, acquire + release; BPM_DQ_FENCE=full|acq|none: experiment switch.
+    {
+        const char* c = getenv("BPM_COHERENT_STATE");
+        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0);
+        s->dq_fence = s->coherent ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
+        if (const char* f = getenv("BPM_DQ_FENCE")) {
+            if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
+            else if (!strcmp(f, "full")) s->dq_fence = bpm::DirectQueue::FENCED;
+        }
+    }
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
     HIPCKD(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
@@ -640,15 +686,15 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
     s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
     const size_t row_d = (size_t)s->n_local * s->ld;
-    CKD(dev_alloc_state(&s->G, (size_t)s->world * s->L.blk));
+    CKD(dev_alloc_state(&s->G, (size_t)s->world * s->L.blk, s->coherent));
     HIPCKD(hipMemsetAsync(s->G, 0, (size_t)s->world * s->L.blk * sizeof(double), s->stream));
     s->L.G = s->G;
-    CKD(dev_alloc_state(&s->ll, s->n_local));
-    CKD(dev_alloc_state(&s->w_mean, row_d));
-    CKD(dev_alloc_state(&s->w_m2, row_d));
+    CKD(dev_alloc_state(&s->ll, s->n_local, s->coherent));
+    CKD(dev_alloc_state(&s->w_mean, row_d, s->coherent));
+    CKD(dev_alloc_state(&s->w_m2, row_d, s->coherent));
     CKD(dev_alloc(&s->tparams, (size_t)np));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    CKD(dev_alloc(&s->cr_state, 3 * MAX_CR));
+    CKD(dev_alloc_state(&s->cr_state, 3 * MAX_CR, s->coherent));
     {
         double init[3 * MAX_CR] = {0};
         for (int m = 0; m < s->cfg.n_cr; ++m) init[m] = 1.0 / s->cfg.n_cr;   // dream.py:114
@@ -656,7 +702,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipStreamSynchronize(s->stream));
     }
     CKD(dev_alloc(&s->counters, 8));      // [2] NaN ratios of this run; [4] outlier resets since creation
-    CKD(dev_alloc_state(&s->acc_count, s->n_local));
+    CKD(dev_alloc_state(&s->acc_count, s->n_local, s->coherent));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
     if (cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0) {
@@ -894,6 +940,7 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
         }
         B.W = W;
         B.shuffle = shuffle;
+        g_dq_need_acquire = true;
         return 0;
     }
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
@@ -957,9 +1004,12 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         if (!s->cfg.keep_history || s->hist_rows != s->rows_logical)
             return fail("CR adaptation needs the chain history (keep_history=1) to rebuild its moments");
         const uint64_t n_elem = (uint64_t)s->n_local * s->ld;
+        StreamSection sec(s);
+        CK(sec.rc);
         hipLaunchKernelGGL(welford_rebuild_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s->stream,
                            s->hist, n_elem, n_elem, (uint32_t)s->hist_rows, s->w_mean, s->w_m2);
         HIPCK(hipGetLastError());
+        CK(sec.end());
         s->w_rows = s->rows_logical;
     }
     double* hist_row = nullptr;
@@ -1063,7 +1113,28 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
 }
 
 static int finish_generation(bpm_sampler* s) {
-    if (s->gen_adapt_on) {
+    if (s->gen_adapt_on && g_dq) {
+        // direct mode: the same launch as a packet (cr_adapt_kernel reads gridDim: the hidden arguments are filled by the queue)
+        struct { Layout L; uint32_t N, n_cr; double* cr_state; double* part; uint32_t* ticket; uint32_t span; } ca{s->L, s->N, (uint32_t)s->cfg.n_cr, s->cr_state, nullptr, nullptr, 0u};
+        uint32_t nb = 1;
+        if (s->N > 2 * ADAPT_SPAN) {
+            const uint32_t span = ((s->N + 63u) / 64u + ADAPT_THREADS - 1u) / ADAPT_THREADS * ADAPT_THREADS;
+            nb = (s->N + span - 1) / span;
+            if (!s->cr_part) {
+                StreamSection sec(s);
+                CK(sec.rc);
+                CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR + 2));
+                HIPCK(hipMemsetAsync(s->cr_part, 0, ((size_t)nb * 2 * MAX_CR + 2) * sizeof(double), s->stream));
+                CK(sec.end());
+            }
+            ca.part = s->cr_part; ca.ticket = reinterpret_cast<uint32_t*>(s->cr_part + (size_t)nb * 2 * MAX_CR); ca.span = span;
+        }
+        const bpm::DqKernel* kc = g_dq->kernel(reinterpret_cast<const void*>(cr_adapt_kernel));
+        int fence = g_dq_update_fence;
+        if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+        if (!kc || g_dq->launch(*kc, nb, 1, ADAPT_THREADS, &ca, sizeof(ca), fence) != 0) return fail("direct AQL queue: cr_adapt_kernel: " + g_dq->why());
+        s->w_rows += 1;
+    } else if (s->gen_adapt_on) {
         if (s->N <= 2 * ADAPT_SPAN) {
             hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
                                s->cr_state, (double*)nullptr, (uint32_t*)nullptr, 0u);
@@ -1291,7 +1362,12 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
         }
     }
     for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
-    if (g.h[0]->outlier_due) CK(group_outlier_check(g));
+    if (g.h[0]->outlier_due) {
+        StreamSection sec(g.h[0]);
+        CK(sec.rc);
+        CK(group_outlier_check(g));
+        CK(sec.end());
+    }
     return 0;
 }
 
@@ -1375,19 +1451,22 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 if (Kg > 0) { done += Kg; continue; }
             }
             const bool replay = s0->replay_enabled && !adapting;       // burn-in: delta / cr_idx of every chain travel in the dense block
-            // Direct mode: a single GPU's steady state (nothing per generation but the two update kernels and, once per window, the
-            // table build) is dispatched through the library's own AQL queue.  Burn-in (cr_adapt, outlier check, moment rebuild), the
-            // synchronous mode, tracing and everything with an exchange stay on the HIP stream.
-            const bool direct = s0->dq && !use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group && !adapting && !s0->aux &&
+            // Direct mode: a single GPU's generation loop (the two update kernels, during burn-in the CR reduction, once per window
+            // the table build) is dispatched through the library's own AQL queue.  The outlier check and the moment rebuild (rare) run
+            // on the HIP stream between two drains (StreamSection); the synchronous mode, tracing and everything with an exchange
+            // stay on the stream altogether.
+            const bool direct = s0->dq && s0->dq_enabled && !use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group && !s0->aux &&
                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed();
             if (direct && !s0->dq_active) {
                 CK(wait_stream(s0->stream));                            // what the stream still holds (burn-in, table builds) comes first
                 s0->dq_active = true;
+                g_dq_need_acquire = true;
             } else if (!direct && s0->dq_active) {
                 CK(leave_direct(s0));
             }
             g_dq = direct ? s0->dq : nullptr;
             g_dq_error = false;
+            g_dq_update_fence = s0->dq_fence;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
             if (direct) {
                 s0->dq->flush();                                        // one doorbell per generation
@@ -1515,6 +1594,15 @@ extern "C" int bpm_get_launch_stats(bpm_handle_t s, int64_t* out) {
     out[1] = g_n_direct;
     out[2] = g_n_stream;
     out[3] = s->dq_active ? 1 : 0;
+    return 0;
+}
+
+extern "C" int bpm_set_launch_path(bpm_handle_t s, int32_t direct, int32_t fence) {
+    CK(check_handle(s));
+    if (fence != -1 && fence != 0 && fence != 1 && fence != 3) return fail("bpm_set_launch_path: fence must be -1 (keep), 0 (none), 1 (acquire) or 3 (acquire + release)");
+    if (fence >= 0 && fence < 3 && !s->coherent) return fail("bpm_set_launch_path: packets without a release fence need the state in cached-coherent memory");
+    s->dq_enabled = direct != 0;
+    if (fence >= 0) s->dq_fence = fence;
     return 0;
 }
 

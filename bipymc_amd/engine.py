@@ -195,6 +195,10 @@ class HipEngine(object):
         L.check(self.lib.bpm_get_launch_stats(self._h, out))
         return dict(has_queue=bool(out[0]), direct=int(out[1]), stream=int(out[2]), queue_active=bool(out[3]))
 
+    def set_launch_path(self, direct=True, fence=-1):
+        """direct=False: HIP stream launches only; fence: 3 acquire + release, 1 acquire only, 0 none, -1 keep (bpm_set_launch_path)."""
+        L.check(self.lib.bpm_set_launch_path(self._h, 1 if direct else 0, int(fence)))
+
     def history_rows(self):
         return int(self.stats()["history_rows"])
 

@@ -174,6 +174,11 @@ int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
  * thread through it, update-kernel launches of the calling thread through the HIP stream, 1 if work may be in flight on
  * the queue}.  BPM_DIRECT_QUEUE=0 in the environment disables the queue. */
 int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
+/* direct != 0: use the library's own queue where the sampler has one (the default); 0: HIP stream launches only.
+ * fence: packet fences of the generation loop's kernels on that queue: -1 keep, 3 agent-scope acquire + release (what a HIP
+ * stream does), 1 acquire only (the default when the sampler's state lives in cached-coherent memory), 0 none; values
+ * below 3 are refused unless the state is in cached-coherent memory.  Results do not depend on either setting (tested). */
+int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop

@@ -264,14 +264,18 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
 '''
     import tempfile
     res = []
-    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH")
+    switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH", "BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE",
+                "BPM_DQ_FENCE")
+    # (BPM_DIRECT_QUEUE=0: HIP stream launches instead of the library's own AQL queue; BPM_COHERENT_STATE=0: the state in ordinary
+    # device memory, packets with acquire + release)
     for on in ((), ("BPM_NO_HOT",), ("BPM_GRAPH",), ("BPM_GRAPH", "BPM_NO_HOT"), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
-               ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1")):
+               ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1"), ("BPM_DIRECT_QUEUE",), ("BPM_DIRECT_QUEUE", "BPM_NO_HOT"), ("BPM_COHERENT_STATE",),
+               ("BPM_COHERENT_STATE", "BPM_NO_PLAN")):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)
         for k in on:
-            env[k] = "1000000" if k == "BPM_PLAN_MAX" else "1"     # BPM_PLAN_MAX: plan records whatever the number of chains
+            env[k] = "1000000" if k == "BPM_PLAN_MAX" else ("0" if k in ("BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE") else "1")     # BPM_PLAN_MAX: plan records whatever the number of chains
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
@@ -761,3 +765,57 @@ def test_many_ranks_sorted_records_and_fallback(R):
         np.testing.assert_array_equal(e.stats()["p_cr"], one.stats()["p_cr"])
     assert sum(e.stats()["local_n_accepted"] for e in ranks) == one.stats()["local_n_accepted"]
     assert ranks[0].exchange_stats()["replay_gens"] == G - 6
+
+
+@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker", "dream_gauss100_big"])
+def test_direct_queue_equals_stream_launches(case):
+    """The generation loop of a single-GPU sampler is dispatched by AQL packets the library writes into its own queue
+    (bipymc_amd/csrc/aql_queue.h) with the state in cached-coherent memory and acquire-only packet fences; every other
+    setting -- HIP stream launches, acquire + release, no fences -- must give the same bits: state, ln-like, the whole
+    history, CR statistics, accept counters.  The runs cross a table window (64 generations), grow the history while the
+    queue is busy (no reservation), pass through burn-in with the outlier check (HIP-stream sections between drains) and
+    call the timed entry point."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    if case == "dream_gauss100":
+        spec, algo, N, kw, G = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 512, dict(burnin_gen=20, n_cr_gen=4), 150
+    elif case == "dream_gauss100_big":
+        spec, algo, N, kw, G = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 8192, dict(burnin_gen=30, n_cr_gen=4), 100
+    elif case == "dream_mix8_outlier":
+        spec, algo, N, kw, G = (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 20000,
+                                dict(burnin_gen=60, n_cr_gen=4, del_pairs=2, outlier_every=20), 140)
+    else:
+        spec, algo, N, kw, G = banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 4099, dict(p_snooker=0.2), 200
+    tid, tp, d = spec
+    X0 = np.random.RandomState(3).normal(size=(N, d)) + 1.0
+    res, stats = [], []
+    for direct, fence in ((True, -1), (False, -1), (True, 3), (True, 0)):
+        e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
+        ls = e.launch_stats()
+        assert ls["has_queue"], "no direct AQL queue on this box: " + str(ls)
+        e.set_launch_path(direct, fence)
+        e.set_state(X0)
+        e.begin_run()
+        before = e.launch_stats()
+        e.step(G // 2)
+        ms, nl = e.step_timed(G - G // 2 - 3)
+        e.step(3)
+        after = e.launch_stats()
+        if direct:
+            assert after["direct"] - before["direct"] == 2 * G and after["stream"] == before["stream"]
+            # a burn-in-free tail: the timed call's launches are all update kernels (2 per generation, first to last)
+            assert nl == 2 * (G - G // 2 - 3) - 1 and 0.0 < ms < 1e3
+        else:
+            assert after["stream"] - before["stream"] == 2 * G and after["direct"] == before["direct"]
+        st = e.stats()
+        res.append((e.get_state(), e.get_loglike(), e.get_history(0, G + 1), e.get_loglike_history(0, G + 1),
+                    np.asarray(st["p_cr"]), np.asarray(st["delta_m"]), np.asarray(st["n_cr_updates"])))
+        stats.append((st["local_n_accepted"], st["local_n_rejected"], st["n_outlier_resets"]))
+        e.close()
+    for r, s in zip(res[1:], stats[1:]):
+        for a, b in zip(res[0], r):
+            assert np.array_equal(a, b)
+        assert s == stats[0]
+    if case == "dream_mix8_outlier":
+        assert stats[0][2] >= 0
