@@ -89,7 +89,7 @@ class DirectQueue {
         const size_t hidden_at = (nbytes + 7) & ~size_t(7);
         const bool hidden = k.kernarg_size >= hidden_at + 66;
         if (nbytes > k.kernarg_size || k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
-        if (!wait_for_room()) return -1;
+        if (!next_slot()) return -1;
         char* slot = kernarg_ + (size_t)(widx_ % N_SLOTS) * SLOT_BYTES;
         std::memcpy(slot, args, nbytes);
         size_t written = nbytes;
@@ -127,7 +127,9 @@ class DirectQueue {
         ++n_unpublished_;
         ++widx_;
         busy_ = true;
-        if (n_unpublished_ == MAX_UNPUBLISHED) flush();
+        // one doorbell never covers packets on both sides of the ring's end (a queue-intercepting tool -- rocprofv3 -- copies the
+        // packets of a doorbell as one linear range)
+        if (n_unpublished_ == MAX_UNPUBLISHED || (widx_ & (q_->size - 1)) == 0) flush();
         return 0;
     }
 
@@ -147,7 +149,7 @@ class DirectQueue {
     int drain(double timeout_s = 120.0) {
         if (!busy_) return 0;
         if (failed_) return -1;
-        if (!wait_for_room()) return -1;
+        if (!next_slot()) return -1;
         flush();
         auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
         std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
@@ -187,6 +189,7 @@ class DirectQueue {
 
   private:
     static constexpr uint32_t MAX_UNPUBLISHED = 8;
+    static constexpr uint32_t EPOCH = 256, N_EPOCH = QUEUE_PACKETS / EPOCH;
     struct Lookup { DirectQueue* self; std::string sym; DqKernel* out; bool found; };
 
     static hsa_status_t exe_cb(hsa_executable_t exe, void* data) {
@@ -252,21 +255,50 @@ class DirectQueue {
         (void)hsa_amd_profiling_set_profiler_enabled(q_, 1);
         if (hsa_signal_create(0, 0, nullptr, &done_) != HSA_STATUS_SUCCESS || hsa_signal_create(0, 0, nullptr, &tsig_[0]) != HSA_STATUS_SUCCESS ||
             hsa_signal_create(0, 0, nullptr, &tsig_[1]) != HSA_STATUS_SUCCESS) { why_ = "hsa_signal_create failed"; return false; }
+        for (auto& es : epoch_sig_) if (hsa_signal_create(0, 0, nullptr, &es) != HSA_STATUS_SUCCESS) { why_ = "hsa_signal_create failed"; return false; }
         uint64_t freq = 0;
         hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq);
         tick_ns_ = freq ? 1e9 / (double)freq : 10.0;
         widx_ = hsa_queue_load_write_index_relaxed(q_);
         return true;
     }
-    // room for one more packet: its kernarg slot was last used by a packet that has finished (every packet carries the
-    // barrier bit, so a packet the processor has taken off the ring means all before it are done)
-    bool wait_for_room() {
-        if (widx_ - hsa_queue_load_read_index_scacquire(q_) < (uint64_t)N_SLOTS - 8) return true;
-        flush();
-        const auto t0 = std::chrono::steady_clock::now();
-        while (widx_ - hsa_queue_load_read_index_scacquire(q_) >= (uint64_t)N_SLOTS - 8) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) { why_ = "timeout waiting for room in the AQL queue"; failed_ = true; return false; }
+    // widx_ names a free packet slot whose kernarg slot is free too.  Packet ring: the processor has taken the packet that used
+    // the slot before (read index).  Kernarg ring: the KERNEL that used the slot before has finished -- the read index does not
+    // say that (a packet is off the ring when it is launched, and under a queue-intercepting profiler when it is forwarded), so the
+    // last slot of every EPOCH of 256 packets is a barrier packet of the queue's own with a completion signal, and an epoch's
+    // slots are reused only after the marker that closed their previous use has completed.
+    bool next_slot() {
+        for (;;) {
+            if (widx_ - hsa_queue_load_read_index_scacquire(q_) >= (uint64_t)QUEUE_PACKETS - 8) {
+                flush();
+                const auto t0 = std::chrono::steady_clock::now();
+                while (widx_ - hsa_queue_load_read_index_scacquire(q_) >= (uint64_t)QUEUE_PACKETS - 8)
+                    if (timed_out(t0, "timeout waiting for room in the AQL queue")) return false;
+            }
+            const uint32_t pos = (uint32_t)(widx_ % EPOCH), e = (uint32_t)((widx_ / EPOCH) % N_EPOCH);
+            if (pos == 0 && epoch_armed_[e]) {
+                flush();
+                const auto t0 = std::chrono::steady_clock::now();
+                while (hsa_signal_load_scacquire(epoch_sig_[e]) > 0)
+                    if (timed_out(t0, "timeout waiting for an epoch of the AQL queue to finish")) return false;
+                epoch_armed_[e] = false;
+            }
+            if (pos != EPOCH - 1) return true;
+            auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
+            std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
+            hsa_signal_store_relaxed(epoch_sig_[e], 1);
+            epoch_armed_[e] = true;
+            b->completion_signal = epoch_sig_[e];
+            pending_header_[n_unpublished_] = (uint32_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+            pending_packet_[n_unpublished_] = reinterpret_cast<uint32_t*>(b);
+            ++n_unpublished_;
+            ++widx_;
+            if (n_unpublished_ >= MAX_UNPUBLISHED - 1 || (widx_ & (q_->size - 1)) == 0) flush();
         }
+    }
+    bool timed_out(std::chrono::steady_clock::time_point t0, const char* what) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) return false;
+        why_ = what; failed_ = true;
         return true;
     }
 
@@ -275,7 +307,8 @@ class DirectQueue {
     hsa_queue_t* q_ = nullptr;
     char* kernarg_ = nullptr;
     uint64_t widx_ = 0;
-    hsa_signal_t done_{}, tsig_[2]{};
+    hsa_signal_t done_{}, tsig_[2]{}, epoch_sig_[N_EPOCH]{};
+    bool epoch_armed_[N_EPOCH] = {};
     bool tsig_armed_[2] = {false, false};
     double tick_ns_ = 10.0;
     bool busy_ = false, failed_ = false, hsa_inited_ = false;
