@@ -50,7 +50,14 @@ constexpr int WAVE = 64;
 // wavefront per workgroup is best for one-wavefront-per-chain (d=100) and one-lane-per-chain (d=2) kernels, four
 // wavefronts for the 4-lanes-per-chain kernel (d=8: 14.8 vs 17.0 us/generation at N=32768).
 // (re-measured with the final kernel: 128- or 256-thread workgroups for one wavefront per chain stay within 1 % of 64)
-constexpr int block_for(int lpc) { return (lpc == 4 || lpc == 16) ? 256 : 64; }
+// Workgroup size of the one-wavefront-per-chain and one-lane-per-chain shapes.  Two wavefronts per workgroup halve the number of
+// workgroups the dispatcher has to place: 11.00 vs 11.35 us per generation at cfg2, 13.66 vs 13.94 at cfg3 once launches are no longer
+// host-paced (round 2, direct queue; under HIP launches round 1 measured no difference).  256 is as good at cfg2 and worse for one lane
+// per chain (15.5 us at cfg3: too few workgroups).  The kernels use no barrier and no cross-wavefront LDS in these shapes.
+#ifndef BPM_BLOCK_WAVE
+#define BPM_BLOCK_WAVE 128
+#endif
+constexpr int block_for(int lpc) { return (lpc == 4 || lpc == 16) ? 256 : BPM_BLOCK_WAVE; }
 constexpr int MAX_CR = 8;
 constexpr int TRACE_I32 = 32;   // ints per chain in the debug trace
 constexpr int TRACE_F64 = 4;
