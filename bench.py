@@ -276,7 +276,8 @@ def main():
                        "exchange": eng.exchange_stats() if use_dist else None,
                        # how the update kernels were dispatched: packets written by the library into its own AQL queue
                        # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (burn-in, multi-GPU, BPM_DIRECT_QUEUE=0)
-                       "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"]},
+                       "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"],
+                                             "state_in_hw_coherent_memory": lstat["coherent_state"], "packet_fence": lstat["fence"]},
                        "final_state_sha256_16": state_sha},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

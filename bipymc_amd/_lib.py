@@ -71,6 +71,7 @@ SIGNATURES = {
     "bpm_get_exchange_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_get_launch_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_set_launch_path": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "bpm_debug_coherence_probe": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_int64)]),
     "bpm_set_history": (C.c_int, [_H, C.c_int64, _dp, _dp]),
     "bpm_reduce_moments": (C.c_int, [_H, C.c_int64, _dp, _dp, _dp, _P(C.c_int64)]),
     "bpm_propose": (C.c_int, [_H, _dp, _ip, _ip]),

@@ -1326,6 +1326,14 @@ __global__ __launch_bounds__(WAVE) void exchange_scatter_kernel(Layout L, double
     for (uint32_t j = threadIdx.x; j < L.ld; j += WAVE) dst[j] = src[j];
 }
 
+// Probe of the memory type the sampler's state is allocated from (sampler.hip: state_memory_is_coherent): launch number `shift` lets
+// workgroup b own block (b + shift) mod nb of x, so every block is touched by a different workgroup -- a different XCD, a different
+// L2 -- in every launch, and x[i] == number of launches afterwards only if each launch saw what the previous one wrote.
+__global__ __launch_bounds__(WAVE) void coherence_probe_kernel(double* x, uint32_t nb, uint32_t shift) {
+    const uint32_t b = (blockIdx.x + shift) % nb;
+    x[b * WAVE + threadIdx.x] += 1.0;
+}
+
 // Shuffle orders of K consecutive generations in one launch: tab[g*N + k] = pi_g(k), inv[g*N + pi_g(k)] = k.
 // The update kernels then look partners up (one 4-byte load) instead of walking the Feistel network
 // (~100 instructions per id, and the kernels are instruction-issue bound).

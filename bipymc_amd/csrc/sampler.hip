@@ -21,6 +21,8 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -475,6 +477,44 @@ static int dev_alloc_state(T** p, size_t n, bool coherent) {
     return 0;
 }
 
+// Does memory from dev_alloc_state really stay coherent across the XCDs without a release fence?  What hipDeviceMallocUncached maps
+// to is the runtime's choice (hsa_amd_pointer_info reports the same flags for it as for plain fine-grained memory, which is NOT
+// coherent that way), so the property itself is tested once per device: 48 dependent dispatches with acquire-only packets hand
+// every block of a 2 MB buffer from workgroup to workgroup; ordinary memory fails this in every element (tools/micro/aql_direct.cpp).
+// -> number of wrong elements (0 = every launch saw its predecessor's writes), -1 = the probe could not run
+static long long coherence_probe(bpm::DirectQueue* dq, bool coherent_alloc) {
+    constexpr uint32_t NB = 4096, L = 48;
+    double* x = nullptr;
+    long long wrong = -1;
+    const bpm::DqKernel* k = dq->kernel(reinterpret_cast<const void*>(coherence_probe_kernel));
+    if (k && dev_alloc_state(&x, (size_t)NB * WAVE, coherent_alloc) == 0) {
+        std::vector<double> h((size_t)NB * WAVE);
+        bool run = hipMemset(x, 0, h.size() * sizeof(double)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        for (uint32_t i = 0; i < L && run; ++i) {
+            struct { double* x; uint32_t nb, shift; } a{x, NB, 7u * i};
+            run = dq->launch(*k, NB, 1, WAVE, &a, sizeof(a), i == 0 ? bpm::DirectQueue::FENCED : bpm::DirectQueue::ACQUIRE) == 0;
+        }
+        run = run && dq->drain() == 0 && hipMemcpy(h.data(), x, h.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        if (run) {
+            wrong = 0;
+            for (double v : h) wrong += v != (double)L;
+        }
+        (void)hipGetLastError();
+    }
+    if (x) (void)hipFree(x);
+    return wrong;
+}
+static bool state_memory_is_coherent(bpm::DirectQueue* dq, int device) {
+    static std::mutex mu;
+    static std::map<int, bool> known;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    const bool ok = coherence_probe(dq, true) == 0;
+    known[device] = ok;
+    return ok;
+}
+
 static int ensure_history(bpm_sampler* s, int64_t rows) {
     if (!s->cfg.keep_history) rows = std::min<int64_t>(rows, 1);
     if (rows <= s->hist_cap) return 0;
@@ -671,7 +711,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // BPM_COHERENT_STATE=0: ordinary memory, acquire + release; BPM_DQ_FENCE=full|acq|none: experiment switch.
     {
         const char* c = getenv("BPM_COHERENT_STATE");
-        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0);
+        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0) && state_memory_is_coherent(s->dq, cfg->device);
         s->dq_fence = s->coherent ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
         if (const char* f = getenv("BPM_DQ_FENCE")) {
             if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
@@ -1594,6 +1634,20 @@ extern "C" int bpm_get_launch_stats(bpm_handle_t s, int64_t* out) {
     out[1] = g_n_direct;
     out[2] = g_n_stream;
     out[3] = s->dq_active ? 1 : 0;
+    out[4] = s->coherent ? 1 : 0;
+    out[5] = s->dq_fence;
+    return 0;
+}
+
+// Test hook: the probe behind the choice of packet fences, on the memory type the state would use (coherent_alloc != 0) or on
+// ordinary device memory.  *wrong = elements that missed an update (0 = coherent without a release fence), -1 = could not run.
+extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc, int64_t* wrong) {
+    if (!wrong) return fail("bpm_debug_coherence_probe: null argument");
+    HIPCK(hipSetDevice(device));
+    bpm::DirectQueue* dq = bpm::DirectQueue::for_device(device);
+    *wrong = -1;
+    if (!dq) return 0;
+    *wrong = coherence_probe(dq, coherent_alloc != 0);
     return 0;
 }
 

@@ -191,9 +191,10 @@ class HipEngine(object):
 
     def launch_stats(self):
         """How the update kernels were dispatched: the library's own AQL queue or the HIP stream (bpm_get_launch_stats)."""
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 6)()
         L.check(self.lib.bpm_get_launch_stats(self._h, out))
-        return dict(has_queue=bool(out[0]), direct=int(out[1]), stream=int(out[2]), queue_active=bool(out[3]))
+        return dict(has_queue=bool(out[0]), direct=int(out[1]), stream=int(out[2]), queue_active=bool(out[3]),
+                    coherent_state=bool(out[4]), fence={3: "acquire+release", 1: "acquire", 0: "none"}.get(int(out[5]), int(out[5])))
 
     def set_launch_path(self, direct=True, fence=-1):
         """direct=False: HIP stream launches only; fence: 3 acquire + release, 1 acquire only, 0 none, -1 keep (bpm_set_launch_path)."""

@@ -170,15 +170,21 @@ int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 /* How the generation loop's kernels reach the GPU (no counterpart in the reference: its loop is the Python interpreter,
  * demc.py:79-140).  A single-GPU sampler with a device target dispatches its steady state through the library's own
  * user-mode AQL queue (packets written by the library, bipymc_amd/csrc/aql_queue.h); burn-in, exchanges and every other
- * entry point use the HIP stream.  out[4] = {1 if the sampler has such a queue, update-kernel dispatches of the calling
+ * entry point use the HIP stream.  out[6] = {1 if the sampler has such a queue, update-kernel dispatches of the calling
  * thread through it, update-kernel launches of the calling thread through the HIP stream, 1 if work may be in flight on
- * the queue}.  BPM_DIRECT_QUEUE=0 in the environment disables the queue. */
+ * the queue, 1 if the sampler's state lives in hardware-coherent device memory (verified with hsa_amd_pointer_info), packet
+ * fences of the generation loop's kernels on the queue: 3 acquire + release, 1 acquire only, 0 none}.
+ * BPM_DIRECT_QUEUE=0 in the environment disables the queue. */
 int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
 /* direct != 0: use the library's own queue where the sampler has one (the default); 0: HIP stream launches only.
  * fence: packet fences of the generation loop's kernels on that queue: -1 keep, 3 agent-scope acquire + release (what a HIP
  * stream does), 1 acquire only (the default when the sampler's state lives in cached-coherent memory), 0 none; values
  * below 3 are refused unless the state is in cached-coherent memory.  Results do not depend on either setting (tested). */
 int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
+/* Test hook: the probe that decides whether packets may go without a release fence -- 48 dependent dispatches with
+ * acquire-only packets hand every block of a 2 MB buffer from workgroup to workgroup (XCD to XCD); *wrong = elements that
+ * missed an update, -1 if there is no queue.  coherent_alloc != 0: the memory type the sampler's state uses; 0: hipMalloc. */
+int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc, int64_t* wrong);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop

@@ -794,6 +794,7 @@ def test_direct_queue_equals_stream_launches(case):
         e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
         ls = e.launch_stats()
         assert ls["has_queue"], "no direct AQL queue on this box: " + str(ls)
+        assert ls["coherent_state"] and ls["fence"] == "acquire", ls      # (the default: hardware-coherent state, no release fence)
         e.set_launch_path(direct, fence)
         e.set_state(X0)
         e.begin_run()
@@ -819,3 +820,17 @@ def test_direct_queue_equals_stream_launches(case):
         assert s == stats[0]
     if case == "dream_mix8_outlier":
         assert stats[0][2] >= 0
+
+
+def test_coherence_probe_discriminates_memory_types():
+    """What lets the generation loop's packets go without a release fence is a property of the memory the state lives in, probed
+    once per device (sampler.hip: state_memory_is_coherent).  The probe must pass on that memory type and FAIL on ordinary
+    device memory (eight XCDs with an L2 each: without the release a block written on one XCD is read stale on another)."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    lib = L.load()
+    w = C.c_int64(-2)
+    L.check(lib.bpm_debug_coherence_probe(0, 1, C.byref(w)))
+    assert w.value == 0, "state memory type is not coherent across XCDs without a release fence: %d wrong" % w.value
+    L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w)))
+    assert w.value > 0, "ordinary device memory passed the probe: it no longer discriminates (%d)" % w.value
