@@ -64,6 +64,7 @@ class DirectQueue {
 
     // the kernel HIP would launch for this host function, as the dispatch packet names it; nullptr if it cannot be located
     const DqKernel* kernel(const void* host_fn) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         auto it = kernels_.find(host_fn);
         if (it != kernels_.end()) return it->second.object ? &it->second : nullptr;
         DqKernel k;
@@ -86,6 +87,7 @@ class DirectQueue {
     // fence: ACQUIRE | RELEASE at agent scope (what a HIP stream puts around every kernel).  sig: 0 / 1 = this dispatch
     // carries timing signal 0 / 1 (see dispatch_end_ns), -1 = none.  The doorbell is rung by flush().
     int launch(const DqKernel& k, uint32_t grid_x, uint32_t grid_y, uint32_t block, const void* args, size_t nbytes, int fence, int sig = -1) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);          // (samplers of several threads may share a device's queue; uncontended: ~20 ns)
         if (failed_) return -1;
         const size_t hidden_at = (nbytes + 7) & ~size_t(7);
         const bool hidden = k.kernarg_size >= hidden_at + 66;
@@ -137,6 +139,7 @@ class DirectQueue {
     // publish what launch() has written: arguments first (store fence + read-back through the BAR: the posted writes have
     // reached device memory), then the packet headers, then the doorbell
     void flush() {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         if (n_unpublished_ == 0) return;
         _mm_sfence();
         if (last_written_) { const uint32_t sink = *last_written_; (void)sink; }
@@ -148,6 +151,7 @@ class DirectQueue {
 
     // everything dispatched so far has finished and is visible to the host and to HIP streams (system-scope release)
     int drain(double timeout_s = 120.0) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         if (!busy_) return 0;
         if (failed_) return -1;
         if (!next_slot()) return -1;
@@ -178,6 +182,7 @@ class DirectQueue {
 
     // end-of-kernel time stamps (ns, one clock) of the dispatches that carried timing signal 0 and 1; call after drain()
     bool dispatch_end_ns(double* t0_ns, double* t1_ns) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
         if (!tsig_armed_[0] || !tsig_armed_[1]) return false;
         hsa_amd_profiling_dispatch_time_t a{}, b{};
         if (hsa_amd_profiling_get_dispatch_time(agent_, tsig_[0], &a) != HSA_STATUS_SUCCESS) return false;
@@ -318,6 +323,7 @@ class DirectQueue {
     uint32_t* pending_packet_[MAX_UNPUBLISHED]{};
     volatile uint32_t* last_written_ = nullptr;
     std::string why_;
+    std::recursive_mutex mu_;
     std::map<const void*, DqKernel> kernels_;
 };
 
