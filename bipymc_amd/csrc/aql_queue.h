@@ -91,7 +91,8 @@ class DirectQueue {
         if (failed_) return -1;
         const size_t hidden_at = (nbytes + 7) & ~size_t(7);
         const bool hidden = k.kernarg_size >= hidden_at + 66;
-        if (nbytes > k.kernarg_size || k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
+        if (nbytes > k.kernarg_size) nbytes = k.kernarg_size;       // (a kernel that ignores trailing arguments has a shorter segment)
+        if (k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
         if (!next_slot()) return -1;
         char* slot = kernarg_ + (size_t)(widx_ % N_SLOTS) * SLOT_BYTES;
         std::memcpy(slot, args, nbytes);

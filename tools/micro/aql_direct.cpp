@@ -71,11 +71,11 @@ static inline uint16_t header(int barrier, int acq, int rel) {
     return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier << HSA_PACKET_HEADER_BARRIER) |
                       (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
 }
-static inline void write_packet(const Kernel& k, uint32_t grid_wg, void* kernarg, uint16_t hdr, hsa_signal_t sig) {
+static inline void write_packet(const Kernel& k, uint32_t grid_wg, void* kernarg, uint16_t hdr, hsa_signal_t sig, uint32_t block = 64) {
     auto* base = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(g_q->base_address);
     hsa_kernel_dispatch_packet_t* p = base + (g_widx & (g_q->size - 1));
-    p->workgroup_size_x = 64; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
-    p->grid_size_x = grid_wg * 64u; p->grid_size_y = 1; p->grid_size_z = 1;
+    p->workgroup_size_x = (uint16_t)block; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
+    p->grid_size_x = grid_wg * block; p->grid_size_y = 1; p->grid_size_z = 1;
     p->private_segment_size = k.priv; p->group_segment_size = k.group;
     p->kernel_object = k.object; p->kernarg_address = kernarg; p->reserved2 = 0; p->completion_signal = sig;
     const uint32_t first = (uint32_t)hdr | ((uint32_t)(3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16);
@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
                                 {"barrier, no fences             ", 1, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE},
                                 {"no barrier, no fences (overlap)", 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE}};
     printf("%-34s %-10s %-22s %-12s %10s  %s\n", "packet header", "kernarg", "kernel", "doorbell", "us/launch", "check");
-    const bool part1 = !(argc > 2 && !strcmp(argv[2], "mem"));
+    const bool part1 = !(argc > 2 && (!strcmp(argv[2], "mem") || !strcmp(argv[2], "p4")));
     const bool full = argc > 2 && !strcmp(argv[2], "full");
     for (int where = (bar && !full) ? 1 : 0; part1 && where < (bar ? 2 : 1); ++where) {
         char* ka = where ? ka_dev : ka_host;
@@ -202,9 +202,10 @@ int main(int argc, char** argv) {
         }
     }
 
+    const bool only4 = argc > 2 && !strcmp(argv[2], "p4");
     // ---- part 2: the data in other kinds of device memory (plain kernels): does memory the L2 does not keep non-coherent
     // copies of make a fence-less boundary correct, and what do its reads cost?
-    if (bar) {
+    if (bar && !only4) {
         struct Mem { const char* name; hsa_amd_memory_pool_t pool; uint32_t flags; };
         const Mem mems[] = {{"coarse-grained", g_gpu_pool, 0}, {"coarse + UNCACHED flag", g_gpu_pool, HSA_AMD_MEMORY_POOL_UNCACHED_FLAG},
                             {"fine-grained", g_gpu_fine_pool, 0}, {"fine + UNCACHED flag", g_gpu_fine_pool, HSA_AMD_MEMORY_POOL_UNCACHED_FLAG},
@@ -261,7 +262,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- part 3: the data allocated by HIP (the product's allocator), kernels still through this program's own queue
-    if (bar) {
+    if (bar && !only4) {
         struct HMem { const char* name; int kind; };
         const HMem hm[] = {{"hipMalloc", 0}, {"hipExtMalloc Finegrained", 1}, {"hipExtMalloc Uncached", 2}};
         printf("\n%-26s %-34s %-22s %10s  %s\n", "data memory (HIP)", "packet header", "kernel", "us/launch", "check");
@@ -315,6 +316,99 @@ int main(int argc, char** argv) {
                 }
             }
             hipFree(mx); hipFree(mtab);
+        }
+    }
+
+    // ---- part 4: what does a THIRD, tiny kernel cost behind two heavy ones (the burn-in generation: update, update, cr_adapt)?
+    if (bar) {
+        const Kernel k_e1024 = get_kernel(exe, "k_empty_1024");
+        printf("\n%-60s %10s\n", "chain of dependent dispatches (acquire-only packets), per round", "us/round");
+        for (int pattern = 0; pattern < 5; ++pattern) {
+            // 0: gather, gather   1: gather, gather, empty 1x64   2: gather, gather, empty 1x1024 (10 KB LDS)   3: empty 1x1024 alone  4: gather, gather, empty 16x64
+            const int per_round = pattern == 0 ? 2 : (pattern == 3 ? 1 : 3);
+            const int rounds = 600;
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                hsa_signal_store_relaxed(g_done, 1);
+                for (int i = 0; i < rounds * per_round; ++i) {
+                    char* slot = ka_dev + (size_t)i * 64;
+                    GatherArgs a{tab, NT - 1, 7u, (uint32_t)i}; memcpy(slot, &a, sizeof(a));
+                }
+                _mm_sfence();
+                { volatile char sink = ka_dev[(size_t)(rounds * per_round - 1) * 64]; (void)sink; }
+                const uint16_t hdr = header(1, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE);
+                const auto t0 = std::chrono::high_resolution_clock::now();
+                int i = 0;
+                for (int r = 0; r < rounds; ++r) {
+                    for (int j = 0; j < per_round; ++j, ++i) {
+                        const bool last = i == rounds * per_round - 1;
+                        const bool tiny = (pattern != 0 && pattern != 3 && j == 2) || pattern == 3;
+                        const uint16_t h = last ? header(1, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM) : hdr;
+                        if (!tiny) write_packet(k_gather, 4096, ka_dev + (size_t)i * 64, h, last ? g_done : hsa_signal_t{0});
+                        else if (pattern == 1) write_packet(k_empty, 1, ka_dev + (size_t)i * 64, h, last ? g_done : hsa_signal_t{0});
+                        else if (pattern == 4) write_packet(k_empty, 16, ka_dev + (size_t)i * 64, h, last ? g_done : hsa_signal_t{0});
+                        else write_packet(k_e1024, 1, ka_dev + (size_t)i * 64, h, last ? g_done : hsa_signal_t{0}, 1024);
+                    }
+                }
+                ring();
+                if (!wait_done()) { fprintf(stderr, "timeout (part 4)\n"); return 3; }
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / rounds;
+                best = us < best ? us : best;
+            }
+            static const char* pn[] = {"gather 4096x64, gather 4096x64", "gather, gather, empty 1x64", "gather, gather, empty 1x1024 with 10 KB LDS", "empty 1x1024 with 10 KB LDS alone",
+                                       "gather, gather, empty 16x64"};
+            printf("%-60s %10.2f\n", pn[pattern], best);
+            fflush(stdout);
+        }
+        // the sampler's own reduction kernel (argv[3] = the library's device code object), N = 0: what does THIS kernel cost as the third dispatch?
+        if (argc > 3) {
+            std::ifstream f2(argv[3], std::ios::binary);
+            std::vector<char> blob2((std::istreambuf_iterator<char>(f2)), std::istreambuf_iterator<char>());
+            hsa_code_object_reader_t rd2; hsa_executable_t exe2;
+            HCK(hsa_code_object_reader_create_from_memory(blob2.data(), blob2.size(), &rd2));
+            HCK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe2));
+            HCK(hsa_executable_load_agent_code_object(exe2, g_gpu, rd2, nullptr, nullptr));
+            HCK(hsa_executable_freeze(exe2, nullptr));
+            const Kernel k_adapt = get_kernel(exe2, "_ZN3bpm15cr_adapt_kernelENS_6LayoutEjjPdS1_Pjj");
+            printf("cr_adapt_kernel: kernarg %u B, LDS %u B, scratch %u B\n", k_adapt.kernarg, k_adapt.group, k_adapt.priv);
+            struct AdaptArgs { void* G; uint64_t blk; uint32_t n_local, ld, dim, world, magic, pad; uint32_t N, n_cr; void* cr_state; void* part; void* ticket; uint32_t span; };
+            static_assert(sizeof(AdaptArgs) == 88 || sizeof(AdaptArgs) == 80, "layout");
+            for (int pattern = 0; pattern < 3; ++pattern) {     // 0: adapt alone, 1: gather, gather, adapt(N=0), 2: gather, gather, adapt(N=8192 over the table)
+                const int per_round = pattern == 0 ? 1 : 3, rounds = 300;
+                double best = 1e30;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hsa_signal_store_relaxed(g_done, 1);
+                    for (int i = 0; i < rounds * per_round; ++i) {
+                        char* slot = ka_dev + (size_t)i * 128;
+                        const bool tiny = pattern == 0 || (i % 3) == 2;
+                        if (tiny) {
+                            AdaptArgs a{}; a.G = tab; a.blk = 8192ull * 102; a.n_local = 8192; a.ld = 100; a.dim = 100; a.world = 1; a.magic = (uint32_t)((1ull << 32) / 8192) + 1u;
+                            a.N = pattern == 2 ? 8192u : 0u; a.n_cr = 3; a.cr_state = x; a.part = nullptr; a.ticket = nullptr; a.span = 0;
+                            memcpy(slot, &a, sizeof(a));
+                            struct { uint32_t bc[3]; uint16_t gs[3], rem[3]; } hid{{1, 1, 1}, {1024, 1, 1}, {0, 0, 0}};
+                            memcpy(slot + ((sizeof(a) + 7) & ~size_t(7)), &hid, sizeof(hid));
+                        } else { GatherArgs a{tab, NT - 1, 7u, (uint32_t)i}; memcpy(slot, &a, sizeof(a)); }
+                    }
+                    _mm_sfence();
+                    { volatile char sink = ka_dev[(size_t)(rounds * per_round - 1) * 128]; (void)sink; }
+                    const uint16_t hdr = header(1, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE);
+                    const auto t0 = std::chrono::high_resolution_clock::now();
+                    for (int i = 0; i < rounds * per_round; ++i) {
+                        const bool last = i == rounds * per_round - 1;
+                        const bool tiny = pattern == 0 || (i % 3) == 2;
+                        const uint16_t h = last ? header(1, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM) : hdr;
+                        if (tiny) write_packet(k_adapt, 1, ka_dev + (size_t)i * 128, h, last ? g_done : hsa_signal_t{0}, 1024);
+                        else write_packet(k_gather, 4096, ka_dev + (size_t)i * 128, h, last ? g_done : hsa_signal_t{0});
+                    }
+                    ring();
+                    if (!wait_done()) { fprintf(stderr, "timeout (part 4b)\n"); return 3; }
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / rounds;
+                    best = us < best ? us : best;
+                }
+                static const char* pn2[] = {"cr_adapt_kernel (N = 0) alone", "gather, gather, cr_adapt_kernel (N = 0)", "gather, gather, cr_adapt_kernel (N = 8192)"};
+                printf("%-60s %10.2f\n", pn2[pattern], best);
+                fflush(stdout);
+            }
         }
     }
     hsa_queue_destroy(g_q);
