@@ -204,6 +204,77 @@ __device__ __forceinline__ int gsum_i(int v) {
     return v;
 }
 
+// ---- CR reduction in two dispatches (round 2) ---------------------------------------------------------------------------
+// One reduction kernel per burn-in generation used to do everything in ONE workgroup of 1024 threads: 16 loads and 64
+// compare-accumulates per thread, then the update of p_cr -- 10 us as the third dependent dispatch of a generation whose two update
+// kernels take 8.3 us each (an EMPTY third dispatch costs 2.4 us: profiles/r02_cr_in_kernel_experiment.txt).  Now:
+//   * cr_partial_kernel: up to CR_PARTS workgroups of 256 (1024 beyond 65536 chains) threads, workgroup b sums the slots of chains [b, b + 1) span in a fixed
+//     order (thread: its strided slots in index order; wavefront: DPP tree; workgroup: its wavefronts in order) and writes
+//     part[k][b] -- no ticket, one load round trip;
+//   * cr_final_kernel: one wavefront folds the <= 64 partial sums (one coalesced load per sum, a fixed DPP tree) into the totals,
+//     re-estimates p_cr and writes cr_state.
+// 22.5 instead of 24.9 us per burn-in generation at cfg2.  (Letting every wavefront of the NEXT generation's update kernels do the
+// fold instead of cr_final_kernel -- two rotating totals buffers, workgroup 0 writing them -- measured slower: 24.4 us at cfg2,
+// 102 instead of 90 us at N = 262144; a last-workgroup ticket inside one kernel was the round-1 form for N > 16384.)
+// Same arithmetic in the same order on every path and every rank: results do not depend on the number of GPUs.
+constexpr int CR_PARTS = 64;
+// workgroup size of cr_partial_kernel: a function of N alone (the summation order depends on it, and every rank of a world must add
+// in the same order); 1024 threads beyond 65536 chains keep the slots per thread at <= 4 (93 -> 90 us per generation at N = 262144)
+__host__ __device__ inline uint32_t cr_part_threads(uint32_t N) { return N > 65536u ? 1024u : 256u; }
+__host__ __device__ inline uint32_t cr_part_span(uint32_t N) {       // chains per workgroup: a multiple of the workgroup size, at most CR_PARTS workgroups
+    const uint32_t per = (N + CR_PARTS - 1u) / CR_PARTS, t = cr_part_threads(N);
+    return (per + t - 1u) / t * t;
+}
+// dream.py:132-140 for one generation: its partial sums folded into the totals T = (p_cr | delta_m | n_cr_updates).  Nothing changes
+// when no update contributed; p_cr is re-estimated once every CR value has been used, then normalised.  All 64 lanes take part.
+struct CrTotals { double p[MAX_CR], d[MAX_CR], n[MAX_CR]; };
+template <bool ATOMIC_LOADS = false>      // true: the partial sums were written by other workgroups of the SAME launch (agent-scope stores)
+__device__ __forceinline__ void cr_fold(const double* tot, const double* part, uint32_t nb, uint32_t n_cr, CrTotals& T) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    double sd[MAX_CR], sn[MAX_CR];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) {
+        sd[m] = 0.0; sn[m] = 0.0;
+        if (m < (int)n_cr && lane < nb) {
+            if (ATOMIC_LOADS) {
+                sd[m] = __hip_atomic_load(&part[m * CR_PARTS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sn[m] = __hip_atomic_load(&part[(MAX_CR + m) * CR_PARTS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                sd[m] = part[m * CR_PARTS + lane];
+                sn[m] = part[(MAX_CR + m) * CR_PARTS + lane];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) { T.p[m] = tot[m]; T.d[m] = tot[MAX_CR + m]; T.n[m] = tot[2 * MAX_CR + m]; }
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) {
+        if (m < (int)n_cr) {                       // uniform
+            const double td = gsum<WAVE>(sd[m]), tn = gsum<WAVE>(sn[m]);
+            if (tn > 0.0) { any = true; T.n[m] += tn; T.d[m] += td; }
+        }
+    }
+    if (!any) return;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && T.n[m] != 0.0) ? 1u : 0u;
+    if (nz == n_cr) {
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.d[m] / T.n[m];     // dream.py:134-137
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) sum += T.p[m];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.p[m] / sum;            // dream.py:140
+}
+__device__ __forceinline__ void cr_write_totals(const CrTotals& T, uint32_t n_cr, double* out) {
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m)
+        if (m < (int)n_cr) { out[m] = T.p[m]; out[MAX_CR + m] = T.d[m]; out[2 * MAX_CR + m] = T.n[m]; }
+}
+
 __device__ __forceinline__ double box_muller(uint32_t w1, uint32_t w2) {
     const double u1 = ((double)w1 + 1.0) * 2.3283064365386963e-10;
     const double u2 = u01_32(w2);
@@ -1175,65 +1246,26 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
 // (delta, cr_idx) slots of ALL N chains of the exchange buffer: identical on every rank.
 // cr_state: p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
 // ---------------------------------------------------------------------------------
-constexpr int ADAPT_THREADS = 1024;     // one round of loads for N = 8192 (measured: 512 threads +5 us, 256 threads +16 us per generation)
-constexpr int ADAPT_UNR = 8;            // independent load pairs in flight per thread
-constexpr uint32_t ADAPT_SPAN = ADAPT_THREADS * ADAPT_UNR;      // chains one workgroup covers in one round of loads
-
-// dream.py:132-140 given this generation's sums over all chains; the state arrives in registers and is written back once
-__device__ __forceinline__ void cr_apply(const double* tot_d, const double* tot_n, uint32_t n_cr, double* cr_state, double* p_cr,
-                                         double* delta_m, double* n_upd) {
-    bool any = false;
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) {
-        if (m < (int)n_cr && tot_n[m] > 0.0) { any = true; n_upd[m] += tot_n[m]; delta_m[m] += tot_d[m]; }
-    }
-    if (!any) return;
-    uint32_t nz = 0;
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && n_upd[m] != 0.0) ? 1u : 0u;
-    if (nz == n_cr) {
-#pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) p_cr[m] = delta_m[m] / n_upd[m];   // dream.py:134-137
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) s += p_cr[m];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) {
-        if (m < (int)n_cr) {
-            cr_state[m] = p_cr[m] / s;                                                          // dream.py:140
-            cr_state[MAX_CR + m] = delta_m[m];
-            cr_state[2 * MAX_CR + m] = n_upd[m];
-        }
-    }
-}
-
-// part == nullptr: ONE workgroup walks all N slots and applies the update (N <= 16384: one or two rounds of loads).
-// part != nullptr: workgroup b sums the slots of chains [b, b + 1) * span and leaves its sums in
-// part[b] = (delta sums[MAX_CR] | counts[MAX_CR]); the last workgroup to finish adds the workgroups' sums in index order
-// and applies the update.  (One workgroup for everything took 170 us per generation at N = 262144: a serial chain of 32 rounds.)
-__global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint32_t N, uint32_t n_cr, double* cr_state, double* part, uint32_t* ticket,
-                                                                 uint32_t span) {
-    __shared__ double s_d[ADAPT_THREADS / WAVE][MAX_CR], s_n[ADAPT_THREADS / WAVE][MAX_CR];
-    __shared__ double tot_d[MAX_CR], tot_n[MAX_CR];
-    const int tid = threadIdx.x;
-    // the adaptation state, requested at entry (uniform address: scalar loads) so that its miss overlaps with the
-    // slot loads instead of following the reduction
-    double p_cr[MAX_CR], delta_m[MAX_CR], n_upd[MAX_CR];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) { p_cr[m] = cr_state[m]; delta_m[m] = cr_state[MAX_CR + m]; n_upd[m] = cr_state[2 * MAX_CR + m]; }
+// TICKET (N > 65536, where a fourth dispatch costs more than it saves: 93.5 vs 90 us per generation at N = 262144): the LAST workgroup
+// to finish folds the partial sums itself -- the same cr_fold, hence the same bits as cr_final_kernel -- and writes cr_state; the sums
+// then travel in agent-scope atomic stores / loads, which go to the memory side (a release fence would write back the XCD's whole L2).
+template <int CR_PART_THREADS, bool TICKET>
+__global__ __launch_bounds__(CR_PART_THREADS) void cr_partial_kernel(Layout L, uint32_t N, uint32_t n_cr, uint32_t span, double* part, double* cr_state,
+                                                                     uint32_t* ticket, uint32_t nb) {
+    __shared__ double s_d[CR_PART_THREADS / WAVE][MAX_CR], s_n[CR_PART_THREADS / WAVE][MAX_CR];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lo = blockIdx.x * span;
+    const uint32_t hi = lo + span < N ? lo + span : N;
     double acc_d[MAX_CR], acc_n[MAX_CR];
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
-    constexpr int UNR = ADAPT_UNR;
-    const uint32_t lo = part ? blockIdx.x * span : 0u;            // span: chains per workgroup (a multiple of ADAPT_THREADS)
-    const uint32_t hi = part ? (lo + span < N ? lo + span : N) : N;
-    for (uint32_t base = lo + tid; base < hi; base += ADAPT_THREADS * UNR) {
+    constexpr int UNR = 4;
+    for (uint32_t base = lo + tid; base < hi; base += CR_PART_THREADS * UNR) {
         int idx[UNR];
         double dl[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const uint32_t c = base + (uint32_t)u * ADAPT_THREADS;
+            const uint32_t c = base + (uint32_t)u * CR_PART_THREADS;
             idx[u] = c < hi ? (int)*cridx_ptr(L, c) : -1;
             dl[u] = c < hi ? *delta_ptr(L, c) : 0.0;
         }
@@ -1241,11 +1273,10 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
         for (int u = 0; u < UNR; ++u) {
 #pragma unroll
             for (int m = 0; m < MAX_CR; ++m) {
-                if (idx[u] == m) { acc_d[m] += dl[u]; acc_n[m] += 1.0; }
+                if (m < (int)n_cr && idx[u] == m) { acc_d[m] += dl[u]; acc_n[m] += 1.0; }
             }
         }
     }
-    // fixed-order reduction: DPP sum inside each wavefront, then the 16 wavefront partials in wave order
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) {
         if (m < (int)n_cr) {                       // uniform
@@ -1254,52 +1285,36 @@ __global__ __launch_bounds__(ADAPT_THREADS) void cr_adapt_kernel(Layout L, uint3
         }
     }
     __syncthreads();
-    if (tid < (int)n_cr) {
+    if (tid < n_cr) {
         double d = 0.0, n = 0.0;
-        for (int w = 0; w < ADAPT_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
-        if (part) {
-            __hip_atomic_store(&part[(uint64_t)blockIdx.x * 2 * MAX_CR + tid], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&part[(uint64_t)blockIdx.x * 2 * MAX_CR + MAX_CR + tid], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket (the barrier does not wait for it)
+        for (int w = 0; w < CR_PART_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
+        if (TICKET) {
+            __hip_atomic_store(&part[tid * CR_PARTS + blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part[(MAX_CR + tid) * CR_PARTS + blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket
+        } else {
+            part[tid * CR_PARTS + blockIdx.x] = d;
+            part[(MAX_CR + tid) * CR_PARTS + blockIdx.x] = n;
         }
-        tot_d[tid] = d; tot_n[tid] = n;
     }
-    __syncthreads();
-    if (!part) {
-        if (tid == 0) cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
-        return;
-    }
-    // Several workgroups: the LAST one to finish (a ticket per launch; the partial sums are published with agent-scope
-    // release / acquire around it -- a few dozen workgroups, not thousands) adds the workgroups' sums IN INDEX ORDER and
-    // applies the update: the same arithmetic on every rank and in every run, and no second launch (cr_final_kernel cost
-    // another 11 us per burn-in generation at N = 262144).
+    if (!TICKET) return;
     __shared__ uint32_t s_last;
-    // (the sums travel in agent-scope atomic stores / loads, which go to the memory side; the barrier above has waited for
-    // them -- an agent-scope release FENCE here writes back the XCD's whole L2 once per workgroup: 29 us with 256 workgroups)
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || tid >= WAVE) return;
+    CrTotals T;
+    cr_fold<true>(cr_state, part, nb, n_cr, T);
     if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // every workgroup's sums in ONE round of loads (thread = workgroup x slot, gridDim.x <= 64), then added in index order
-    __shared__ double s_part[64 * 2 * MAX_CR];
-    for (uint32_t i = tid; i < gridDim.x * 2u * MAX_CR; i += ADAPT_THREADS)
-        s_part[i] = __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (tid < (int)n_cr) {
-        double d = 0.0, n = 0.0;
-        for (uint32_t b = 0; b < gridDim.x; ++b) {
-            d += s_part[b * 2u * MAX_CR + tid];
-            n += s_part[b * 2u * MAX_CR + MAX_CR + tid];
-        }
-        tot_d[tid] = d; tot_n[tid] = n;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        cr_apply(tot_d, tot_n, n_cr, cr_state, p_cr, delta_m, n_upd);
+        cr_write_totals(T, n_cr, cr_state);
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // armed for the next generation
     }
+}
+// totals `tot` + the partial sums of one generation -> cr_state (one wavefront; tot may be cr_state itself)
+__global__ __launch_bounds__(WAVE) void cr_final_kernel(const double* tot, const double* part, uint32_t nb, uint32_t n_cr, double* cr_state) {
+    CrTotals T;
+    cr_fold(tot, part, nb, n_cr, T);
+    if (threadIdx.x == 0) cr_write_totals(T, n_cr, cr_state);
 }
 
 // Sparse exchange, receiving side: after the all-gather of the packed blocks PK[r] = [count | pad | ids[cap] | rows[cap][ld]]

@@ -305,7 +305,7 @@ struct bpm_sampler {
     int64_t w_rows = 0;        // history rows folded into the Welford moments
     double* tparams = nullptr;
     double* cr_state = nullptr;
-    double* cr_part = nullptr;    // per-workgroup sums of the two-stage CR reduction (N > 16384)            // p_cr | delta_m | n_cr_updates (MAX_CR each)
+    double* cr_part = nullptr;    // [2 MAX_CR][CR_PARTS] partial sums of a generation's CR statistics (cr_partial_kernel -> cr_final_kernel) + ticket
     unsigned long long* counters = nullptr;  // device: [2] = NaN ratios
     uint32_t* acc_count = nullptr;           // device: accepted updates per local chain, this run
     int64_t gens_this_run_local = 0;
@@ -735,6 +735,10 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc(&s->tparams, (size_t)np));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
     CKD(dev_alloc_state(&s->cr_state, 3 * MAX_CR, s->coherent));
+    if (cfg->algo == BPM_ALGO_DREAM) {       // (+ the ticket of the one-dispatch form behind the sums)
+        CKD(dev_alloc_state(&s->cr_part, (size_t)2 * MAX_CR * CR_PARTS + 2, s->coherent));
+        HIPCKD(hipMemsetAsync(s->cr_part, 0, ((size_t)2 * MAX_CR * CR_PARTS + 2) * sizeof(double), s->stream));
+    }
     {
         double init[3 * MAX_CR] = {0};
         for (int m = 0; m < s->cfg.n_cr; ++m) init[m] = 1.0 / s->cfg.n_cr;   // dream.py:114
@@ -1153,43 +1157,35 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
 }
 
 static int finish_generation(bpm_sampler* s) {
-    if (s->gen_adapt_on && g_dq) {
-        // direct mode: the same launch as a packet (cr_adapt_kernel reads gridDim: the hidden arguments are filled by the queue)
-        struct { Layout L; uint32_t N, n_cr; double* cr_state; double* part; uint32_t* ticket; uint32_t span; } ca{s->L, s->N, (uint32_t)s->cfg.n_cr, s->cr_state, nullptr, nullptr, 0u};
-        uint32_t nb = 1;
-        if (s->N > 2 * ADAPT_SPAN) {
-            const uint32_t span = ((s->N + 63u) / 64u + ADAPT_THREADS - 1u) / ADAPT_THREADS * ADAPT_THREADS;
-            nb = (s->N + span - 1) / span;
-            if (!s->cr_part) {
-                StreamSection sec(s);
-                CK(sec.rc);
-                CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR + 2));
-                HIPCK(hipMemsetAsync(s->cr_part, 0, ((size_t)nb * 2 * MAX_CR + 2) * sizeof(double), s->stream));
-                CK(sec.end());
-            }
-            ca.part = s->cr_part; ca.ticket = reinterpret_cast<uint32_t*>(s->cr_part + (size_t)nb * 2 * MAX_CR); ca.span = span;
+    if (s->gen_adapt_on) {
+        // this generation's (delta, cr) slots -> partial sums -> totals, p_cr (kernels.h: "CR reduction in two dispatches"; beyond
+        // 65536 chains ONE dispatch whose last workgroup folds)
+        const uint32_t span = cr_part_span(s->N), nb = (s->N + span - 1) / span;
+        const bool big = cr_part_threads(s->N) == 1024u;
+        uint32_t* ticket = reinterpret_cast<uint32_t*>(s->cr_part + (size_t)2 * MAX_CR * CR_PARTS);
+        if (g_dq) {
+            struct { Layout L; uint32_t N, n_cr, span, _pad; double* part; double* cr_state; uint32_t* ticket; uint32_t nb; } pa{
+                s->L, s->N, (uint32_t)s->cfg.n_cr, span, 0u, s->cr_part, s->cr_state, ticket, nb};
+            static_assert(offsetof(decltype(pa), part) == sizeof(Layout) + 16, "kernarg layout of cr_partial_kernel");
+            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, s->cr_part, nb, (uint32_t)s->cfg.n_cr, s->cr_state};
+            const bpm::DqKernel* kp = g_dq->kernel(big ? reinterpret_cast<const void*>(cr_partial_kernel<1024, true>) : reinterpret_cast<const void*>(cr_partial_kernel<256, false>));
+            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(cr_final_kernel));
+            int fence = g_dq_update_fence;
+            if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+            if (!kp || !kf || g_dq->launch(*kp, nb, 1, big ? 1024u : 256u, &pa, sizeof(pa), fence) != 0 ||
+                (!big && g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), g_dq_update_fence) != 0))
+                return fail("direct AQL queue: CR reduction kernels: " + g_dq->why());
+        } else if (big) {
+            hipLaunchKernelGGL((cr_partial_kernel<1024, true>), dim3(nb), dim3(1024), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr, span, s->cr_part, s->cr_state,
+                               ticket, nb);
+            HIPCK(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL((cr_partial_kernel<256, false>), dim3(nb), dim3(256), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr, span, s->cr_part, s->cr_state,
+                               ticket, nb);
+            hipLaunchKernelGGL(cr_final_kernel, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, (const double*)s->cr_part, nb, (uint32_t)s->cfg.n_cr,
+                               s->cr_state);
+            HIPCK(hipGetLastError());
         }
-        const bpm::DqKernel* kc = g_dq->kernel(reinterpret_cast<const void*>(cr_adapt_kernel));
-        int fence = g_dq_update_fence;
-        if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
-        if (!kc || g_dq->launch(*kc, nb, 1, ADAPT_THREADS, &ca, sizeof(ca), fence) != 0) return fail("direct AQL queue: cr_adapt_kernel: " + g_dq->why());
-        s->w_rows += 1;
-    } else if (s->gen_adapt_on) {
-        if (s->N <= 2 * ADAPT_SPAN) {
-            hipLaunchKernelGGL(cr_adapt_kernel, dim3(1), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
-                               s->cr_state, (double*)nullptr, (uint32_t*)nullptr, 0u);
-        } else {            // up to 64 workgroups (their tickets are same-address atomics: ~28 ns each), a few chains per thread; the last
-                            // workgroup to finish adds their sums in index order
-            uint32_t span = ((s->N + 63u) / 64u + ADAPT_THREADS - 1u) / ADAPT_THREADS * ADAPT_THREADS;
-            const uint32_t nb = (s->N + span - 1) / span;
-            if (!s->cr_part) {
-                CK(dev_alloc(&s->cr_part, (size_t)nb * 2 * MAX_CR + 2));
-                HIPCK(hipMemsetAsync(s->cr_part, 0, ((size_t)nb * 2 * MAX_CR + 2) * sizeof(double), s->stream));    // (the ticket lives behind the sums)
-            }
-            hipLaunchKernelGGL(cr_adapt_kernel, dim3(nb), dim3(ADAPT_THREADS), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr,
-                               s->cr_state, s->cr_part, reinterpret_cast<uint32_t*>(s->cr_part + (size_t)nb * 2 * MAX_CR), span);
-        }
-        HIPCK(hipGetLastError());
         s->w_rows += 1;
     }
     if (s->cfg.keep_history) s->hist_rows += 1;

@@ -214,7 +214,7 @@ def test_dream_generation_parity(d, N, P_):
 
 def test_cr_adaptation_two_stage_reduction_matches_oracle():
     """Above 16384 chains the per-generation CR reduction runs as one workgroup per 8192 chains plus a final kernel
-    (cr_adapt_kernel with partial sums + cr_final_kernel); same decisions, delta_m and p_cr as the oracle."""
+    (cr_partial_kernel's one-dispatch form: partial sums, last workgroup folds); same decisions, delta_m and p_cr as the oracle."""
     d, N = 2, 20000
     eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 77, del_pairs=3, burnin_gen=100, n_cr_gen=2, n_cr=3)
     X = np.random.RandomState(5).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: time per generation DURING DREAM's CR adaptation (burn-in) -- update kernels with Welford moments and
-CR statistics plus the per-generation cr_adapt reduction -- beside the steady-state figure of tools/bench_configs.py."""
+CR statistics plus the per-generation CR reduction kernels -- beside the steady-state figure of tools/bench_configs.py."""
 import os
 import sys
 import time

@@ -46,7 +46,7 @@ out.append(entry("cfg2 DREAM d=100 N=8192 steady", "phase_fused_kernel<1,1,64,2,
                  (2 * pmc("r02_pmc_bench_driver.txt", "FETCH_SIZE") + pmc("r02_pmc_bench_driver.txt", "WRITE_SIZE")) * 1024,
                  "kernel-trace duration; bench.py reports the back-to-back launch period (6.0-6.2 us -> 0.60)"))
 out.append(entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", "r02_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
-                 "Welford moments r/w add 32 d bytes per update; + cr_adapt_kernel 9.3 us per generation"))
+                 "Welford moments r/w add 32 d bytes per update; + cr_partial_kernel 2.9 us + cr_final_kernel 3.0 us per generation"))
 out.append(entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", "r02_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
                  pmc("r02_pmc_tcc_cfg5_cfg3_cfg2.txt", "TCC_EA0_RDREQ_sum", "cfg3") * 128 + 6320 * 64 + (83616 - 6320) * 32,
                  "latency bound: launch floor + three dependent Infinity-Cache round trips (r02_hop_floor_micro.txt); a 16-byte row is an eighth of a 128-byte line"))
@@ -56,5 +56,5 @@ out.append(entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1
 out.append(entry("cfg5 one GPU's share N=32768 steady", "phase_fused_kernel<1,2,4,2,3,2>", "r02_kernel_stats_cfg5_local.csv", "<1, 2, 4, 2, 3, 2>", 592, 16384, None,
                  "latency bound (1024 wavefronts)"))
 out.append(entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", "r02_kernel_stats_cfg5_burnin_outlier.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
-                 "+ cr_adapt_kernel 11.3 us per generation, outlier check 0.44 ms per 50 generations"))
+                 "+ cr_partial_kernel (ticket form) 11 us per generation, outlier check 0.44 ms per 50 generations"))
 print(json.dumps(out, indent=1))
