@@ -212,10 +212,12 @@ def test_dream_generation_parity(d, N, P_):
     print("fraction of state entries bit-identical to the oracle per generation:", exact)
 
 
-def test_cr_adaptation_two_stage_reduction_matches_oracle():
-    """Above 16384 chains the per-generation CR reduction runs as one workgroup per 8192 chains plus a final kernel
-    (cr_partial_kernel's one-dispatch form: partial sums, last workgroup folds); same decisions, delta_m and p_cr as the oracle."""
-    d, N = 2, 20000
+@pytest.mark.parametrize("N", [20000, 70000])
+def test_cr_adaptation_two_stage_reduction_matches_oracle(N):
+    """The per-generation CR reduction in both of its forms -- up to 65536 chains partial sums by up to 64 workgroups + one folding
+    wavefront in a second dispatch (N = 20000: 40 workgroups of 512 chains), beyond that ONE dispatch whose last workgroup to finish
+    folds (N = 70000: 35 workgroups of 2048 chains) -- gives the same decisions, delta_m and p_cr as the oracle."""
+    d = 2
     eng, ora = _pair(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 77, del_pairs=3, burnin_gen=100, n_cr_gen=2, n_cr=3)
     X = np.random.RandomState(5).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
     _start(eng, ora, X)
