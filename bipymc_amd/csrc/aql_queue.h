@@ -3,8 +3,8 @@
 // Why: the steady state of a run is two DEPENDENT update kernels of ~6 us per generation.  A HIP launch call costs the host
 // 2.4-4.8 us (and now and then 10-30 us), so a call that starts from a drained queue -- the 20 generations the driver times --
 // runs host-paced.  Here the library writes the 64-byte AQL dispatch packets itself: kernel
-// arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, one doorbell per
-// generation.  ~0.3 us of host work per dispatch, nothing of the HIP runtime on the path (tools/micro/aql_direct.cpp measures
+// arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, the doorbell.
+// ~1 us of host work per dispatch (most of it the read-back that proves the arguments have landed), nothing of the HIP runtime on the path (tools/micro/aql_direct.cpp measures
 // the pieces: a dependent empty dispatch costs 1.92 us this way against 2.62 us through hipLaunchKernelGGL; kernel arguments
 // in HOST memory cost 27 us per 4096-wavefront dispatch, hence the device ring).
 //
@@ -20,6 +20,7 @@
 #include <hsa/hsa_ven_amd_loader.h>
 #include <x86intrin.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -133,7 +134,7 @@ class DirectQueue {
         busy_ = true;
         // one doorbell never covers packets on both sides of the ring's end (a queue-intercepting tool -- rocprofv3 -- copies the
         // packets of a doorbell as one linear range)
-        if (n_unpublished_ == MAX_UNPUBLISHED || (widx_ & (q_->size - 1)) == 0) flush();
+        if (n_unpublished_ >= batch_cap() || (widx_ & (q_->size - 1)) == 0) flush();
         return 0;
     }
 
@@ -151,8 +152,9 @@ class DirectQueue {
     }
 
     // everything dispatched so far has finished and is visible to the host and to HIP streams (system-scope release)
-    int drain(double timeout_s = 120.0) {
+    int drain(double timeout_s = -1.0) {
         std::lock_guard<std::recursive_mutex> lk(mu_);
+        if (timeout_s < 0.0) timeout_s = wait_limit_s();
         if (!busy_) return 0;
         if (failed_) return -1;
         if (!next_slot()) return -1;
@@ -303,8 +305,20 @@ class DirectQueue {
             if (n_unpublished_ >= MAX_UNPUBLISHED - 1 || (widx_ & (q_->size - 1)) == 0) flush();
         }
     }
+    // Packets per doorbell.  ONE: ringing per packet costs the host ~1 us (the read-back through the BAR) against >= 5 us of GPU time
+    // per kernel and measures the same (7.31e8 / 7.79e8 at cfg2 either way), and rocprofv3's counter collection (--pmc) stalls on doorbells
+    // that cover several of this library's packets once the burn-in generation has four of them (a 15 s drain timeout instead of
+    // a result; kernel tracing is not affected).  BPM_QUEUE_BATCH=n (<= 8) batches again.
+    static uint32_t batch_cap() {
+        static const uint32_t v = getenv("BPM_QUEUE_BATCH") ? (uint32_t)std::max(1, std::min((int)MAX_UNPUBLISHED, atoi(getenv("BPM_QUEUE_BATCH")))) : 1u;
+        return v;
+    }
+    static double wait_limit_s() {
+        static const double v = getenv("BPM_QUEUE_TIMEOUT_S") ? atof(getenv("BPM_QUEUE_TIMEOUT_S")) : 120.0;
+        return v;
+    }
     bool timed_out(std::chrono::steady_clock::time_point t0, const char* what) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) return false;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < wait_limit_s()) return false;
         why_ = what; failed_ = true;
         return true;
     }

@@ -1505,7 +1505,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             g_dq_update_fence = s0->dq_fence;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
             if (direct) {
-                s0->dq->flush();                                        // one doorbell per generation
+                s0->dq->flush();                                        // (whatever is still unpublished: with BPM_QUEUE_BATCH > 1 the doorbell of the generation)
                 g_dq = nullptr;
                 if (g_dq_error || s0->dq->failed()) return fail("direct AQL queue: " + (s0->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s0->dq->why()));
             }
