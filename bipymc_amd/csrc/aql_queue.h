@@ -3,8 +3,8 @@
 // Why: the steady state of a run is two DEPENDENT update kernels of ~6 us per generation.  A HIP launch call costs the host
 // 2.4-4.8 us (and now and then 10-30 us), so a call that starts from a drained queue -- the 20 generations the driver times --
 // runs host-paced.  Here the library writes the 64-byte AQL dispatch packets itself: kernel
-// arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, the doorbell.
-// ~1 us of host work per dispatch (most of it the read-back that proves the arguments have landed), nothing of the HIP runtime on the path (tools/micro/aql_direct.cpp measures
+// arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, one doorbell per
+// generation.  ~0.5 us of host work per dispatch (half of it the read-back that proves the arguments have landed), nothing of the HIP runtime on the path (tools/micro/aql_direct.cpp measures
 // the pieces: a dependent empty dispatch costs 1.92 us this way against 2.62 us through hipLaunchKernelGGL; kernel arguments
 // in HOST memory cost 27 us per 4096-wavefront dispatch, hence the device ring).
 //
@@ -305,12 +305,11 @@ class DirectQueue {
             if (n_unpublished_ >= MAX_UNPUBLISHED - 1 || (widx_ & (q_->size - 1)) == 0) flush();
         }
     }
-    // Packets per doorbell.  ONE: ringing per packet costs the host ~1 us (the read-back through the BAR) against >= 5 us of GPU time
-    // per kernel and measures the same (7.31e8 / 7.79e8 at cfg2 either way), and rocprofv3's counter collection (--pmc) stalls on doorbells
-    // that cover several of this library's packets once the burn-in generation has four of them (a 15 s drain timeout instead of
-    // a result; kernel tracing is not affected).  BPM_QUEUE_BATCH=n (<= 8) batches again.
+    // Packets per doorbell at most: the sampler rings once per generation (2-4 packets).  Ringing per packet (BPM_QUEUE_BATCH=1) measures
+    // the same without a profiler (7.31e8 / 7.79e8 at cfg2 either way) but makes a kernel trace slower: every doorbell is a call into
+    // rocprofv3's intercepting queue (5.44 instead of 5.01 us average kernel duration in the trace of the driver's invocation).
     static uint32_t batch_cap() {
-        static const uint32_t v = getenv("BPM_QUEUE_BATCH") ? (uint32_t)std::max(1, std::min((int)MAX_UNPUBLISHED, atoi(getenv("BPM_QUEUE_BATCH")))) : 1u;
+        static const uint32_t v = getenv("BPM_QUEUE_BATCH") ? (uint32_t)std::max(1, std::min((int)MAX_UNPUBLISHED, atoi(getenv("BPM_QUEUE_BATCH")))) : MAX_UNPUBLISHED;
         return v;
     }
     static double wait_limit_s() {

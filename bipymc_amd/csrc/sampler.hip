@@ -701,6 +701,9 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (s->world == 1 && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
+        // BPM_LAUNCH_PATH=stream: everything as with the queue (state in coherent memory) but launched on the HIP stream, like
+        // bpm_set_launch_path(h, 0, -1) -- what the rocprofv3 --pmc passes of tools/profile_bench.sh use (see there)
+        if (const char* lp = getenv("BPM_LAUNCH_PATH")) s->dq_enabled = strcmp(lp, "stream") != 0;
     }
     // With its own queue the sampler keeps what one generation-loop kernel writes and a later one reads -- state matrix, ln-like
     // cache, accept counters, Welford moments, CR state -- in cached-coherent memory; the packets of those kernels then carry
@@ -1505,7 +1508,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             g_dq_update_fence = s0->dq_fence;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
             if (direct) {
-                s0->dq->flush();                                        // (whatever is still unpublished: with BPM_QUEUE_BATCH > 1 the doorbell of the generation)
+                s0->dq->flush();                                        // one doorbell per generation
                 g_dq = nullptr;
                 if (g_dq_error || s0->dq->failed()) return fail("direct AQL queue: " + (s0->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s0->dq->why()));
             }

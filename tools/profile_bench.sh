@@ -12,10 +12,22 @@ ARGS="--steps 20 --warmup 5"
 for i in 1 2 3; do python bench.py $ARGS 2>/dev/null | tail -1 >> $O/bench_driver.jsonl; done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
+echo "kernel trace" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
+# The counter passes launch on the HIP stream (BPM_LAUNCH_PATH=stream: same kernels, same memory types, the launch path of
+# bpm_set_launch_path(h, 0, -1)).  rocprofv3's counter collection serialises every dispatch behind its own packets and, with this
+# library's packets arriving through its intercepting queue, now and then stops forwarding them during burn-in (a drain timeout,
+# "N incomplete dispatches" at exit; not with --kernel-trace, never without the profiler).  The counters are properties of the
+# kernel, not of how it was launched.
+export BPM_LAUNCH_PATH=stream BPM_QUEUE_TIMEOUT_S=30
+echo "pmc FETCH_SIZE" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
+echo "pmc WRITE_SIZE" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
+echo "pmc SQ" >> $O/progress.txt
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
+unset BPM_LAUNCH_PATH
+echo "summaries" >> $O/progress.txt
 cd $R
 K="phase_fused_kernel<1, 1, 64, 2, 3, 1>"
 python tools/rocpd_summary.py stats $(find $O/kt -name "*.db" | head -1) > $P/${TAG}_kernel_stats_bench_driver.csv
