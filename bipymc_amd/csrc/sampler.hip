@@ -714,7 +714,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // BPM_COHERENT_STATE=0: ordinary memory, acquire + release; BPM_DQ_FENCE=full|acq|none: experiment switch.
     {
         const char* c = getenv("BPM_COHERENT_STATE");
-        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0) && state_memory_is_coherent(s->dq, cfg->device);
+        // (BPM_COHERENT_STATE=2: take the memory type on trust, without the probe -- diagnostics)
+        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0) && ((c && atoi(c) == 2) || state_memory_is_coherent(s->dq, cfg->device));
         s->dq_fence = s->coherent ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
         if (const char* f = getenv("BPM_DQ_FENCE")) {
             if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
