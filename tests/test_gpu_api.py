@@ -834,3 +834,45 @@ def test_coherence_probe_discriminates_memory_types():
     assert w.value == 0, "state memory type is not coherent across XCDs without a release fence: %d wrong" % w.value
     L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w)))
     assert w.value > 0, "ordinary device memory passed the probe: it no longer discriminates (%d)" % w.value
+
+
+def test_direct_queue_interleaved_with_other_entry_points():
+    """Every entry point other than the step calls uses the HIP stream and must first drain the library's own queue (check_handle ->
+    leave_direct); the next step call waits for the stream and goes back to the queue.  A run chopped into many short calls with
+    reads, writes and a second run in between must equal the same sequence on HIP-stream launches bit for bit."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D()._bpm_target_spec()
+    N = 1024
+    X0 = np.random.RandomState(9).normal(size=(N, d)) + 0.5
+    outs = []
+    for direct in (True, False):
+        e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=21, burnin_gen=7, n_cr_gen=3)
+        e.set_launch_path(direct)
+        e.set_state(X0)
+        e.begin_run()
+        before = e.launch_stats()                                   # (the dispatch counters are per thread, not per sampler)
+        seen = []
+        for n in (0, 1, 2, 5, 1, 70, 3, 0, 64, 1):
+            e.step(n)
+            seen.append(e.get_state()[::97].copy())                 # (drains the queue, reads through the stream)
+            if n == 5:
+                seen.append(e.get_loglike()[:8].copy())
+                e.set_state(e.get_state() * 1.0)                    # a write through the stream between two direct-mode calls
+            if n == 70:
+                seen.append(np.asarray(e.stats()["p_cr"]))
+                cnt, s1, s2, sh = e.reduce_moments(0)
+                seen.append(np.concatenate([[cnt], s1, s2]))
+        e.begin_run()                                               # a second run: counters reset, generation counter restarts
+        e.step(9)
+        ms, nl = e.step_timed(4)
+        seen.append(e.get_history(0, e.history_rows()))
+        seen.append(np.array([e.stats()["local_n_accepted"], e.stats()["k_gen"], e.history_rows()], dtype=float))
+        ls = e.launch_stats()
+        assert (ls["direct"] - before["direct"] > 0) == direct and (ls["stream"] - before["stream"] > 0) == (not direct)
+        outs.append(seen)
+        e.close()
+    assert len(outs[0]) == len(outs[1])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
