@@ -265,17 +265,19 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     import tempfile
     res = []
     switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH", "BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE",
-                "BPM_DQ_FENCE")
+                "BPM_DQ_FENCE", "BPM_LAUNCH_PATH", "BPM_QUEUE_BATCH")
     # (BPM_DIRECT_QUEUE=0: HIP stream launches instead of the library's own AQL queue; BPM_COHERENT_STATE=0: the state in ordinary
     # device memory, packets with acquire + release)
     for on in ((), ("BPM_NO_HOT",), ("BPM_GRAPH",), ("BPM_GRAPH", "BPM_NO_HOT"), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
                ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1"), ("BPM_DIRECT_QUEUE",), ("BPM_DIRECT_QUEUE", "BPM_NO_HOT"), ("BPM_COHERENT_STATE",),
-               ("BPM_COHERENT_STATE", "BPM_NO_PLAN")):
+               ("BPM_COHERENT_STATE", "BPM_NO_PLAN"), ("BPM_LAUNCH_PATH",), ("BPM_QUEUE_BATCH",), ("BPM_DQ_FENCE",)):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)
         for k in on:
-            env[k] = "1000000" if k == "BPM_PLAN_MAX" else ("0" if k in ("BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE") else "1")     # BPM_PLAN_MAX: plan records whatever the number of chains
+            # BPM_PLAN_MAX: plan records whatever the number of chains; BPM_LAUNCH_PATH=stream: the queue's memory types, HIP stream launches;
+            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release packets on coherent memory
+            env[k] = {"BPM_PLAN_MAX": "1000000", "BPM_DIRECT_QUEUE": "0", "BPM_COHERENT_STATE": "0", "BPM_LAUNCH_PATH": "stream", "BPM_DQ_FENCE": "full"}.get(k, "1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
