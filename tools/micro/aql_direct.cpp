@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
                                 {"barrier, no fences             ", 1, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE},
                                 {"no barrier, no fences (overlap)", 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE}};
     printf("%-34s %-10s %-22s %-12s %10s  %s\n", "packet header", "kernarg", "kernel", "doorbell", "us/launch", "check");
-    const bool part1 = !(argc > 2 && (!strcmp(argv[2], "mem") || !strcmp(argv[2], "p4")));
+    const bool part1 = !(argc > 2 && (!strcmp(argv[2], "mem") || !strcmp(argv[2], "p4") || !strcmp(argv[2], "p5")));
     const bool full = argc > 2 && !strcmp(argv[2], "full");
     for (int where = (bar && !full) ? 1 : 0; part1 && where < (bar ? 2 : 1); ++where) {
         char* ka = where ? ka_dev : ka_host;
@@ -202,7 +202,7 @@ int main(int argc, char** argv) {
         }
     }
 
-    const bool only4 = argc > 2 && !strcmp(argv[2], "p4");
+    const bool only4 = argc > 2 && (!strcmp(argv[2], "p4") || !strcmp(argv[2], "p5"));
     // ---- part 2: the data in other kinds of device memory (plain kernels): does memory the L2 does not keep non-coherent
     // copies of make a fence-less boundary correct, and what do its reads cost?
     if (bar && !only4) {
@@ -320,7 +320,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- part 4: what does a THIRD, tiny kernel cost behind two heavy ones (the burn-in generation: update, update, cr_adapt)?
-    if (bar) {
+    if (bar && !(argc > 2 && !strcmp(argv[2], "p5"))) {
         const Kernel k_e1024 = get_kernel(exe, "k_empty_1024");
         printf("\n%-60s %10s\n", "chain of dependent dispatches (acquire-only packets), per round", "us/round");
         for (int pattern = 0; pattern < 5; ++pattern) {
@@ -409,6 +409,51 @@ int main(int argc, char** argv) {
                 printf("%-60s %10.2f\n", pn2[pattern], best);
                 fflush(stdout);
             }
+        }
+    }
+
+    // ---- part 5: does what launch i brings into an XCD's L2 survive the kernel boundary (prefetch of the next launch's records)?
+    if (bar && argc > 2 && !strcmp(argv[2], "p5")) {
+        const Kernel k_slice = get_kernel(exe, "k_slice");
+        struct SliceArgs { void* rec; void* data; void* out; uint32_t slice, n_per_slice, mask, prefetch; };
+        const uint32_t NPS = 4096, SLICES = 600;
+        struct Mem { const char* name; hsa_amd_memory_pool_t pool; };
+        const Mem mems[] = {{"records in ordinary memory", g_gpu_pool}, {"records in ext-scope fine-grained memory", g_gpu_ext_fine_pool}};
+        printf("\n%-44s %-28s %-9s %10s\n", "record table", "packet header", "prefetch", "us/launch");
+        for (const Mem& m : mems) {
+            if (!m.pool.handle) continue;
+            void *rec = nullptr, *out = nullptr;
+            HCK(hsa_amd_memory_pool_allocate(m.pool, (size_t)(SLICES + 2) * NPS * 64, 0, &rec));
+            HCK(hsa_amd_memory_pool_allocate(g_gpu_pool, (size_t)NPS * 16, 0, &out));
+            HCK(hsa_amd_memory_fill(rec, 12345u, (size_t)(SLICES + 2) * NPS * 16));
+            for (int vi : {2, 4}) {      // acquire only / no fences
+                const Variant& v = variants[vi];
+                for (uint32_t pf = 0; pf < 2; ++pf) {
+                    double best = 1e30;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        hsa_signal_store_relaxed(g_done, 1);
+                        for (uint32_t i = 0; i < SLICES; ++i) {
+                            SliceArgs a{rec, tab, out, i, NPS, NT - 1, pf};
+                            memcpy(ka_dev + (size_t)i * 64, &a, sizeof(a));
+                        }
+                        _mm_sfence();
+                        { volatile char sink = ka_dev[(size_t)(SLICES - 1) * 64]; (void)sink; }
+                        const auto t0 = std::chrono::high_resolution_clock::now();
+                        for (uint32_t i = 0; i < SLICES; ++i) {
+                            const bool last = i == SLICES - 1;
+                            write_packet(k_slice, NPS, ka_dev + (size_t)i * 64, last ? header(1, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM) : header(v.barrier, v.acq, v.rel),
+                                         last ? g_done : hsa_signal_t{0});
+                        }
+                        ring();
+                        if (!wait_done()) { fprintf(stderr, "timeout (part 5)\n"); return 3; }
+                        const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / SLICES;
+                        best = us < best ? us : best;
+                    }
+                    printf("%-44s %-28s %-9u %10.2f\n", m.name, v.name, pf, best);
+                    fflush(stdout);
+                }
+            }
+            hsa_amd_memory_pool_free(rec); hsa_amd_memory_pool_free(out);
         }
     }
     hsa_queue_destroy(g_q);

@@ -43,3 +43,17 @@ extern "C" __global__ __launch_bounds__(1024) void k_empty_1024(int* p) {
     __shared__ double pad[1280];
     if (p && threadIdx.x == 99999) { pad[threadIdx.x & 1023] = 1.0; *p = (int)pad[3]; }
 }
+
+// Part 5: does a line that launch i pulls into an XCD's L2 survive into launch i + 1?  Launch i: workgroup (= wavefront) w reads the
+// 64-byte record w of slice i of a read-only table (first touch: every launch has a slice of its own), then one dependent 16-byte gather,
+// and, with prefetch != 0, also touches record w of slice i + 1 (workgroup w of the next launch runs on the same XCD: w mod 8).
+extern "C" __global__ void k_slice(const uint4* rec, const uint4* data, uint4* out, uint32_t slice, uint32_t n_per_slice, uint32_t mask, uint32_t prefetch) {
+    const uint32_t w = blockIdx.x;
+    const uint4 r = rec[(slice * n_per_slice + w) * 4u + (threadIdx.x & 3u)];          // 64-byte record, 4 x 16 B
+    const uint4 v = data[(r.x + threadIdx.x) & mask];                                   // dependent gather
+    if (prefetch) {
+        const uint4 nx = rec[((slice + 1u) * n_per_slice + w) * 4u + (threadIdx.x & 3u)];
+        if (nx.w == 0xdeadbeefu) out[0] = nx;                                           // (keeps the load alive)
+    }
+    if (threadIdx.x == 0) out[w] = v;
+}
