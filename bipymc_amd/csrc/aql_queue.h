@@ -213,7 +213,7 @@ class DirectQueue {
         lk->found = true;
         return HSA_STATUS_INFO_BREAK;
     }
-    struct AgentPick { uint32_t bdf; uint32_t domain; bool any_gpu_only; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; int n_gpu; };
+    struct AgentPick { uint32_t bdf; uint32_t domain; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; };
     static hsa_status_t agent_cb(hsa_agent_t a, void* data) {
         AgentPick* p = static_cast<AgentPick*>(data);
         hsa_device_type_t t;
@@ -223,7 +223,6 @@ class DirectQueue {
             uint32_t bdf = 0, dom = 0;
             hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
             hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
-            ++p->n_gpu;
             if (!p->have_gpu && bdf == p->bdf && dom == p->domain) { p->gpu = a; p->have_gpu = true; }
         }
         return HSA_STATUS_SUCCESS;
@@ -245,7 +244,6 @@ class DirectQueue {
         if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_dev) != hipSuccess || hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_dev) != hipSuccess ||
             hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_dev) != hipSuccess) { (void)hipGetLastError(); why_ = "no PCI address of the HIP device"; return false; }
         if (hsa_init() != HSA_STATUS_SUCCESS) { why_ = "hsa_init failed"; return false; }           // (reference counted: HIP holds the runtime open already)
-        hsa_inited_ = true;
         AgentPick pick{};
         pick.bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3); pick.domain = (uint32_t)dom;
         if (hsa_iterate_agents(&DirectQueue::agent_cb, &pick) != HSA_STATUS_SUCCESS || !pick.have_gpu || !pick.have_cpu) { why_ = "HSA agent of the HIP device not found"; return false; }
@@ -331,7 +329,7 @@ class DirectQueue {
     bool epoch_armed_[N_EPOCH] = {};
     bool tsig_armed_[2] = {false, false};
     double tick_ns_ = 10.0;
-    bool busy_ = false, failed_ = false, hsa_inited_ = false;
+    bool busy_ = false, failed_ = false;
     uint32_t n_unpublished_ = 0;
     uint32_t pending_header_[MAX_UNPUBLISHED]{};
     uint32_t* pending_packet_[MAX_UNPUBLISHED]{};
