@@ -705,17 +705,18 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         // bpm_set_launch_path(h, 0, -1) -- what the rocprofv3 --pmc passes of tools/profile_bench.sh use (see there)
         if (const char* lp = getenv("BPM_LAUNCH_PATH")) s->dq_enabled = strcmp(lp, "stream") != 0;
     }
-    // With its own queue the sampler keeps what one generation-loop kernel writes and a later one reads -- state matrix, ln-like
-    // cache, accept counters, Welford moments, CR state -- in cached-coherent memory; the packets of those kernels then carry
-    // an agent-scope ACQUIRE only (L1 / scalar cache / non-coherent L2 lines invalidated at kernel start): nothing a later kernel
-    // reads waits in an L2 for the release, and the end-of-kernel L2 write-back -- 0.7 us of a 6.1 us launch period at cfg2 --
-    // goes.  History rows (ordinary memory, non-temporal stores) are read only after the queue is drained, which releases at
-    // system scope.  Results are bit-identical (final state and the moments of 9.8 M history rows, all fence modes).
-    // BPM_COHERENT_STATE=0: ordinary memory, acquire + release; BPM_DQ_FENCE=full|acq|none: experiment switch.
+    // The packets of the generation loop carry agent-scope acquire + release, like every kernel of a HIP stream, and the state lives in
+    // ordinary device memory.  EXPERIMENTAL, opt-in (BPM_COHERENT_STATE=1): state, ln-like cache, accept counters, Welford moments and CR
+    // state in the GPU's hardware-coherent memory type (dev_alloc_state) with acquire-ONLY packets -- the end-of-kernel L2 write-back,
+    // 0.7 us of a 6.1 us launch period at cfg2, goes (10.8 instead of 12.0 us per generation).  NOT the default because it is not safe:
+    // with that memory type in use, history rows (and once whole histories) came back holding older contents in a sequence of
+    // samplers created and destroyed in one process (a row rewritten after bpm_set_state in the middle of a run, buffers reused by the
+    // next sampler) -- with acquire-only AND with full fences, with uploads by DMA or by kernels, never with ordinary memory
+    // (tools/coherent_memory_hazard.py, profiles/r02_coherent_memory_hazard.txt).  The cause was not found in this round.
     {
         const char* c = getenv("BPM_COHERENT_STATE");
         // (BPM_COHERENT_STATE=2: take the memory type on trust, without the probe -- diagnostics)
-        s->coherent = s->dq != nullptr && !(c && atoi(c) == 0) && ((c && atoi(c) == 2) || state_memory_is_coherent(s->dq, cfg->device));
+        s->coherent = s->dq != nullptr && c && atoi(c) != 0 && (atoi(c) == 2 || state_memory_is_coherent(s->dq, cfg->device));
         s->dq_fence = s->coherent ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
         if (const char* f = getenv("BPM_DQ_FENCE")) {
             if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;

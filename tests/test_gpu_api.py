@@ -772,11 +772,10 @@ def test_many_ranks_sorted_records_and_fallback(R):
 @pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker", "dream_gauss100_big"])
 def test_direct_queue_equals_stream_launches(case):
     """The generation loop of a single-GPU sampler is dispatched by AQL packets the library writes into its own queue
-    (bipymc_amd/csrc/aql_queue.h) with the state in cached-coherent memory and acquire-only packet fences; every other
-    setting -- HIP stream launches, acquire + release, no fences -- must give the same bits: state, ln-like, the whole
-    history, CR statistics, accept counters.  The runs cross a table window (64 generations), grow the history while the
-    queue is busy (no reservation), pass through burn-in with the outlier check (HIP-stream sections between drains) and
-    call the timed entry point."""
+    (bipymc_amd/csrc/aql_queue.h), with the fences a HIP stream puts around its kernels; launching the same kernels on the
+    HIP stream must give the same bits: state, ln-like, the whole history, CR statistics, accept counters.  The runs cross
+    a table window (64 generations), grow the history while the queue is busy (no reservation), pass through burn-in with
+    the outlier check (HIP-stream sections between drains) and call the timed entry point."""
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
     from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
@@ -792,11 +791,11 @@ def test_direct_queue_equals_stream_launches(case):
     tid, tp, d = spec
     X0 = np.random.RandomState(3).normal(size=(N, d)) + 1.0
     res, stats = [], []
-    for direct, fence in ((True, -1), (False, -1), (True, 3), (True, 0)):
+    for direct, fence in ((True, -1), (False, -1), (True, 3)):
         e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
         ls = e.launch_stats()
         assert ls["has_queue"], "no direct AQL queue on this box: " + str(ls)
-        assert ls["coherent_state"] and ls["fence"] == "acquire", ls      # (the default: hardware-coherent state, no release fence)
+        assert not ls["coherent_state"] and ls["fence"] == "acquire+release", ls      # (the default: ordinary memory, a HIP stream's fences)
         e.set_launch_path(direct, fence)
         e.set_state(X0)
         e.begin_run()
@@ -858,7 +857,7 @@ def test_direct_queue_interleaved_with_other_entry_points():
         seen = []
         for n in (0, 1, 2, 5, 1, 70, 3, 0, 64, 1):
             e.step(n)
-            seen.append(e.get_state()[::97].copy())                 # (drains the queue, reads through the stream)
+            seen.append(e.get_state())                              # (drains the queue, reads through the stream)
             if n == 5:
                 seen.append(e.get_loglike()[:8].copy())
                 e.set_state(e.get_state() * 1.0)                    # a write through the stream between two direct-mode calls
@@ -878,3 +877,16 @@ def test_direct_queue_interleaved_with_other_entry_points():
     assert len(outs[0]) == len(outs[1])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_sampler_sequence_in_one_process_keeps_histories_intact():
+    """Samplers of different shapes created, run through both launch paths and destroyed one after the other in ONE process, then a
+    run with a history row that is written twice (bpm_set_state in the middle) and a history that grows through several buffers: the
+    four repetitions -- own queue, HIP stream, own queue, HIP stream -- must hold the same history bit for bit.  (With the state in
+    the hardware-coherent memory type this is where rows came back with older contents: tools/coherent_memory_hazard.py.)"""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "coherent_memory_hazard.py")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "all four histories equal" in out.stdout, out.stdout[-2000:]
