@@ -14,11 +14,11 @@ python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
 cd /tmp; export TMPDIR=/tmp
 echo "kernel trace" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
-# The counter passes launch on the HIP stream (BPM_LAUNCH_PATH=stream: same kernels, same memory types, the launch path of
-# bpm_set_launch_path(h, 0, -1)).  rocprofv3's counter collection serialises every dispatch behind its own packets and, with this
-# library's packets arriving through its intercepting queue AND the state in the coherent memory type, stops forwarding them some
-# hundred dispatches into burn-in (a drain timeout, "N incomplete dispatches" at exit; not with BPM_COHERENT_STATE=0, not with
-# --kernel-trace, never without the profiler; cause not found).  The counters are properties of the kernel, not of how it was launched.
+# The counter passes launch on the HIP stream (BPM_LAUNCH_PATH=stream: same kernels, the launch path of bpm_set_launch_path(h, 0, -1)).
+# rocprofv3's counter collection serialises every dispatch behind its own packets and, with this library's packets arriving through
+# its intercepting queue, stops forwarding them some hundred dispatches into burn-in more often than not (a drain timeout,
+# "N incomplete dispatches" at exit; not with --kernel-trace, never without the profiler; cause not found).  The counters are
+# properties of the kernel, not of how it was launched.
 export BPM_LAUNCH_PATH=stream BPM_QUEUE_TIMEOUT_S=30
 echo "pmc FETCH_SIZE" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
