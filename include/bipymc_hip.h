@@ -178,8 +178,9 @@ int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
 /* direct != 0: use the library's own queue where the sampler has one (the default); 0: HIP stream launches only.
  * fence: packet fences of the generation loop's kernels on that queue: -1 keep, 3 agent-scope acquire + release (what a HIP
- * stream does), 1 acquire only (the default when the sampler's state lives in cached-coherent memory), 0 none; values
- * below 3 are refused unless the state is in cached-coherent memory.  Results do not depend on either setting (tested). */
+ * stream does; the default), 1 acquire only, 0 none; values below 3 are refused unless the sampler was created in the
+ * experimental mode that keeps its state in hardware-coherent memory (BPM_COHERENT_STATE=1 in the environment; not safe,
+ * DESIGN.md section 5).  Results do not depend on the launch path (tested). */
 int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
 /* Test hook: the probe that decides whether packets may go without a release fence -- 48 dependent dispatches with
  * acquire-only packets hand every block of a 2 MB buffer from workgroup to workgroup (XCD to XCD); *wrong = elements that
