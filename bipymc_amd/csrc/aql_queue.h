@@ -10,7 +10,7 @@
 //
 // What it is not: a second code path for the kernels.  The kernel objects are the ones HIP loaded from this library's own fat
 // binary (found through the HSA loader's executable list), the packets carry the barrier bit and agent-scope fences like a HIP
-// stream's (the sampler drops the release when its state lives in hardware-coherent memory: sampler.hip, bpm_create), and memory
+// stream's (an experimental mode of the sampler drops the release: sampler.hip, bpm_create; not the default), and memory
 // is HIP's.  Ordering against the sampler's HIP stream is by the host: the
 // sampler drains one before it uses the other (transitions happen at the end of burn-in and at the API boundary only).
 #pragma once

@@ -463,13 +463,11 @@ static int dev_alloc(T** p, size_t n) {
     return 0;
 }
 
-// Buffers that one update kernel writes and the next one reads (state matrix, ln-like cache, accept counters, Welford moments).
-// hipDeviceMallocUncached is, on this runtime, the GPU's EXTENDED-SCOPE FINE-GRAINED pool: local HBM mapped with the cached-coherent
-// memory type, i.e. the XCDs' L2s stay coherent on these lines by themselves (tools/micro/aql_direct.cpp: a dependent chain of
-// kernels is correct on it with NO acquire / release fence between the dispatches, wrong on hipMalloc memory) and a kernel
-// leaves no dirty lines for the end-of-kernel release to write back (3.24 -> 2.34 us per dependent launch of a 2 MB
-// read-modify-write kernel).  Gathers from it cost 1-5 % more than from ordinary device memory, so only a sampler that
-// dispatches through its own queue -- where the release fence can then be dropped -- allocates its state there.
+// Buffers that one update kernel writes and the next one reads (state matrix, ln-like cache, accept counters, Welford moments): ordinary
+// device memory, or -- coherent == true, the experimental mode of bpm_create -- the GPU's EXTENDED-SCOPE FINE-GRAINED pool
+// (hipDeviceMallocUncached on this runtime): local HBM mapped with the cached-coherent memory type, i.e. the XCDs' L2s stay coherent on
+// these lines by themselves (tools/micro/aql_direct.cpp: a dependent chain of kernels is correct on it with NO release fence between
+// the dispatches, wrong on hipMalloc memory).  Gathers from it cost 1-5 % more than from ordinary device memory.
 template <class T>
 static int dev_alloc_state(T** p, size_t n, bool coherent) {
     if (!coherent) return dev_alloc(p, n);
