@@ -266,8 +266,8 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     res = []
     switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH", "BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE",
                 "BPM_DQ_FENCE", "BPM_LAUNCH_PATH", "BPM_QUEUE_BATCH")
-    # (BPM_DIRECT_QUEUE=0: HIP stream launches instead of the library's own AQL queue; BPM_COHERENT_STATE=0: the state in ordinary
-    # device memory, packets with acquire + release)
+    # (BPM_DIRECT_QUEUE=0: HIP stream launches instead of the library's own AQL queue; BPM_COHERENT_STATE=0: the default spelled out --
+    # the experimental value 1 is not part of the suite: tools/coherent_memory_hazard.py)
     for on in ((), ("BPM_NO_HOT",), ("BPM_GRAPH",), ("BPM_GRAPH", "BPM_NO_HOT"), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
                ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1"), ("BPM_DIRECT_QUEUE",), ("BPM_DIRECT_QUEUE", "BPM_NO_HOT"), ("BPM_COHERENT_STATE",),
                ("BPM_COHERENT_STATE", "BPM_NO_PLAN"), ("BPM_LAUNCH_PATH",), ("BPM_QUEUE_BATCH",), ("BPM_DQ_FENCE",)):
@@ -276,7 +276,7 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
             env.pop(k, None)
         for k in on:
             # BPM_PLAN_MAX: plan records whatever the number of chains; BPM_LAUNCH_PATH=stream: the queue's memory types, HIP stream launches;
-            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release packets on coherent memory
+            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release packets (the default, spelled out)
             env[k] = {"BPM_PLAN_MAX": "1000000", "BPM_DIRECT_QUEUE": "0", "BPM_COHERENT_STATE": "0", "BPM_LAUNCH_PATH": "stream", "BPM_DQ_FENCE": "full"}.get(k, "1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
@@ -824,17 +824,20 @@ def test_direct_queue_equals_stream_launches(case):
 
 
 def test_coherence_probe_discriminates_memory_types():
-    """What lets the generation loop's packets go without a release fence is a property of the memory the state lives in, probed
-    once per device (sampler.hip: state_memory_is_coherent).  The probe must pass on that memory type and FAIL on ordinary
-    device memory (eight XCDs with an L2 each: without the release a block written on one XCD is read stale on another)."""
-    import ctypes as C
-    from bipymc_amd import _lib as L
-    lib = L.load()
-    w = C.c_int64(-2)
-    L.check(lib.bpm_debug_coherence_probe(0, 1, C.byref(w)))
-    assert w.value == 0, "state memory type is not coherent across XCDs without a release fence: %d wrong" % w.value
-    L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w)))
-    assert w.value > 0, "ordinary device memory passed the probe: it no longer discriminates (%d)" % w.value
+    """What would let the generation loop's packets go without a release fence is a property of the memory the state lives in, probed
+    once per device before the experimental mode relies on it (sampler.hip: state_memory_is_coherent).  The probe must pass on the
+    hardware-coherent memory type and FAIL on ordinary device memory (eight XCDs with an L2 each: without the release a block written
+    on one XCD is read stale on another).  In a process of its own: allocations of that memory type are not wanted in the test process
+    (tools/coherent_memory_hazard.py)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, os.getcwd()); from bipymc_amd import _lib as L; lib = L.load(); w = C.c_int64(-2); "
+            "L.check(lib.bpm_debug_coherence_probe(0, 1, C.byref(w))); a = w.value; L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w))); print(a, w.value)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(__file__), ".."), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    coherent_wrong, ordinary_wrong = (int(v) for v in out.stdout.split()[-2:])
+    assert coherent_wrong == 0, "the coherent memory type is not coherent across XCDs without a release fence: %d wrong" % coherent_wrong
+    assert ordinary_wrong > 0, "ordinary device memory passed the probe: it no longer discriminates (%d)" % ordinary_wrong
 
 
 def test_direct_queue_interleaved_with_other_entry_points():
