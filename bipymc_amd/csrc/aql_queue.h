@@ -95,6 +95,7 @@ class DirectQueue {
         if (nbytes > k.kernarg_size) nbytes = k.kernarg_size;       // (a kernel that ignores trailing arguments has a shorter segment)
         if (k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
         if (!next_slot()) return -1;
+        if (!(fence & RELEASE)) unreleased_ = true;
         char* slot = kernarg_ + (size_t)(widx_ % N_SLOTS) * SLOT_BYTES;
         std::memcpy(slot, args, nbytes);
         size_t written = nbytes;
@@ -159,6 +160,16 @@ class DirectQueue {
         if (failed_) return -1;
         if (!next_slot()) return -1;
         flush();
+        if (unreleased_) {
+            // packets without a release fence were dispatched: an (empty) kernel with acquire + release first, so that the caches end up as
+            // after the last kernel of a HIP stream (history rows of non-temporal stores may still wait in an L2)
+            if (!fence_kernel_.object) { why_ = "release-less packets without a fence kernel"; failed_ = true; return -1; }
+            uint64_t zero = 0;
+            if (launch(fence_kernel_, 64, 1, 64, &zero, sizeof(zero), FENCED) != 0) return -1;
+            unreleased_ = false;
+            flush();
+            if (!next_slot()) return -1;
+        }
         auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
         std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
         hsa_signal_store_relaxed(done_, 1);
@@ -179,6 +190,10 @@ class DirectQueue {
         busy_ = false;
         return 0;
     }
+    // the empty kernel drain() runs behind release-less packets (set once by the owner of the code object); without it launch() callers
+    // must keep the release fence
+    bool set_fence_kernel(const void* host_fn) { if (const DqKernel* k = kernel(host_fn)) fence_kernel_ = *k; return fence_kernel_.object != 0; }
+    bool has_fence_kernel() const { return fence_kernel_.object != 0; }
     bool busy() const { return busy_; }
     bool failed() const { return failed_; }
     const std::string& why() const { return why_; }
@@ -337,6 +352,8 @@ class DirectQueue {
     std::string why_;
     std::recursive_mutex mu_;
     std::map<const void*, DqKernel> kernels_;
+    DqKernel fence_kernel_;
+    bool unreleased_ = false;
 };
 
 }  // namespace bpm

@@ -141,6 +141,8 @@ struct PhaseArgs {
     uint32_t seg_off[MAX_SEG + 1];
     uint32_t n_seg, seg_me;     // number of ranks, this rank
     uint32_t acc_by_item;       // accept bytes indexed by the owner's item number (sorted records) instead of its local chain index
+    uint32_t wt;                // 1: the dispatch packet of this launch carries NO release fence -- what a later kernel reads (accepted state
+                                // rows, ln-like cache, accept counters) leaves through agent-scope (write-through) stores (store_row_wt)
     uint64_t seed;
     uint64_t t;            // absolute generation
     uint32_t k;            // generation within this run_mcmc call (demc.py:78)
@@ -413,6 +415,23 @@ __device__ __forceinline__ void store_row(double* row, int q, uint32_t ld, const
     for (int u = 0; u < DPL / 2; ++u) {
         const uint32_t pi = (uint32_t)(q + u * LPC);
         if (2 * pi < ld) reinterpret_cast<double2*>(row)[pi] = make_double2(v[2 * u], v[2 * u + 1]);
+    }
+}
+
+// Release-less launches (the library's own queue in the steady state, DESIGN.md section 5 "Packet fences"): an ordinary store leaves its
+// line dirty in one XCD's L2 until a release fence writes it back; without that fence the next kernel, on another XCD, would read the old
+// row from memory.  A relaxed agent-scope atomic store goes through to the memory side -- the memory model's own guarantee -- so the
+// state is visible to whatever runs next without any write-back of the caches.  (Two 8-byte stores per lane instead of one 16-byte
+// store: 3 % on the launch period when the packets do carry a release, which is why this path is chosen per launch.)
+template <int LPC, int DPL>
+__device__ __forceinline__ void store_row_wt(double* row, int q, uint32_t ld, const double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        if (2 * pi < ld) {
+            __hip_atomic_store(row + 2 * pi, v[2 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 2 * pi + 1, v[2 * u + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -890,7 +909,10 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     // accept bookkeeping without same-address atomics (8192 of them serialise at ~12 ns each):
     // every chain owns one counter, the host sums them (demc.py:143-150)
     if (q == 0) {
-        if (accepted) a.acc_count[li] = wk.acc_prev + 1u;
+        if (accepted) {
+            if (a.wt) __hip_atomic_store(&a.acc_count[li], wk.acc_prev + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else a.acc_count[li] = wk.acc_prev + 1u;
+        }
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
         if (a.accbits) a.accbits[a.acc_by_item ? wk.item : li] = accepted ? (uint8_t)1 : (uint8_t)0;
     }
@@ -903,8 +925,13 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         store_row<LPC, DPL>(a.x_next + (uint32_t)(li * ld), q, ld, nv);
         if (accepted && q == 0) a.ll[li] = new_ll;
     } else if (accepted) {
-        store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
-        if (q == 0) a.ll[li] = new_ll;
+        if (a.wt) {
+            store_row_wt<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
+            if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
+            if (q == 0) a.ll[li] = new_ll;
+        }
     }
     if (a.pack && accepted) {
         // sparse exchange: only rows that changed travel.  One slot per accepted chain (order irrelevant: the
@@ -1339,6 +1366,13 @@ __global__ __launch_bounds__(WAVE) void exchange_scatter_kernel(Layout L, double
     const double* src = blk + 2 + cap + (uint64_t)slot * L.ld;
     double* dst = row_ptr(L, id);
     for (uint32_t j = threadIdx.x; j < L.ld; j += WAVE) dst[j] = src[j];
+}
+
+// The (empty) kernel the library's own queue ends a session with when packets without a release fence have been dispatched: its own
+// packet carries acquire + release, so whatever still waits in an L2 (history rows of the non-temporal stores) is written back the way the
+// end of any HIP kernel would (DirectQueue::drain).
+__global__ __launch_bounds__(WAVE) void queue_fence_kernel(uint32_t* sink) {
+    if (sink && threadIdx.x == 0xffffu) *sink = blockIdx.x;        // (never true: a kernel that is not optimised away)
 }
 
 // Probe of the memory type the sampler's state is allocated from (sampler.hip: state_memory_is_coherent): launch number `shift` lets

@@ -135,10 +135,16 @@ static_assert(offsetof(FusedKernarg, a) == 24 && sizeof(FusedKernarg) == 24 + si
 static thread_local bpm::DirectQueue* g_dq = nullptr;
 static thread_local int g_dq_sig = -1;            // the next update dispatch carries this timing signal (bpm_step_timed)
 static thread_local bool g_dq_error = false;      // a dispatch could not be made: run_generations reports it
-// Fences of an update-kernel packet.  Default: agent-scope acquire + release, what a HIP stream puts around every kernel.
-// With the state in cached-coherent memory (dev_alloc_state) an update kernel leaves nothing in the L2s that the next one
-// could miss, and the release -- then the acquire too -- can go (experiment switch BPM_DQ_FENCE=acq|none, only honoured together
-// with BPM_COHERENT_STATE=1; the packet after a table build or after entering direct mode always acquires).
+// Fences of an update-kernel packet.  A HIP stream puts agent-scope acquire + release around every kernel; the release (write-back of
+// every XCD's L2 at the end of the kernel) is 0.6 us of a 6 us launch period at cfg2.  In the steady state the update kernel instead
+// sends what the next kernel reads (accepted rows, ln-like, accept counters) through agent-scope stores (PhaseArgs::wt, kernels.h:
+// store_row_wt) and its packet carries the acquire only; history rows (non-temporal stores, read by nobody before the drain) are
+// written back by the fenced empty kernel DirectQueue::drain puts behind such packets.  Burn-in generations (Welford moments, CR
+// slots) and half generations that rewrite more than WT_MAX_BYTES of state keep acquire + release with plain stores.
+// (BPM_DQ_FENCE=full: always; =none only together with the BPM_COHERENT_STATE=1 experiment.  The packet after a table build or after
+// entering direct mode always acquires.)
+static constexpr uint64_t WT_MAX_BYTES = 16ull << 20;      // N=65536 x d=100 (26 MB per half generation): 73.2 us / generation with
+                                                           // write-through stores, 70.1 with the release fence; 8.4 MB (cfg5): 56.9 / 58.3
 static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
 static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
@@ -485,6 +491,7 @@ static long long coherence_probe(bpm::DirectQueue* dq, bool coherent_alloc) {
     double* x = nullptr;
     long long wrong = -1;
     const bpm::DqKernel* k = dq->kernel(reinterpret_cast<const void*>(coherence_probe_kernel));
+    if (!dq->set_fence_kernel(reinterpret_cast<const void*>(queue_fence_kernel))) k = nullptr;      // (drain() behind release-less packets)
     if (k && dev_alloc_state(&x, (size_t)NB * WAVE, coherent_alloc) == 0) {
         std::vector<double> h((size_t)NB * WAVE);
         bool run = hipMemset(x, 0, h.size() * sizeof(double)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
@@ -703,8 +710,10 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         // bpm_set_launch_path(h, 0, -1) -- what the rocprofv3 --pmc passes of tools/profile_bench.sh use (see there)
         if (const char* lp = getenv("BPM_LAUNCH_PATH")) s->dq_enabled = strcmp(lp, "stream") != 0;
     }
-    // The packets of the generation loop carry agent-scope acquire + release, like every kernel of a HIP stream, and the state lives in
-    // ordinary device memory.  EXPERIMENTAL, opt-in (BPM_COHERENT_STATE=1): state, ln-like cache, accept counters, Welford moments and CR
+    // The state lives in ordinary device memory; the steady-state packets of the generation loop carry the acquire fence only and the
+    // update kernel writes what its successor reads with agent-scope stores (g_dq_update_fence above).  Without the fence kernel (not
+    // found among the loaded code objects) or with BPM_DQ_FENCE=full: acquire + release on every packet, like a HIP stream.
+    // EXPERIMENTAL, opt-in (BPM_COHERENT_STATE=1): state, ln-like cache, accept counters, Welford moments and CR
     // state in the GPU's hardware-coherent memory type (dev_alloc_state) with acquire-ONLY packets -- the end-of-kernel L2 write-back,
     // 0.7 us of a 6.1 us launch period at cfg2, goes (10.8 instead of 12.0 us per generation).  NOT the default because it is not safe:
     // with that memory type in use, history rows (and once whole histories) came back holding older contents in a sequence of
@@ -715,7 +724,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         const char* c = getenv("BPM_COHERENT_STATE");
         // (BPM_COHERENT_STATE=2: take the memory type on trust, without the probe -- diagnostics)
         s->coherent = s->dq != nullptr && c && atoi(c) != 0 && (atoi(c) == 2 || state_memory_is_coherent(s->dq, cfg->device));
-        s->dq_fence = s->coherent ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
+        const bool fence_kernel = s->dq != nullptr && s->dq->set_fence_kernel(reinterpret_cast<const void*>(queue_fence_kernel));
+        s->dq_fence = fence_kernel ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
         if (const char* f = getenv("BPM_DQ_FENCE")) {
             if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
             else if (!strcmp(f, "full")) s->dq_fence = bpm::DirectQueue::FENCED;
@@ -1129,6 +1139,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
+        a.wt = (g_dq && !(g_dq_update_fence & bpm::DirectQueue::RELEASE) && !s->coherent) ? 1u : 0u;
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;
@@ -1505,7 +1516,9 @@ static int run_generations(const Group& g, int64_t n_gens) {
             }
             g_dq = direct ? s0->dq : nullptr;
             g_dq_error = false;
-            g_dq_update_fence = s0->dq_fence;
+            // (half a generation rewrites at most N/2 + 1 rows)
+            const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
+            g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
             if (direct) {
                 s0->dq->flush();                                        // one doorbell per generation
@@ -1653,7 +1666,8 @@ extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc,
 extern "C" int bpm_set_launch_path(bpm_handle_t s, int32_t direct, int32_t fence) {
     CK(check_handle(s));
     if (fence != -1 && fence != 0 && fence != 1 && fence != 3) return fail("bpm_set_launch_path: fence must be -1 (keep), 0 (none), 1 (acquire) or 3 (acquire + release)");
-    if (fence >= 0 && fence < 3 && !s->coherent) return fail("bpm_set_launch_path: packets without a release fence need the state in cached-coherent memory");
+    if (fence == 0 && !s->coherent) return fail("bpm_set_launch_path: packets without an acquire fence need the state in cached-coherent memory");
+    if (fence == 1 && (!s->dq || !s->dq->has_fence_kernel())) return fail("bpm_set_launch_path: acquire-only packets need the library's queue and its fence kernel");
     s->dq_enabled = direct != 0;
     if (fence >= 0) s->dq_fence = fence;
     return 0;

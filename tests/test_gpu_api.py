@@ -276,7 +276,7 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
             env.pop(k, None)
         for k in on:
             # BPM_PLAN_MAX: plan records whatever the number of chains; BPM_LAUNCH_PATH=stream: the queue's memory types, HIP stream launches;
-            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release packets (the default, spelled out)
+            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release on every packet, plain stores
             env[k] = {"BPM_PLAN_MAX": "1000000", "BPM_DIRECT_QUEUE": "0", "BPM_COHERENT_STATE": "0", "BPM_LAUNCH_PATH": "stream", "BPM_DQ_FENCE": "full"}.get(k, "1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
@@ -769,13 +769,15 @@ def test_many_ranks_sorted_records_and_fallback(R):
     assert ranks[0].exchange_stats()["replay_gens"] == G - 6
 
 
-@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker", "dream_gauss100_big"])
+@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker", "dream_gauss100_big", "dream_gauss100_wide"])
 def test_direct_queue_equals_stream_launches(case):
     """The generation loop of a single-GPU sampler is dispatched by AQL packets the library writes into its own queue
-    (bipymc_amd/csrc/aql_queue.h), with the fences a HIP stream puts around its kernels; launching the same kernels on the
-    HIP stream must give the same bits: state, ln-like, the whole history, CR statistics, accept counters.  The runs cross
-    a table window (64 generations), grow the history while the queue is busy (no reservation), pass through burn-in with
-    the outlier check (HIP-stream sections between drains) and call the timed entry point."""
+    (bipymc_amd/csrc/aql_queue.h).  In the steady state those packets carry the acquire fence only and the update kernel writes what
+    its successor reads with agent-scope stores (sampler.hip: g_dq_update_fence); launching the same kernels on the HIP stream, or
+    through the queue with a HIP stream's acquire + release on every packet, must give the same bits: state, ln-like, the whole
+    history, CR statistics, accept counters.  The runs cross a table window (64 generations), grow the history while the queue is
+    busy (no reservation), pass through burn-in with the outlier check (HIP-stream sections between drains) and call the timed entry
+    point; the "wide" case rewrites more than 16 MiB of state per half generation (the size from which the packets keep the release)."""
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
     from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
@@ -783,6 +785,8 @@ def test_direct_queue_equals_stream_launches(case):
         spec, algo, N, kw, G = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 512, dict(burnin_gen=20, n_cr_gen=4), 150
     elif case == "dream_gauss100_big":
         spec, algo, N, kw, G = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 8192, dict(burnin_gen=30, n_cr_gen=4), 100
+    elif case == "dream_gauss100_wide":
+        spec, algo, N, kw, G = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 49152, dict(burnin_gen=4, n_cr_gen=2), 14
     elif case == "dream_mix8_outlier":
         spec, algo, N, kw, G = (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 20000,
                                 dict(burnin_gen=60, n_cr_gen=4, del_pairs=2, outlier_every=20), 140)
@@ -795,7 +799,7 @@ def test_direct_queue_equals_stream_launches(case):
         e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
         ls = e.launch_stats()
         assert ls["has_queue"], "no direct AQL queue on this box: " + str(ls)
-        assert not ls["coherent_state"] and ls["fence"] == "acquire+release", ls      # (the default: ordinary memory, a HIP stream's fences)
+        assert not ls["coherent_state"] and ls["fence"] == "acquire", ls      # (the default: ordinary memory, release-less steady state)
         e.set_launch_path(direct, fence)
         e.set_state(X0)
         e.begin_run()
