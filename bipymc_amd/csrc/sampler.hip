@@ -146,6 +146,7 @@ static thread_local bool g_dq_error = false;      // a dispatch could not be mad
 static constexpr uint64_t WT_MAX_BYTES = 16ull << 20;      // N=65536 x d=100 (26 MB per half generation): 73.2 us / generation with
                                                            // write-through stores, 70.1 with the release fence; 8.4 MB (cfg5): 56.9 / 58.3
 static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
+static thread_local bool g_wt_stores = false;             // this generation's update kernels store through (PhaseArgs::wt)
 static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
 template <class K>
@@ -1139,7 +1140,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
-        a.wt = (g_dq && !(g_dq_update_fence & bpm::DirectQueue::RELEASE) && !s->coherent) ? 1u : 0u;
+        a.wt = g_wt_stores ? 1u : 0u;
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;
@@ -1519,7 +1520,11 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // (half a generation rewrites at most N/2 + 1 rows)
             const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
+            // (BPM_WT_STORES=1: the same stores on HIP-stream launches -- the rocprofv3 counter passes, which cannot run on the queue)
+            static const bool wt_on_stream = getenv("BPM_WT_STORES") != nullptr;
+            g_wt_stores = !plain_stores && !s0->coherent && (direct ? !(g_dq_update_fence & bpm::DirectQueue::RELEASE) : (wt_on_stream && g.R == 1 && s0->world == 1));
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
+            g_wt_stores = false;
             if (direct) {
                 s0->dq->flush();                                        // one doorbell per generation
                 g_dq = nullptr;

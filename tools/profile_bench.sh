@@ -18,15 +18,16 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/b
 # rocprofv3's counter collection serialises every dispatch behind its own packets and, with this library's packets arriving through
 # its intercepting queue, stops forwarding them some hundred dispatches into burn-in more often than not (a drain timeout,
 # "N incomplete dispatches" at exit; not with --kernel-trace, never without the profiler; cause not found).  The counters are
-# properties of the kernel, not of how it was launched.
-export BPM_LAUNCH_PATH=stream BPM_QUEUE_TIMEOUT_S=30
+# properties of the kernel, not of how it was launched; BPM_WT_STORES=1 makes the stream launches use the agent-scope stores the
+# queue's release-less packets go with (sampler.hip: g_wt_stores), so the counters are those of the kernel as shipped.
+export BPM_LAUNCH_PATH=stream BPM_WT_STORES=1 BPM_QUEUE_TIMEOUT_S=30
 echo "pmc FETCH_SIZE" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
 echo "pmc WRITE_SIZE" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
 echo "pmc SQ" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
-unset BPM_LAUNCH_PATH
+unset BPM_LAUNCH_PATH BPM_WT_STORES
 echo "summaries" >> $O/progress.txt
 cd $R
 K="phase_fused_kernel<1, 1, 64, 2, 3, 1>"
