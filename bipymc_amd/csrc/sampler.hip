@@ -143,8 +143,9 @@ static thread_local bool g_dq_error = false;      // a dispatch could not be mad
 // slots) and half generations that rewrite more than WT_MAX_BYTES of state keep acquire + release with plain stores.
 // (BPM_DQ_FENCE=full: always; =none only together with the BPM_COHERENT_STATE=1 experiment.  The packet after a table build or after
 // entering direct mode always acquires.)
-static constexpr uint64_t WT_MAX_BYTES = 16ull << 20;      // N=65536 x d=100 (26 MB per half generation): 73.2 us / generation with
-                                                           // write-through stores, 70.1 with the release fence; 8.4 MB (cfg5): 56.9 / 58.3
+static constexpr uint64_t WT_MAX_BYTES = 4ull << 20;       // per generation, write-through stores / release fence, same box: 3.3 MB (cfg2)
+                                                           // 11.2 / 12.5 us, 1 MB (cfg5 / 8) 9.7 / 11.0, 0.5 MB (cfg3) 13.8 / 15.2;
+                                                           // 8.4 MB (cfg5) 59.2 / 58.8; 26 MB (N=65536 x d=100) 73.2 / 70.1
 static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
 static thread_local bool g_wt_stores = false;             // this generation's update kernels store through (PhaseArgs::wt)
 static thread_local bool g_dq_need_acquire = false;

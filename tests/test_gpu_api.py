@@ -778,7 +778,7 @@ def test_direct_queue_equals_stream_launches(case):
     through the queue with a HIP stream's acquire + release on every packet, must give the same bits: state, ln-like, the whole
     history, CR statistics, accept counters.  The runs cross a table window (64 generations), grow the history while the queue is
     busy (no reservation), pass through burn-in with the outlier check (HIP-stream sections between drains) and call the timed entry
-    point; the "wide" case rewrites more than 16 MiB of state per half generation (the size from which the packets keep the release)."""
+    point; the "wide" case rewrites more than 4 MiB of state per half generation (the size from which the packets keep the release)."""
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
     from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd

@@ -18,14 +18,16 @@ def run(name, algo, N, spec, x0, bytes_per_update, gens=500, **kw):
     tid, tp, d = spec
     e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=42, **kw)
     e.set_state(x0)
-    e.reserve_history(gens * 2 + 80)
+    e.reserve_history(gens * 3 + 80)
     e.begin_run()
     e.step(60)
     e.synchronize()
-    t0 = time.perf_counter()
-    e.step(gens)
-    e.synchronize()
-    el = time.perf_counter() - t0
+    el = 1e9
+    for _ in range(3):        # best of three windows (the first one of a process finds the GPU at idle clocks)
+        t0 = time.perf_counter()
+        e.step(gens)
+        e.synchronize()
+        el = min(el, time.perf_counter() - t0)
     st = e.stats()
     ups = N * gens / el
     print("%-28s N=%-7d d=%-4d %.3e updates/s  %.2f us/gen  %.1f GB/s algorithmic (%.3f of 8 TB/s)  acc=%.3f"
