@@ -274,7 +274,11 @@ __device__ __forceinline__ void cr_fold(const double* tot, const double* part, u
 __device__ __forceinline__ void cr_write_totals(const CrTotals& T, uint32_t n_cr, double* out) {
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m)
-        if (m < (int)n_cr) { out[m] = T.p[m]; out[MAX_CR + m] = T.d[m]; out[2 * MAX_CR + m] = T.n[m]; }
+        if (m < (int)n_cr) {      // (agent-scope stores: the packet of a CR reduction kernel carries no release fence on the library's own queue)
+            __hip_atomic_store(&out[m], T.p[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&out[MAX_CR + m], T.d[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&out[2 * MAX_CR + m], T.n[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 }
 
 __device__ __forceinline__ double box_muller(uint32_t w1, uint32_t w2) {
@@ -1315,14 +1319,11 @@ __global__ __launch_bounds__(CR_PART_THREADS) void cr_partial_kernel(Layout L, u
     if (tid < n_cr) {
         double d = 0.0, n = 0.0;
         for (int w = 0; w < CR_PART_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
-        if (TICKET) {
-            __hip_atomic_store(&part[tid * CR_PARTS + blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&part[(MAX_CR + tid) * CR_PARTS + blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket
-        } else {
-            part[tid * CR_PARTS + blockIdx.x] = d;
-            part[(MAX_CR + tid) * CR_PARTS + blockIdx.x] = n;
-        }
+        // agent-scope stores: read by other workgroups of the SAME launch (ticket form), or by cr_final_kernel behind a packet without a
+        // release fence (the library's own queue: sampler.hip finish_generation)
+        __hip_atomic_store(&part[tid * CR_PARTS + blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[(MAX_CR + tid) * CR_PARTS + blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (TICKET) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket
     }
     if (!TICKET) return;
     __shared__ uint32_t s_last;

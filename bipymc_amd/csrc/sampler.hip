@@ -1186,10 +1186,12 @@ static int finish_generation(bpm_sampler* s) {
             struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, s->cr_part, nb, (uint32_t)s->cfg.n_cr, s->cr_state};
             const bpm::DqKernel* kp = g_dq->kernel(big ? reinterpret_cast<const void*>(cr_partial_kernel<1024, true>) : reinterpret_cast<const void*>(cr_partial_kernel<256, false>));
             const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(cr_final_kernel));
-            int fence = g_dq_update_fence;
-            if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+            // the reduction kernels write a few hundred bytes, all with agent-scope stores: no release on their packets (s->dq_fence: the
+            // sampler's steady-state fence) -- the update kernels before them keep theirs
+            const int fence = s->dq_fence | bpm::DirectQueue::ACQUIRE;
+            g_dq_need_acquire = false;
             if (!kp || !kf || g_dq->launch(*kp, nb, 1, big ? 1024u : 256u, &pa, sizeof(pa), fence) != 0 ||
-                (!big && g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), g_dq_update_fence) != 0))
+                (!big && g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0))
                 return fail("direct AQL queue: CR reduction kernels: " + g_dq->why());
         } else if (big) {
             hipLaunchKernelGGL((cr_partial_kernel<1024, true>), dim3(nb), dim3(1024), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr, span, s->cr_part, s->cr_state,
