@@ -95,7 +95,10 @@ class DirectQueue {
         if (nbytes > k.kernarg_size) nbytes = k.kernarg_size;       // (a kernel that ignores trailing arguments has a shorter segment)
         if (k.kernarg_size > SLOT_BYTES) { why_ = "kernel argument block of " + k.name + " does not fit"; failed_ = true; return -1; }
         if (!next_slot()) return -1;
+        // a release at the end of a kernel that ran on every XCD (>= 64 workgroups) writes back what EARLIER release-less kernels left
+        // in the L2s as well (every packet waits for its predecessor: barrier bit)
         if (!(fence & RELEASE)) unreleased_ = true;
+        else if ((uint64_t)grid_x * grid_y >= 64) unreleased_ = false;
         char* slot = kernarg_ + (size_t)(widx_ % N_SLOTS) * SLOT_BYTES;
         std::memcpy(slot, args, nbytes);
         size_t written = nbytes;

@@ -147,6 +147,9 @@ static constexpr uint64_t WT_MAX_BYTES = 4ull << 20;       // per generation, wr
                                                            // 11.2 / 12.5 us, 1 MB (cfg5 / 8) 9.7 / 11.0, 0.5 MB (cfg3) 13.8 / 15.2;
                                                            // 8.4 MB (cfg5) 59.2 / 58.8; 26 MB (N=65536 x d=100) 73.2 / 70.1
 static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
+static thread_local bool g_dq_call_last_gen = false;      // run_generations: this is the last generation of the bpm_step call ...
+static thread_local bool g_dq_release_this = false;       // ... whose last update dispatch carries the release: the drain that usually
+                                                           // follows the call then needs no fence kernel (2.5 us of a short window)
 static thread_local bool g_wt_stores = false;             // this generation's update kernels store through (PhaseArgs::wt)
 static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
@@ -161,6 +164,7 @@ static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a
         const int sig = g_dq_sig; g_dq_sig = -1;
         int fence = g_dq_update_fence;
         if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+        if (g_dq_release_this) { fence |= bpm::DirectQueue::RELEASE; g_dq_release_this = false; }
         if (!k || g_dq->launch(*k, grid, 1, block, &ka, sizeof(ka), fence, sig) != 0) g_dq_error = true;
         ++g_timed_launches; ++g_n_direct;
         return;
@@ -1394,6 +1398,7 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (s->cur_args[ph].n_items > 0) {
+                    g_dq_release_this = g_dq && g_dq_call_last_gen && (ph == 1 || s->cur_args[1].n_items == 0);
                     if (g_dq && s->timed_last_gen >= 0) {
                         // direct mode: attaching a time stamp costs the host nothing -- the first and the last update dispatch of the call
                         if (s->timed_want_first) { s->timed_want_first = false; g_dq_sig = 0; s->timed_l0 = g_timed_launches; }
@@ -1526,8 +1531,9 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // (BPM_WT_STORES=1: the same stores on HIP-stream launches -- the rocprofv3 counter passes, which cannot run on the queue)
             static const bool wt_on_stream = getenv("BPM_WT_STORES") != nullptr;
             g_wt_stores = !plain_stores && !s0->coherent && (direct ? !(g_dq_update_fence & bpm::DirectQueue::RELEASE) : (wt_on_stream && g.R == 1 && s0->world == 1));
+            g_dq_call_last_gen = direct && done == n_gens - 1;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
-            g_wt_stores = false;
+            g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false;
             if (direct) {
                 s0->dq->flush();                                        // one doorbell per generation
                 g_dq = nullptr;
