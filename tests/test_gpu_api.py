@@ -887,6 +887,68 @@ def test_direct_queue_interleaved_with_other_entry_points():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("seq_seed", [77, 1234])
+@pytest.mark.parametrize("case", ["dream_gauss100", "demc_banana_snooker", "dream_mix8"])
+def test_random_call_sequences_equal_on_every_launch_path(case, seq_seed):
+    """The steady state on the library's queue leaves the L2 write-back to the last dispatch of a step call (or to a fenced kernel at the
+    drain) and sends what the next kernel reads through agent-scope stores: whatever a caller does between two step calls -- reads of
+    state / ln-like / history rows / moments, writes of rows or of the whole state, launch-path switches, new runs -- must see and leave
+    exactly what HIP-stream launches do.  Seeded random sequences of 150 such calls, three launch configurations, every read compared."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    if case == "dream_gauss100":
+        spec, algo, N, kw = d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 2048, dict(burnin_gen=9, n_cr_gen=3)
+    elif case == "dream_mix8":
+        spec, algo, N, kw = mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 6000, dict(burnin_gen=12, n_cr_gen=3, outlier_every=5)
+    else:
+        spec, algo, N, kw = banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 3001, dict(p_snooker=0.15)
+    tid, tp, d = spec
+    X0 = np.random.RandomState(4).normal(size=(N, d)) + 0.7
+    outs = []
+    for direct, fence in ((True, -1), (False, -1), (True, 3)):
+        rs = np.random.RandomState(seq_seed)                 # the same sequence for every configuration
+        e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=31, **kw)
+        e.set_launch_path(direct, fence)
+        e.set_state(X0)
+        e.begin_run()
+        seen = []
+        for _ in range(150):
+            op = rs.randint(0, 10)
+            if op <= 3:
+                e.step(int(rs.choice([1, 1, 2, 3, 7, 20, 65])))
+            elif op == 4:
+                e.step_timed(int(rs.choice([1, 2, 9])))
+            elif op == 5:
+                seen.append(e.get_state())
+            elif op == 6:
+                seen.append(e.get_loglike().copy())
+                rows = e.history_rows()
+                lo = max(0, rows - 3)
+                seen.append(e.get_history(lo, rows))
+                seen.append(e.get_loglike_history(lo, rows))
+            elif op == 7:
+                X = e.get_state()
+                X[rs.randint(0, N, size=5)] += 0.25                # rewrite a few rows through the stream
+                e.set_state(X)
+            elif op == 8:
+                cnt, s1, s2, sh = e.reduce_moments(0)
+                seen.append(np.concatenate([[cnt], s1, s2]))
+                st = e.stats()
+                seen.append(np.array([st["local_n_accepted"], st["local_n_rejected"], st["k_gen"]], dtype=float))
+            else:
+                flip = bool(rs.randint(0, 2))                                   # (drawn in every configuration)
+                e.set_launch_path(direct and flip, fence)
+        seen.append(e.get_state())
+        seen.append(e.get_history(0, e.history_rows()))
+        outs.append(seen)
+        e.close()
+    for o in outs[1:]:
+        assert len(o) == len(outs[0])
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 def test_sampler_sequence_in_one_process_keeps_histories_intact():
     """Samplers of different shapes created, run through both launch paths and destroyed one after the other in ONE process, then a
     run with a history row that is written twice (bpm_set_state in the middle) and a history that grows through several buffers: the
