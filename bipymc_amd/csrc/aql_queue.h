@@ -139,6 +139,9 @@ class DirectQueue {
         // one doorbell never covers packets on both sides of the ring's end (a queue-intercepting tool -- rocprofv3 -- copies the
         // packets of a doorbell as one linear range)
         if (n_unpublished_ >= batch_cap() || (widx_ & (q_->size - 1)) == 0) flush();
+        // BPM_QUEUE_INFLIGHT=n: never more than n dispatches between two drains (a throttle for tools that sit between this queue and
+        // the hardware queue -- rocprofv3's counter collection: tools/profile_bench.sh)
+        if (inflight_cap() && !in_drain_ && ++since_drain_ >= inflight_cap()) { since_drain_ = 0; if (drain() != 0) return -1; busy_ = true; }
         return 0;
     }
 
@@ -161,6 +164,8 @@ class DirectQueue {
         if (timeout_s < 0.0) timeout_s = wait_limit_s();
         if (!busy_) return 0;
         if (failed_) return -1;
+        struct InDrain { bool& f; bool old; InDrain(bool& x) : f(x), old(x) { f = true; } ~InDrain() { f = old; } } guard(in_drain_);
+        since_drain_ = 0;
         if (!next_slot()) return -1;
         flush();
         if (unreleased_) {
@@ -328,6 +333,10 @@ class DirectQueue {
         static const uint32_t v = getenv("BPM_QUEUE_BATCH") ? (uint32_t)std::max(1, std::min((int)MAX_UNPUBLISHED, atoi(getenv("BPM_QUEUE_BATCH")))) : MAX_UNPUBLISHED;
         return v;
     }
+    static uint32_t inflight_cap() {
+        static const uint32_t v = getenv("BPM_QUEUE_INFLIGHT") ? (uint32_t)std::max(0, atoi(getenv("BPM_QUEUE_INFLIGHT"))) : 0u;
+        return v;
+    }
     static double wait_limit_s() {
         static const double v = getenv("BPM_QUEUE_TIMEOUT_S") ? atof(getenv("BPM_QUEUE_TIMEOUT_S")) : 120.0;
         return v;
@@ -357,6 +366,8 @@ class DirectQueue {
     std::map<const void*, DqKernel> kernels_;
     DqKernel fence_kernel_;
     bool unreleased_ = false;
+    bool in_drain_ = false;
+    uint32_t since_drain_ = 0;
 };
 
 }  // namespace bpm

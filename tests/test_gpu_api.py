@@ -265,20 +265,20 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     import tempfile
     res = []
     switches = ("BPM_FORCE_MODE1", "BPM_NO_PLAN", "BPM_NO_PERM_TAB", "BPM_PLAN_MAX", "BPM_NO_HOT", "BPM_GRAPH", "BPM_DIRECT_QUEUE", "BPM_COHERENT_STATE",
-                "BPM_DQ_FENCE", "BPM_LAUNCH_PATH", "BPM_QUEUE_BATCH", "BPM_WT_STORES")
+                "BPM_DQ_FENCE", "BPM_LAUNCH_PATH", "BPM_QUEUE_BATCH", "BPM_WT_STORES", "BPM_QUEUE_INFLIGHT")
     # (BPM_DIRECT_QUEUE=0: HIP stream launches instead of the library's own AQL queue; BPM_COHERENT_STATE=0: the default spelled out --
     # the experimental value 1 is not part of the suite: tools/coherent_memory_hazard.py)
     for on in ((), ("BPM_NO_HOT",), ("BPM_GRAPH",), ("BPM_GRAPH", "BPM_NO_HOT"), ("BPM_FORCE_MODE1",), ("BPM_NO_PLAN",), ("BPM_NO_PERM_TAB",), ("BPM_FORCE_MODE1", "BPM_NO_PLAN"),
                ("BPM_PLAN_MAX",), ("BPM_PLAN_MAX", "BPM_FORCE_MODE1"), ("BPM_DIRECT_QUEUE",), ("BPM_DIRECT_QUEUE", "BPM_NO_HOT"), ("BPM_COHERENT_STATE",),
                ("BPM_COHERENT_STATE", "BPM_NO_PLAN"), ("BPM_LAUNCH_PATH",), ("BPM_QUEUE_BATCH",), ("BPM_DQ_FENCE",),
-               ("BPM_LAUNCH_PATH", "BPM_WT_STORES")):
+               ("BPM_LAUNCH_PATH", "BPM_WT_STORES"), ("BPM_QUEUE_INFLIGHT",)):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)
         for k in on:
             # BPM_PLAN_MAX: plan records whatever the number of chains; BPM_LAUNCH_PATH=stream: the queue's memory types, HIP stream launches;
-            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release on every packet, plain stores; BPM_WT_STORES=1: the queue's agent-scope stores on stream launches
-            env[k] = {"BPM_PLAN_MAX": "1000000", "BPM_DIRECT_QUEUE": "0", "BPM_COHERENT_STATE": "0", "BPM_LAUNCH_PATH": "stream", "BPM_DQ_FENCE": "full"}.get(k, "1")
+            # BPM_QUEUE_BATCH=1: a doorbell per packet; BPM_DQ_FENCE=full: acquire + release on every packet, plain stores; BPM_WT_STORES=1: the queue's agent-scope stores on stream launches; BPM_QUEUE_INFLIGHT=1..: a drain every so many dispatches
+            env[k] = {"BPM_PLAN_MAX": "1000000", "BPM_DIRECT_QUEUE": "0", "BPM_COHERENT_STATE": "0", "BPM_LAUNCH_PATH": "stream", "BPM_DQ_FENCE": "full", "BPM_QUEUE_INFLIGHT": "3"}.get(k, "1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
             subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))

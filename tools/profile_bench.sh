@@ -14,20 +14,19 @@ python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
 cd /tmp; export TMPDIR=/tmp
 echo "kernel trace" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
-# The counter passes launch on the HIP stream (BPM_LAUNCH_PATH=stream: same kernels, the launch path of bpm_set_launch_path(h, 0, -1)).
-# rocprofv3's counter collection serialises every dispatch behind its own packets and, with this library's packets arriving through
-# its intercepting queue, stops forwarding them some hundred dispatches into burn-in more often than not (a drain timeout,
-# "N incomplete dispatches" at exit; not with --kernel-trace, never without the profiler; cause not found).  The counters are
-# properties of the kernel, not of how it was launched; BPM_WT_STORES=1 makes the stream launches use the agent-scope stores the
-# queue's release-less packets go with (sampler.hip: g_wt_stores), so the counters are those of the kernel as shipped.
-export BPM_LAUNCH_PATH=stream BPM_WT_STORES=1 BPM_QUEUE_TIMEOUT_S=30
+# The counter passes run on the library's own queue like everything else, throttled to 64 dispatches between two drains
+# (BPM_QUEUE_INFLIGHT): rocprofv3's counter collection serialises every dispatch behind packets of its own and stops forwarding the
+# packets of a queue that has more than a few hundred dispatches outstanding (fine with 256, a drain timeout with 600 or without a
+# limit; a HIP stream never gets that far ahead of the profiler because its launch calls block).  BPM_LAUNCH_PATH=stream BPM_WT_STORES=1
+# is the alternative: same kernels, same stores, launched on the HIP stream.
+export BPM_QUEUE_INFLIGHT=64 BPM_QUEUE_TIMEOUT_S=30
 echo "pmc FETCH_SIZE" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
 echo "pmc WRITE_SIZE" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
 echo "pmc SQ" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
-unset BPM_LAUNCH_PATH BPM_WT_STORES
+unset BPM_QUEUE_INFLIGHT
 echo "summaries" >> $O/progress.txt
 cd $R
 K="phase_fused_kernel<1, 1, 64, 2, 3, 1>"
