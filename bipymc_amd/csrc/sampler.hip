@@ -712,8 +712,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (s->world == 1 && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
-        // BPM_LAUNCH_PATH=stream: everything as with the queue (state in coherent memory) but launched on the HIP stream, like
-        // bpm_set_launch_path(h, 0, -1) -- what the rocprofv3 --pmc passes of tools/profile_bench.sh use (see there)
+        // BPM_LAUNCH_PATH=stream: the sampler keeps its queue but launches on the HIP stream, like bpm_set_launch_path(h, 0, -1)
         if (const char* lp = getenv("BPM_LAUNCH_PATH")) s->dq_enabled = strcmp(lp, "stream") != 0;
     }
     // The state lives in ordinary device memory; the steady-state packets of the generation loop carry the acquire fence only and the
