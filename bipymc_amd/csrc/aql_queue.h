@@ -1,6 +1,6 @@
 // DirectQueue: the sampler's own user-mode AQL queue (host side only).
 //
-// Why: the steady state of a run is two DEPENDENT update kernels of ~6 us per generation.  A HIP launch call costs the host
+// Why: the steady state of a run is two DEPENDENT update kernels of 5-6 us per generation.  A HIP launch call costs the host
 // 2.4-4.8 us (and now and then 10-30 us), so a call that starts from a drained queue -- the 20 generations the driver times --
 // runs host-paced.  Here the library writes the 64-byte AQL dispatch packets itself: kernel
 // arguments into a ring in device memory (through the PCIe BAR), the packet into the queue's ring, one doorbell per
@@ -9,10 +9,13 @@
 // in HOST memory cost 27 us per 4096-wavefront dispatch, hence the device ring).
 //
 // What it is not: a second code path for the kernels.  The kernel objects are the ones HIP loaded from this library's own fat
-// binary (found through the HSA loader's executable list), the packets carry the barrier bit and agent-scope fences like a HIP
-// stream's (an experimental mode of the sampler drops the release: sampler.hip, bpm_create; not the default), and memory
-// is HIP's.  Ordering against the sampler's HIP stream is by the host: the
-// sampler drains one before it uses the other (transitions happen at the end of burn-in and at the API boundary only).
+// binary (found through the HSA loader's executable list), every packet carries the barrier bit, and memory is HIP's.  Fences are the
+// caller's choice per packet: agent-scope acquire + release like a HIP stream's, or the acquire only -- the sampler's steady state,
+// whose kernels send what their successor reads through agent-scope stores (sampler.hip: g_dq_update_fence).  The queue keeps track of
+// release-less packets: drain() puts a fenced empty kernel behind them unless a later kernel on every XCD has released since.
+// Ordering against the sampler's HIP stream is by the host: the sampler drains one before it uses the other (transitions happen at
+// the end of burn-in and at the API boundary only).  BPM_QUEUE_INFLIGHT=n bounds the dispatches between two drains (for tools that
+// sit between this queue and the hardware queue: rocprofv3's counter collection stalls behind a few hundred outstanding dispatches).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
