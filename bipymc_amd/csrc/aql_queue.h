@@ -15,7 +15,8 @@
 // release-less packets: drain() puts a fenced empty kernel behind them unless a later kernel on every XCD has released since.
 // Ordering against the sampler's HIP stream is by the host: the sampler drains one before it uses the other (transitions happen at
 // the end of burn-in and at the API boundary only).  BPM_QUEUE_INFLIGHT=n bounds the dispatches between two drains (for tools that
-// sit between this queue and the hardware queue: rocprofv3's counter collection stalls behind a few hundred outstanding dispatches).
+// sit between this queue and the hardware queue: rocprofv3's counter collection stalls behind a few hundred outstanding dispatches;
+// chosen automatically, 64, when ROCPROF_COUNTER_COLLECTION is set in the environment).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
@@ -337,7 +338,9 @@ class DirectQueue {
         return v;
     }
     static uint32_t inflight_cap() {
-        static const uint32_t v = getenv("BPM_QUEUE_INFLIGHT") ? (uint32_t)std::max(0, atoi(getenv("BPM_QUEUE_INFLIGHT"))) : 0u;
+        // under rocprofv3's counter collection (it exports ROCPROF_COUNTER_COLLECTION=1 to the profiled process) 64 unless told otherwise
+        static const uint32_t v = getenv("BPM_QUEUE_INFLIGHT") ? (uint32_t)std::max(0, atoi(getenv("BPM_QUEUE_INFLIGHT")))
+                                  : (getenv("ROCPROF_COUNTER_COLLECTION") && atoi(getenv("ROCPROF_COUNTER_COLLECTION")) != 0 ? 64u : 0u);
         return v;
     }
     static double wait_limit_s() {

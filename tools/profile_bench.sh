@@ -17,7 +17,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/b
 # The counter passes run on the library's own queue like everything else, throttled to 64 dispatches between two drains
 # (BPM_QUEUE_INFLIGHT): rocprofv3's counter collection serialises every dispatch behind packets of its own and stops forwarding the
 # packets of a queue that has more than a few hundred dispatches outstanding (fine with 256, a drain timeout with 600 or without a
-# limit; a HIP stream never gets that far ahead of the profiler because its launch calls block).  BPM_LAUNCH_PATH=stream BPM_WT_STORES=1
+# limit; a HIP stream never gets that far ahead of the profiler because its launch calls block).  The library applies this bound by itself
+# when ROCPROF_COUNTER_COLLECTION is in its environment; it is spelled out here.  BPM_LAUNCH_PATH=stream BPM_WT_STORES=1
 # is the alternative: same kernels, same stores, launched on the HIP stream.
 export BPM_QUEUE_INFLIGHT=64 BPM_QUEUE_TIMEOUT_S=30
 echo "pmc FETCH_SIZE" >> $O/progress.txt
