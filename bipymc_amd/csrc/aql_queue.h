@@ -196,7 +196,9 @@ class DirectQueue {
         const auto t0 = std::chrono::steady_clock::now();
         while (hsa_signal_load_scacquire(done_) > 0) {                       // polling: a parked thread wakes up on a slow clock
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-                why_ = "timeout waiting for the AQL queue to drain"; failed_ = true; return -1;
+                why_ = "timeout waiting for the AQL queue to drain (a tool sitting between this queue and the hardware? BPM_QUEUE_INFLIGHT=64 bounds the "
+                       "dispatches in flight, BPM_DIRECT_QUEUE=0 launches on the HIP stream)";
+                failed_ = true; return -1;
             }
         }
         busy_ = false;
