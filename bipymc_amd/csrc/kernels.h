@@ -1395,9 +1395,8 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)n_gens * N) return;
     const uint32_t g = (uint32_t)(e / N), k = (uint32_t)(e % N);
-    const uint32_t c = perm_fwd(k, keys.k[g]);
-    tab[e] = c;
-    inv[(uint64_t)g * N + c] = k;
+    tab[e] = perm_fwd(k, keys.k[g]);
+    inv[e] = perm_inv(k, keys.k[g]);      // (walking the network backwards costs less than the scattered store inv[g N + c] = k did: 7.5 -> 4.9 us at cfg2)
 }
 
 // Records of K consecutive generations in one launch, one thread per (generation, position in shuffle order):
@@ -1409,10 +1408,17 @@ struct PlanParams {
     uint64_t seed, t0;
     uint32_t n_gens, N, np, snooker;     // np pairs (<= 5); snooker: also the three snooker partners (DE-MC, pools of >= 3)
 };
-__global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan, const uint32_t* sidx) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)P.n_gens * P.N) return;
-    const uint32_t g = (uint32_t)(e / P.N), pos = (uint32_t)(e % P.N);
+constexpr int PLAN_THREADS = 256;
+__global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan, const uint32_t* sidx) {
+    // records by position leave through LDS: a thread's 64-byte record as four 16-byte pieces 64 bytes apart makes every store instruction of a
+    // wavefront touch 64 lines; transposed, it writes 1 KB in a row
+    __shared__ uint4 s_stage[PLAN_THREADS * (PLAN_WORDS / 4)];
+    const uint64_t e = (uint64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
+    const uint64_t total = (uint64_t)P.n_gens * P.N;
+    const bool valid = e < total;
+    if (!valid && sidx) return;
+    const uint64_t ev = valid ? e : total - 1u;
+    const uint32_t g = (uint32_t)(ev / P.N), pos = (uint32_t)(ev % P.N);
     const uint64_t t = P.t0 + g;
     const uint32_t* tg = tab + (uint64_t)g * P.N;
     const uint32_t n_first = (P.N + 1u) / 2u;
@@ -1443,10 +1449,25 @@ __global__ void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* p
         r[9] = tg[pool_off + i2];
     }
     // where the record goes: by position, or (world > 1) to its slot in the owner-sorted order of its generation
-    const uint64_t oe = sidx ? (uint64_t)g * P.N + sidx[e] : e;
-    uint4* out = reinterpret_cast<uint4*>(plan + oe * PLAN_WORDS);
+    if (sidx) {
+        const uint64_t oe = (uint64_t)g * P.N + sidx[e];
+        uint4* out = reinterpret_cast<uint4*>(plan + oe * PLAN_WORDS);
 #pragma unroll
-    for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+        for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+        return;
+    }
+    constexpr int Q = PLAN_WORDS / 4;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) s_stage[threadIdx.x * Q + i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PLAN_THREADS * Q;               // this workgroup's first 16-byte piece
+    uint4* out = reinterpret_cast<uint4*>(plan) + base;
+    const uint64_t pieces = total * Q;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const uint32_t j = (uint32_t)i * PLAN_THREADS + threadIdx.x;
+        if (base + j < pieces) out[j] = s_stage[j];
+    }
 }
 
 // Owner-sorted order of the update records (world > 1): block (group, generation) walks the group's positions in order and gives
