@@ -701,7 +701,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     HIPCKD(hipSetDevice(cfg->device));
     HIPCKD(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     // Where the per-generation tables are built.  Default: on the update stream itself, ONE WINDOW AHEAD (on entering window W
-    // the build of W + 1 is enqueued in front of W's first update kernel): 23 us per 64 generations at cfg2, and no bpm_step
+    // the build of W + 1 is enqueued in front of W's first update kernel): 16 us per 64 generations at cfg2, and no bpm_step
     // call ever starts with a table build.  BPM_TAB_AUX=1 builds on a second stream beside the update kernels instead --
     // measured SLOWER on MI355X: 13.7 vs 12.3 us per generation at cfg2 (~90 us per window: the cross-queue dependencies and
     // the concurrent build cost the latency-bound update kernels far more than the 23 us they hide;
