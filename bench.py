@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one generation = every chain updated once (two half-generation kernel launches,
-plus, for N > 1, the RCCL all-gather of the state after each).  N = 1: DREAM, 100-D
+plus, for N > 1, the exchange of the accepted updates after each).  N = 1: DREAM, 100-D
 equicorrelated Gaussian, n_chains = 8192, del_pairs = 3 (BASELINE configs[1]).  N > 1: weak
 scaling, 8192 chains per GPU sharded by contiguous global-id blocks (configs[3] at N = 8), one
-process per GPU launched by torch.distributed.run.
+process per GPU.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts
+its N rank processes ITSELF, as children (never an exec; the parent makes no GPU call), relays
+rank 0's JSON line and returns non-zero when a rank fails; under torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks.
 
 Timed region = steady state after burn-in (CR adaptation finished), history append included,
 inputs resident in HBM; bracketed by barrier + synchronize on both sides, max over ranks.
@@ -16,11 +19,15 @@ generations of the same workload on a scratch sampler that keeps no history: a f
 timed region of 20 generations is 0.25 ms long (tools/window_anatomy.py, profiles/r02_window_anatomy.txt).
 The posterior gate reported with the number is evaluated over at least POSTERIOR_MIN_GENS post-burn-in generations
 (the timed ones plus an untimed extension when --steps is short).
+At N = 1 the line also carries `configs`: the other BASELINE configurations that fit one GPU (cfg3, cfg5's per-GPU
+share, cfg5 whole, cfg2 / cfg5 burn-in), each a few hundred generations timed OUTSIDE the headline's region.
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,42 +49,170 @@ HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARC
 POSTERIOR_MIN_GENS = 1200                                      # post-burn-in generations the moment gate is evaluated over
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU oracle timed on this host on a bounded sample of the same workload (N=8192, d=100, steady
-    state): the plain-C + OpenMP restatement (oracle/csrc/dream_ref.c, checked against the NumPy oracle in
-    tests/test_oracle_c.py) on the box's CPU share, and the NumPy oracle (1 process) for reference."""
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts the rank processes (reference: one MPI rank per chain block in lock-step,
+# bipymc/demc.py:14-32,93-94,116-117 -- `mpirun -n N python script.py`; here `python bench.py --gpus N`)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_gpu_count(timeout=180.0):
+    """hipGetDeviceCount, asked in a CHILD process (bpm_device_count of the product library): the launching parent itself
+    never initialises HIP.  -1 when the probe cannot run (library not built)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from bipymc_amd import _lib\n"
+            "print('BPM_NDEV', _lib.device_count())\n" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except Exception:
+        return -1
+    for line in out.stdout.decode("utf-8", "replace").splitlines():
+        if line.startswith("BPM_NDEV"):
+            return int(line.split()[1])
+    return -1
+
+
+def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys.stdout, err=sys.stderr):
+    """Start n rank processes of this script as children, relay rank 0's last JSON line to `out`, everything else to `err`.
+    Returns the exit code: 0 only when every rank exited 0 and rank 0 printed its line.  Fewer visible GPUs than ranks is an
+    error before anything starts (RCCL refuses two ranks on one device; no silent oversubscription).  When one rank fails
+    the others are given grace_s seconds, then ended (their exact PIDs) -- a rank that died inside a collective would leave
+    its peers waiting for ever.  worker_cmd / n_visible: test hooks (tests/test_bench_launcher.py)."""
+    if n_visible is None:
+        n_visible = visible_gpu_count()
+    if n_visible < n:
+        err.write("bench.py: --gpus %d but %s GPU(s) visible to this process: one process per GPU, no oversubscription "
+                  "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the set)\n"
+                  % (n, "no" if n_visible <= 0 else str(n_visible)))
+        return 2
+    cmd = list(worker_cmd) if worker_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BPM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and the IPC-mapped exchange buffers need here
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else err, stderr=err))
+    line = None
+    first_fail_t = None
+    rc = 0
+    # rank 0's stdout is read in a thread so that a full pipe never blocks it
+    import threading
+    got = []
+
+    def reader():
+        for raw in procs[0].stdout:
+            got.append(raw.decode("utf-8", "replace"))
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0:
+                err.write("bench.py: rank %d exited with code %d\n" % (r, c))
+                rc = rc or (c if 0 < c < 256 else 1)
+                if first_fail_t is None:
+                    first_fail_t = time.time()
+        if live and first_fail_t is not None and time.time() - first_fail_t > grace_s:
+            for r in sorted(live):
+                err.write("bench.py: ending rank %d (pid %d): another rank failed\n" % (r, procs[r].pid))
+                procs[r].kill()
+            for r in sorted(live):
+                procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    th.join(timeout=5.0)
+    for text in got:
+        s = text.strip()
+        if s.startswith("{") and s.endswith("}"):
+            line = s
+        elif s:
+            err.write(text if text.endswith("\n") else text + "\n")
+    if rc == 0 and line is None:
+        err.write("bench.py: rank 0 exited without printing its JSON line\n")
+        rc = 1
+    if rc == 0:
+        out.write(line + "\n")
+        out.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_budget=16.0):
+    """The CPU oracle timed on this host on a bounded sample of the same workload (N=8192, d=100, steady state): the
+    plain-C + OpenMP restatement (oracle/csrc/dream_ref.c, checked against the NumPy oracle in tests/test_oracle_c.py) on
+    1 core, on a one-GPU box's CPU share (<= 16 cores: `value`) and on all cores this process may use, and the NumPy
+    oracle (1 process).  BASELINE.md section 5."""
     from oracle import dream_ref_c as CR
     from oracle import sampler_ref as R
     params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(DIM) + 1.0))
     rs = np.random.RandomState(0)
     X = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, 1))
                                          + np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, DIM)))
-    threads = max(1, min(16, os.cpu_count() or 1, CR.max_threads()))      # a one-GPU box's CPU share is 16 cores
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    cores_all = max(1, min(usable, CR.max_threads()))
+    threads = max(1, min(16, cores_all))                                  # a one-GPU box's CPU share is 16 cores
+    legs = [("c1", 1), ("cN", threads)]
+    if cores_all != threads:
+        legs.append(("call", cores_all))
     out = {}
-    for label, nt in (("c1", 1), ("cN", threads)):
+    per_leg = seconds_budget / (len(legs) + 1)
+    for label, nt in legs:
         Xc = X.copy()
         ll = R.ll_gauss_equicorr(Xc, params)
         CR.dream_run(Xc, ll, params, 42, 0, 0, 2, del_pairs=DEL_PAIRS, n_threads=nt)     # warm-up
         gens, el, t0 = 0, 0.0, time.perf_counter()
-        while el < seconds_budget / 3 and gens < 2000:
-            CR.dream_run(Xc, ll, params, 42, 2 + gens, 2 + gens, 10, del_pairs=DEL_PAIRS, n_threads=nt)
-            gens += 10
+        step = 2 if nt == 1 else 10
+        while el < per_leg and gens < 4000:
+            CR.dream_run(Xc, ll, params, 42, 2 + gens, 2 + gens, step, del_pairs=DEL_PAIRS, n_threads=nt)
+            gens += step
             el = time.perf_counter() - t0
         out[label] = (CHAINS_PER_GPU * gens / el, gens, el)
+    if "call" not in out:
+        out["call"] = out["cN"]
     ora = R.OracleSampler(R.ALGO_DREAM, CHAINS_PER_GPU, DIM, R.TARGET_GAUSS_EQUICORR, params, 42,
                           del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN)
     ora.set_state(X)
     ora.run(1)
     gens, el, t0 = 0, 0.0, time.perf_counter()
-    while el < seconds_budget / 3 and gens < 200:
+    while el < per_leg and gens < 200:
         ora.run(1)
         gens += 1
         el = time.perf_counter() - t0
     return dict(value=out["cN"][0], unit="chain-updates/s", cores=threads, kind="port",
-                sample="%d generations of DREAM d=100 n_chains=8192 in %.1f s with oracle/csrc/dream_ref.c on %d OpenMP threads "
-                       "(1 thread: %.3g chain-updates/s; NumPy oracle, 1 process: %.3g chain-updates/s over %d generations); "
-                       "host has %d cores" % (out["cN"][1], out["cN"][2], threads, out["c1"][0],
-                                              CHAINS_PER_GPU * gens / el, gens, os.cpu_count() or 0))
+                value_1core=out["c1"][0], value_allcores=out["call"][0], cores_all=cores_all,
+                value_numpy_1proc=CHAINS_PER_GPU * gens / el,
+                cpu_model=_cpu_model(), cpu_count_host=os.cpu_count() or 0,
+                sample="DREAM d=100 n_chains=8192 steady state with oracle/csrc/dream_ref.c (C + OpenMP over the chains of a "
+                       "half generation): %d generations in %.1f s on %d threads (value), %d in %.1f s on 1 thread, %d in %.1f s "
+                       "on %d threads (all cores this process may use); NumPy oracle %d generations in %.1f s"
+                       % (out["cN"][1], out["cN"][2], threads, out["c1"][1], out["c1"][2], out["call"][1], out["call"][2],
+                          cores_all, gens, el))
 
 
 def measured_copy_bandwidth(torch, dev):
@@ -98,7 +233,69 @@ def measured_copy_bandwidth(torch, dev):
     return 2.0 * n * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------------------
+# The other BASELINE configurations that fit one GPU, under the same clock.  bytes = SURVEY 8(d).
+# ---------------------------------------------------------------------------------------------------------------------
+def other_configs(device, budget_s=6.0):
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    np.random.seed(20261004)
+    gauss, banana, mix8 = d100_gauss.Gauss_100D(rho=0.5, dim=DIM), banana_rv.Banana_2D(), mixture_nd.BimodeGauss_ND(8)
+    # (name, algo, target, N, generations, bytes per update, kernel, engine kwargs)
+    specs = [
+        ("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", L.ALGO_DEMC, banana, 65536, 400, 97.6,
+         "phase_fused_kernel<0,3,1,2,1,2> (one lane per chain)", dict(p_snooker=0.1)),
+        ("cfg5 one GPU's share: DREAM mixture d=8 N=32768 steady", L.ALGO_DREAM, mix8, 32768, 400, 592.0,
+         "phase_fused_kernel<1,2,4,2,3,2> (4 lanes per chain)", dict(burnin_gen=0)),
+        ("cfg5 whole on one GPU: DREAM mixture d=8 N=262144 steady", L.ALGO_DREAM, mix8, 262144, 200, 592.0,
+         "phase_fused_kernel<1,2,4,2,3,2> (4 lanes per chain)", dict(burnin_gen=0)),
+        ("cfg2 burn-in: DREAM gauss d=100 N=8192, CR adaptation on", L.ALGO_DREAM, gauss, 8192, 300, 10416.0,
+         "phase_fused_kernel<1,1,64,2,3,3> + cr_partial_kernel + cr_final_kernel", dict(burnin_gen=10 ** 6, n_cr_gen=5)),
+        ("cfg5 burn-in: DREAM mixture d=8 N=262144, CR adaptation + outlier check every 50", L.ALGO_DREAM, mix8, 262144, 100,
+         848.0, "phase_fused_kernel<1,2,4,2,3,4> + cr_partial_kernel (ticket) + outlier kernels",
+         dict(burnin_gen=10 ** 6, n_cr_gen=5, outlier_every=50)),
+    ]
+    out = []
+    t_begin = time.perf_counter()
+    for name, algo, tgt, N, gens, bpu, kernel, kw in specs:
+        if time.perf_counter() - t_begin > budget_s:
+            out.append(dict(config=name, skipped="time budget of the extra configurations used up"))
+            continue
+        tid, tp, d = tgt._bpm_target_spec()
+        x0 = tgt.rvs(N)
+        if isinstance(x0, tuple):
+            x0 = np.stack(x0, axis=1)
+        e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=42, device=device, **kw)
+        try:
+            e.set_state(x0)
+            e.reserve_history(gens + 48)
+            e.begin_run()
+            e.step(30)
+            e.synchronize()
+            t0 = time.perf_counter()
+            ev_ms, ev_n = e.step_timed(gens)
+            el = time.perf_counter() - t0
+            st = e.stats()
+            ls = e.launch_stats()
+        finally:
+            e.close()
+        value = N * gens / el
+        gen_us_dev = (ev_ms * 1e3 / ev_n * 2.0) if ev_n > 0 else None     # two update launches per generation; with CR adaptation
+        ach = N * bpu / ((gen_us_dev or el / gens * 1e6) * 1e-6) / 1e9      # the reduction dispatches sit inside the period
+        out.append(dict(config=name, value=value, unit="chain-updates/s", n_chains=N, dim=d, steps=gens,
+                        ms_per_step=el / gens * 1e3, start="exact draws of the target",
+                        acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
+                        packet_fence=ls["fence"],
+                        roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                      traffic=None, kernel=kernel, bytes_per_unit=bpu, units_per_launch=N / 2.0,
+                                      avg_launch_us=(ev_ms * 1e3 / ev_n) if ev_n > 0 else None, launches_timed=ev_n,
+                                      note="achieved = n_chains x bytes_per_unit / device-timed generation period (two update "
+                                           "launches back to back, reduction dispatches of burn-in included)")))
+    return out
+
+
+def main(argv=None):
     global CHAINS_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,20 +303,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--preheat", type=float, default=0.5, help="seconds of untimed steady-state generations before burn-in (0: none)")
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU, help="experiments only; the default is the BASELINE workload")
-    args = ap.parse_args()
+    ap.add_argument("--exchange", default=None, help="N > 1: push (default) | replay | rows | dense")
+    args = ap.parse_args(argv)
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the parent of the N ranks.  Nothing of torch.cuda / HIP has been touched.
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
-                         % (args.gpus, args.gpus))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d in the environment\n" % (args.gpus, world))
+        return 2
 
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
     ndev = torch.cuda.device_count()
-    if ndev > 0 and local_rank >= ndev:   # launcher exposed one device per process
+    if ndev <= 0:
+        sys.stderr.write("bench.py: no GPU visible (this benchmark has no CPU path)\n")
+        return 2
+    if world > 1 and local_rank >= ndev and ndev > 1:
+        sys.stderr.write("bench.py: local rank %d but only %d visible GPU(s): one process per GPU\n" % (local_rank, ndev))
+        return 2
+    if local_rank >= ndev:            # launcher exposed one device per process
         local_rank = 0
     dist = None
     # BPM_FORCE_DIST=1 takes the multi-process path with a single rank (process group + one-rank RCCL
@@ -127,6 +338,7 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("BPM_FORCE_DIST"))
     if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -146,9 +358,11 @@ def main():
     eng = HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42,
                     device=local_rank, rank=rank, world_size=world, nccl_uid=uid,
                     del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
+    if use_dist and args.exchange:
+        eng.set_exchange(mode=args.exchange)
     # Synthetic start: exact draws of the target (x_i = sigma_i (sqrt(rho) g + sqrt(1-rho) e_i)), so the
     # timed region is the stationary regime and the moment gate below tests invariance.  (From the
-    # reference's default start -- theta_0 + 1e-3 jitter -- or an independent over-dispersed one the
+    # reference's default start -- theta_0 = 0 + 1e-3 jitter, SURVEY 8(d) -- or an independent over-dispersed one the
     # population needs ~1000 generations to find the correlated scale: tools/convergence_check.py.)
     rs = np.random.RandomState(1234)
     X0 = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((n_chains, 1))
@@ -191,11 +405,9 @@ def main():
     if args.warmup > 0:
         eng.step_timed(1)          # (reads the events too: every host-side path of the timed call has run once)
     fence()
-    # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two HIP events
-    # bound to the first and the last update-kernel dispatch of the same K generations on the sampler's own stream
-    # (bpm_step_timed: end of launch K/2 -> end of launch 2K, back-to-back launch periods of the last three quarters of the timed
-    # region -- binding an event to a dispatch costs the host 10-30 us, which would stall the GPU at the head of the region; it
-    # returns with the sampler's stream drained).
+    # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two time stamps
+    # bound to the first and the last update-kernel dispatch of the same K generations (bpm_step_timed; it returns with the
+    # sampler's queue / stream drained).
     t0 = time.perf_counter()
     eng.step_timed(args.steps, read=False)
     torch.cuda.synchronize()
@@ -209,13 +421,13 @@ def main():
         el = float(t.item())
     value = n_chains * args.steps / el
 
-    # ---- dominant kernel (phase_fused_kernel): 2 launches per generation, back to back on one stream; at
+    # ---- dominant kernel (phase_fused_kernel): 2 launches per generation, back to back on one queue; at
     # N = 1 nothing else runs in the region, so event time / launches is its average launch duration
     # (inter-launch gaps included; rocprofv3 --kernel-trace gives the gap-free figure, profiles/).
     n_launch = ev_launches
     k_avg_ms = ev_ms / max(n_launch, 1)
     units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
-    achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9
+    achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
     pair_ms, pair_n = eng.step_profiled(32)                       # cross-check: an event pair around every launch
     fence()
     traffic = None
@@ -257,27 +469,40 @@ def main():
     import hashlib
     state_sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]   # (A/B of launch paths: same bits)
     lstat = eng.launch_stats()
+    xstat = eng.exchange_stats() if use_dist else None
+    # N > 1: what every rank saw -- its update / exchange kernel periods and the size of the world its exchange runs in
+    per_rank = None
+    if dist is not None:
+        mine = dict(rank=rank, device=local_rank, avg_launch_us=k_avg_ms * 1e3, launches_timed=int(n_launch),
+                    exchange=xstat, update_dispatches=dict(direct_aql_queue=lstat["direct"], hip_stream=lstat["stream"]),
+                    final_state_sha256_16=state_sha)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    eng.close()
     if rank == 0:
         copy_gbs = measured_copy_bandwidth(torch, local_rank)
         out = {
             "metric": "chain-updates/sec", "value": value, "unit": "chain-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            # the same K generations by the HIP event pair on the sampler's stream (no host launch / wake-up latency)
-            "value_event_timed": n_chains / (2.0 * k_avg_ms * 1e-3),
+            # the same K generations by the time stamps of the first / last update dispatch (no host launch / wake-up latency)
+            "value_event_timed": (n_chains / (2.0 * k_avg_ms * 1e-3)) if k_avg_ms > 0 else None,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "DREAM, 100-D equicorrelated Gaussian (tests/test_100dgauss.py target), "
-                                   "n_chains=%d (%d per GPU), del_pairs=3, n_cr=3, steady state after %d burn-in "
-                                   "generations, history appended every generation; GPU pre-heated for %.2f s (%d untimed "
-                                   "steady-state generations on a scratch sampler) before burn-in"
+                                   "n_chains=%d (%d per GPU), del_pairs=3, n_cr=3; start = EXACT DRAWS OF THE TARGET (not the "
+                                   "reference's theta_0=0 + 1e-3 jitter: from there the population needs ~1000 generations to reach "
+                                   "the stationary scale), steady state after %d burn-in generations with CR adaptation, history "
+                                   "appended every generation; GPU pre-heated for %.2f s (%d untimed steady-state generations on a "
+                                   "scratch sampler) before burn-in"
                                    % (n_chains, CHAINS_PER_GPU, BURNIN_GEN, preheat["seconds"], preheat["generations"]),
-                       "n_chains": n_chains, "dim": DIM, "parallelism": "chains sharded x%d" % world,
+                       "start": "exact draws of the target", "n_chains": n_chains, "dim": DIM,
+                       "parallelism": "chains sharded x%d" % world,
                        "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s,
-                       "exchange": eng.exchange_stats() if use_dist else None,
+                       "exchange": xstat,
                        # how the update kernels were dispatched: packets written by the library into its own AQL queue
-                       # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (burn-in, multi-GPU, BPM_DIRECT_QUEUE=0)
+                       # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (BPM_DIRECT_QUEUE=0)
                        "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"],
-                                             "state_in_hw_coherent_memory": lstat["coherent_state"], "packet_fence": lstat["fence"]},
+                                             "packet_fence": lstat["fence"]},
                        "final_state_sha256_16": state_sha},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -288,13 +513,20 @@ def main():
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs},
             "posterior": extra,
         }
+        if per_rank is not None:
+            out["ranks"] = per_rank
+            out["config"]["replicas_identical"] = len(set(p["final_state_sha256_16"] for p in per_rank)) == 1
+        if world == 1 and not use_dist and not args.no_other_configs and CHAINS_PER_GPU == 8192:
+            out["configs"] = other_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

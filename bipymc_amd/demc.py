@@ -44,6 +44,11 @@ def _default_engine_factory(**kw):
     return HipEngine(**kw)
 
 
+# The engine behind the sampler classes.  Not a constructor argument: the product has one engine (the HIP library);
+# the CPU tests replace this module attribute with the oracle engine (tests/_oracle_engine.py) to exercise the host logic.
+_engine_factory = _default_engine_factory
+
+
 class DeMcMpi(object):
     """!
     @brief DE-MC population sampler, one process per MI355X.
@@ -79,12 +84,14 @@ class DeMcMpi(object):
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 62)) if self.comm.rank == 0 else None
         self.seed = int(self.comm.bcast(seed, root=0))
-        self._target_id, self._target_params = _target.resolve(ln_like_fn, self._ln_kwargs, self.dim)
+        # which ln_like_fn runs on the device: the shipped targets, the reference's own target objects (recognised and
+        # verified, utils/_target.py), else the host callback of samplers.py:36-43
+        self._target_id, self._target_params, self.target_rule = _target.resolve_info(ln_like_fn, self._ln_kwargs, self.dim)
         if kwargs.get("force_host_callback", False):
-            self._target_id, self._target_params = L.TARGET_HOST_CALLBACK, None
-        factory = kwargs.get("engine_factory", _default_engine_factory)
+            self._target_id, self._target_params, self.target_rule = L.TARGET_HOST_CALLBACK, None, "host-callback"
+        factory = _engine_factory
         uid = None
-        if self.comm.size > 1 and kwargs.get("engine_needs_uid", True):
+        if self.comm.size > 1:
             if self.comm.rank == 0:
                 from .engine import HipEngine
                 uid = HipEngine.unique_id() if factory is _default_engine_factory else b"\0" * L.UID_BYTES
@@ -111,7 +118,10 @@ class DeMcMpi(object):
     def _default_device(self):
         """One process per GPU: the node-local rank as the launcher exports it (torchrun: LOCAL_RANK; Open MPI, MVAPICH,
         Slurm), else rank modulo the number of visible devices.  A launcher that already narrowed the visible devices to
-        one per process (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) gets device 0."""
+        one per process (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) gets device 0.  EVERY rank enters the one collective
+        of this function, whatever it found locally, and all ranks raise together afterwards: a mis-launch is an error
+        message on every rank, not a hang of the well-configured ones in an allgather (the reference's ranks share the
+        host's cores and pick nothing, demc.py:15)."""
         import os
         if self.comm.size == 1:
             return 0
@@ -123,15 +133,26 @@ class DeMcMpi(object):
         ndev = _visible_device_count()
         if local is None:
             local = self.comm.rank % max(ndev, 1)
+        error = None
         if ndev <= 1:          # one device exposed per process (or none at all: bpm_create will say so)
-            return 0
-        if local >= ndev:
-            raise RuntimeError("local rank %d but only %d visible GPU(s): launch one process per GPU" % (local, ndev))
-        # two ranks of one node on the same device would deadlock in ncclCommInitRank: say so instead
-        taken = self.comm.allgather((_hostname(), local))
-        if taken.count((_hostname(), local)) > 1:
-            raise RuntimeError("several ranks of host %s resolved to GPU %d; set LOCAL_RANK (or pass device=)" % (_hostname(), local))
-        return local
+            device = 0
+        elif local >= ndev:
+            device = -1
+            error = "rank %d: local rank %d but only %d visible GPU(s): launch one process per GPU" % (self.comm.rank, local, ndev)
+        else:
+            device = local
+        host = _hostname()
+        seen = self.comm.allgather((host, device, ndev, error))
+        errors = [e[3] for e in seen if e[3]]
+        # two ranks of one node on the same device of a multi-device view would deadlock in ncclCommInitRank: say so instead
+        multi = [(e[0], e[1]) for e in seen if e[2] > 1 and e[1] >= 0]
+        dup = sorted(set(k for k in multi if multi.count(k) > 1))
+        if dup:
+            errors.append("several ranks resolved to the same GPU: %s; set LOCAL_RANK (or pass device=)"
+                          % ", ".join("host %s GPU %d" % k for k in dup))
+        if errors:
+            raise RuntimeError("; ".join(errors))
+        return device
 
     # ---- samplers.py:36-47 -----------------------------------------------
     def _freeze_ln_like_fn(self, **kwargs):

@@ -45,8 +45,8 @@ class DeMc(object):
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 62))
         tid, tparams = _target.resolve(self.log_like_fn, self._ln_kwargs, dim)
-        from .engine import HipEngine
-        factory = self._kw.get("engine_factory", lambda **kw: HipEngine(**kw))
+        from . import demc as _demc
+        factory = _demc._engine_factory                                  # (the HIP engine; CPU tests patch the module attribute)
         if self._engine is not None:
             self._engine.close()
         eng = factory(algo=L.ALGO_DEMC_SYNC, n_chains=self.n_chains, dim=dim, target_id=tid, target_params=tparams,

@@ -1,12 +1,25 @@
-"""Device-target protocol: a target object whose bound `ln_like` method is handed to
-DeMcMpi/DreamMpi is recognised through `__self__._bpm_target_spec()` and evaluated
-on the GPU; any other callable takes the host-callback path (samplers.py:36-43)."""
+"""Device-target protocol and registry.
+
+A callable handed to DeMcMpi/DreamMpi as `ln_like_fn` is evaluated ON THE GPU when it is
+  (1) the bound `ln_like` of an object that publishes `_bpm_target_spec()` (the targets shipped in
+      bipymc_amd.utils), or
+  (2) the bound `ln_like` of one of the REFERENCE's own target objects -- `bipymc.utils.d100_gauss.Gauss_100D`
+      (utils/d100_gauss.py:10-35), `dblgauss_rv.BimodeGauss_2D` (utils/dblgauss_rv.py:10-32), `banana_rv.Banana_2D`
+      (utils/banana_rv.py:10-40) -- recognised by class name and the attributes their constructors set.  A user script
+      that keeps `from bipymc.utils import d100_gauss` and only switches the sampler import is the drop-in case; without
+      this it would silently take the host-callback path (samplers.py:36-43), ~10^4 x slower.  The device parameter block is
+      rebuilt from the object's attributes and then VERIFIED: the callable itself is evaluated at a handful of points near
+      the target's mass and compared with the closed form the device evaluates; any mismatch (a subclass that overrides
+      ln_like, edited attributes, a look-alike with other semantics) falls back to the host callback.
+Any other callable takes the host-callback path.  `resolve_info()` says which rule applied."""
 import math
 
 import numpy as np
 
 LN_2PI = math.log(2.0 * math.pi)
 TARGET_HOST_CALLBACK, TARGET_GAUSS_EQUICORR, TARGET_MIXTURE_PAIRS, TARGET_BANANA_2D = 0, 1, 2, 3
+VERIFY_RTOL = 1e-9          # closed form vs the object's own ln_like (scipy pdf -> log: ~1e-13 relative near the mode)
+VERIFY_ATOL = 1e-9
 
 
 def pair_block(mu, sg, rho):
@@ -20,13 +33,127 @@ def log_binormal(u, v, rho, h, ln_norm):
     return ln_norm - 0.5 * (u * u - 2.0 * rho * u * v + v * v) * h
 
 
-def resolve(ln_like_fn, ln_kwargs, dim):
-    """-> (target_id, params or None).  Device target only for a bound method of an object that
-    publishes a spec of matching dimension and when no extra kwargs are frozen in."""
+# ---- look-alikes of the reference's target classes ---------------------------------------------------------------
+def _cov2(cov):
+    """(sigma_x, sigma_y, rho) of a 2 x 2 covariance matrix, or None"""
+    c = np.asarray(cov, dtype=np.float64)
+    if c.shape != (2, 2) or not np.all(np.isfinite(c)) or c[0, 0] <= 0 or c[1, 1] <= 0 or abs(c[0, 1] - c[1, 0]) > 1e-14 * abs(c[0, 0]):
+        return None
+    sx, sy = math.sqrt(c[0, 0]), math.sqrt(c[1, 1])
+    rho = c[0, 1] / (sx * sy)
+    return (sx, sy, rho) if abs(rho) < 1.0 else None
+
+
+def _like_gauss(o, dim):
+    """utils/d100_gauss.py:14-27: mu (zeros), var (std devs), cov (dense, equicorrelated), dim, rho"""
+    from .d100_gauss import equicorr_block, equicorr_ln_like
+    cov = np.asarray(getattr(o, "cov"), dtype=np.float64)
+    d = int(getattr(o, "dim"))
+    mu = np.asarray(getattr(o, "mu"), dtype=np.float64)
+    if d != dim or d < 2 or cov.shape != (d, d) or mu.shape != (d,) or np.any(mu != 0.0):
+        return None
+    sg = np.sqrt(np.diag(cov))
+    if not np.all(sg > 0):
+        return None
+    rho = float(cov[0, 1] / (sg[0] * sg[1]))
+    if not (-1.0 / (d - 1) < rho < 1.0):
+        return None
+    want = rho * np.outer(sg, sg)
+    want[np.diag_indices(d)] = sg ** 2
+    if not np.allclose(cov, want, rtol=1e-12, atol=0.0):
+        return None                                             # not equicorrelated: no O(d) closed form
+    blk = equicorr_block(rho, sg)
+    rs = np.random.RandomState(12345)
+    pts = [np.zeros(d), 0.5 * sg, -0.25 * sg * (1 + np.arange(d) % 2)] + [sg * 0.7 * rs.standard_normal(d) for _ in range(3)]
+    return TARGET_GAUSS_EQUICORR, blk, pts, lambda y: equicorr_ln_like(blk, y)
+
+
+def _like_mixture(o, dim):
+    """utils/dblgauss_rv.py:11-25: mu_g1, mu_g2, cov_g1, cov_g2, w_g1, w_g2 (normalised)"""
+    if dim != 2:
+        return None
+    m1 = np.asarray(getattr(o, "mu_g1"), dtype=np.float64).reshape(-1)
+    m2 = np.asarray(getattr(o, "mu_g2"), dtype=np.float64).reshape(-1)
+    c1, c2 = _cov2(getattr(o, "cov_g1")), _cov2(getattr(o, "cov_g2"))
+    w1, w2 = float(getattr(o, "w_g1")), float(getattr(o, "w_g2"))
+    if m1.size != 2 or m2.size != 2 or c1 is None or c2 is None or not (w1 > 0 and w2 > 0) or abs(w1 + w2 - 1.0) > 1e-12:
+        return None
+    blk = np.array([math.log(w1), math.log(w2)] + pair_block(m1, c1[:2], c1[2]) + pair_block(m2, c2[:2], c2[2]), dtype=np.float64)
+
+    def closed(y):
+        y = np.asarray(y, dtype=np.float64)
+        comp = []
+        for c in range(2):
+            mx, my, isx, isy, rho, h, ln_norm = blk[2 + 7 * c: 9 + 7 * c]
+            comp.append(blk[c] + log_binormal((y[0] - mx) * isx, (y[1] - my) * isy, rho, h, ln_norm))
+        m = max(comp)
+        return m + math.log(math.exp(comp[0] - m) + math.exp(comp[1] - m))
+    s1, s2 = np.array(c1[:2]), np.array(c2[:2])
+    pts = [m1, m2, m1 + 0.5 * s1, m2 - 0.7 * s2, 0.5 * (m1 + m2) * np.array([1.0, 0.9]), m1 + np.array([1.5, -1.0]) * s1,
+           m2 + np.array([-2.0, 0.5]) * s2]
+    return TARGET_MIXTURE_PAIRS, blk, pts, closed
+
+
+def _like_banana(o, dim):
+    """utils/banana_rv.py:11-24: mu1, mu2, sigma1, sigma2, rho, a, b"""
+    if dim != 2:
+        return None
+    mu1, mu2, s1, s2 = float(o.mu1), float(o.mu2), float(o.sigma1), float(o.sigma2)
+    rho, a, b = float(o.rho), float(o.a), float(o.b)
+    if not (s1 > 0 and s2 > 0 and abs(rho) < 1 and a != 0):
+        return None
+    blk = np.array(pair_block((mu1, mu2), (s1, s2), rho) + [a, b], dtype=np.float64)
+
+    def closed(y):
+        x1 = y[0] / a
+        x2 = (y[1] - b * (x1 * x1 + a * a)) * a
+        return log_binormal((x1 - mu1) / s1, (x2 - mu2) / s2, rho, blk[5], blk[6])
+    pts = []
+    for x1, x2 in ((mu1, mu2), (mu1 + s1, mu2 + 0.8 * s2), (mu1 - 1.5 * s1, mu2 - s2), (mu1 + 0.3 * s1, mu2 - 1.2 * s2), (mu1 - 0.4 * s1, mu2 + 2 * s2)):
+        pts.append(np.array([a * x1, x2 / a + b * (x1 * x1 + a * a)]))       # banana_rv.py:42-45 transform
+    return TARGET_BANANA_2D, blk, pts, closed
+
+
+_LOOKALIKES = {"Gauss_100D": _like_gauss, "BimodeGauss_2D": _like_mixture, "Banana_2D": _like_banana}
+
+
+def _resolve_lookalike(ln_like_fn, owner, dim):
+    build = _LOOKALIKES.get(type(owner).__name__)
+    if build is None:
+        return None
+    try:
+        got = build(owner, dim)
+        if got is None:
+            return None
+        tid, blk, pts, closed = got
+        for y in pts:
+            ref = float(np.asarray(ln_like_fn(np.array(y, dtype=np.float64))).reshape(-1)[0])
+            mine = float(closed(np.asarray(y, dtype=np.float64)))
+            if not (np.isfinite(ref) and abs(ref - mine) <= VERIFY_ATOL + VERIFY_RTOL * abs(mine)):
+                return None
+        return tid, np.ascontiguousarray(blk, dtype=np.float64)
+    except Exception:
+        return None                                             # anything unexpected: the host callback is always right
+
+
+def resolve_info(ln_like_fn, ln_kwargs, dim):
+    """-> (target_id, params or None, rule) with rule in {"spec", "reference-lookalike", "host-callback"}."""
     owner = getattr(ln_like_fn, "__self__", None)
-    spec = getattr(owner, "_bpm_target_spec", None)
-    if spec is not None and not ln_kwargs and getattr(ln_like_fn, "__name__", "") == "ln_like":
-        tid, params, tdim = spec()
-        if tdim == dim:
-            return tid, np.ascontiguousarray(params, dtype=np.float64)
-    return TARGET_HOST_CALLBACK, None
+    if owner is not None and not ln_kwargs and getattr(ln_like_fn, "__name__", "") == "ln_like":
+        spec = getattr(owner, "_bpm_target_spec", None)
+        if spec is not None:
+            tid, params, tdim = spec()
+            if tdim == dim:
+                return tid, np.ascontiguousarray(params, dtype=np.float64), "spec"
+        else:
+            got = _resolve_lookalike(ln_like_fn, owner, dim)
+            if got is not None:
+                return got[0], got[1], "reference-lookalike"
+    return TARGET_HOST_CALLBACK, None, "host-callback"
+
+
+def resolve(ln_like_fn, ln_kwargs, dim):
+    """-> (target_id, params or None).  Device target only for a bound `ln_like` of a recognised target object of matching
+    dimension and when no extra kwargs are frozen in."""
+    tid, params, _ = resolve_info(ln_like_fn, ln_kwargs, dim)
+    return tid, params

@@ -14,6 +14,27 @@ import numpy as np
 from ._target import LN_2PI, TARGET_GAUSS_EQUICORR
 
 
+def equicorr_block(rho, sigma):
+    """Device parameter block [rho, c0, a, b, 1/sigma_0 .. 1/sigma_{d-1}] of a zero-mean Gaussian with
+    cov_ii = sigma_i^2, cov_ij = rho sigma_i sigma_j (BPM_TARGET_GAUSS_EQUICORR, include/bipymc_hip.h)."""
+    sg = np.asarray(sigma, dtype=np.float64)
+    dim = sg.size
+    logdet = 2.0 * np.sum(np.log(sg)) + (dim - 1) * math.log(1.0 - rho) + math.log(1.0 + (dim - 1) * rho)
+    c0 = -0.5 * (dim * LN_2PI + logdet)
+    a = 1.0 / (1.0 - rho)
+    b = rho / ((1.0 + (dim - 1) * rho) * (1.0 - rho))
+    return np.concatenate([[rho, c0, a, b], 1.0 / sg])
+
+
+def equicorr_ln_like(block, y):
+    """the closed form the device evaluates, on the host (rows of y)"""
+    y = np.asarray(y, dtype=np.float64)
+    z = y * block[4:]
+    s1 = np.sum(z, axis=-1)
+    s2 = np.sum(z * z, axis=-1)
+    return block[1] - 0.5 * (block[2] * s2 - block[3] * s1 * s1)
+
+
 class Gauss_100D(object):
     def __init__(self, rho=0.5, dim=100):
         self.mu = np.zeros(dim)
@@ -23,10 +44,8 @@ class Gauss_100D(object):
         sg = self.var
         self.cov = rho * np.outer(sg, sg)
         self.cov[np.diag_indices(dim)] = sg ** 2.0
-        logdet = 2.0 * np.sum(np.log(sg)) + (dim - 1) * math.log(1.0 - rho) + math.log(1.0 + (dim - 1) * rho)
-        self._c0 = -0.5 * (dim * LN_2PI + logdet)
-        self._a = 1.0 / (1.0 - rho)
-        self._b = rho / ((1.0 + (dim - 1) * rho) * (1.0 - rho))
+        blk = equicorr_block(rho, sg)
+        self._c0, self._a, self._b = float(blk[1]), float(blk[2]), float(blk[3])
         self._inv_sigma = 1.0 / sg
 
     def _bpm_target_spec(self):

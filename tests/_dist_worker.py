@@ -16,17 +16,18 @@ def run(rank, world, port, out_dir, case):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         from _oracle_engine import factory
+        import bipymc_amd.demc as _demc
+        _demc._engine_factory = factory            # (this worker process only: the oracle engine stands in for the HIP engine)
         from bipymc_amd.demc import DeMcMpi
         from bipymc_amd.dream import DreamMpi
         from bipymc_amd.utils import banana_rv, d100_gauss
         if case == "dream":
             t = d100_gauss.Gauss_100D(rho=0.5, dim=6)
-            s = DreamMpi(t.ln_like, np.zeros(6), n_chains=12, mpi_comm="torch", n_cr_gen=3, burnin_gen=8,
-                         engine_factory=factory, seed=1234)
+            s = DreamMpi(t.ln_like, np.zeros(6), n_chains=12, mpi_comm="torch", n_cr_gen=3, burnin_gen=8, seed=1234)
             s.run_mcmc(12 * 16)
         else:
             t = banana_rv.Banana_2D()
-            s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm="torch", engine_factory=factory, seed=99, p_snooker=0.2)
+            s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm="torch", seed=99, p_snooker=0.2)
             s.run_mcmc(8 * 21, flip=0.3)
         assert s.comm.size == world and s.comm.rank == rank
         assert list(s.rank_chain_ids) == list(range(rank * s.n_local, (rank + 1) * s.n_local))     # demc.py:39

@@ -1,0 +1,96 @@
+"""bench.py --gpus N without a launcher: the parent starts N rank processes as children, relays rank 0's JSON line and
+fails loudly (CPU; stub workers stand in for the ranks).  The reference's counterpart is `mpirun -n N python script.py`
+(bipymc/demc.py:14-32: every rank enters the same collectives in lock-step, demc.py:93-94,116-117)."""
+import io
+import json
+import os
+import sys
+import time
+
+import bench
+
+STUB = r"""
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+if mode == "ok":
+    if rank == 0:
+        print("some chatter that is not the line")
+        print(json.dumps(dict(metric="chain-updates/sec", n_gpus=world, port=os.environ["MASTER_PORT"], addr=os.environ["MASTER_ADDR"],
+                              local_rank=os.environ["LOCAL_RANK"], ipc=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))))
+    else:
+        print("rank %d says hello" % rank)
+    sys.exit(0)
+if mode == "fail1":
+    if rank == 1:
+        sys.exit(3)
+    time.sleep(600)          # a peer waiting in a collective for ever
+if mode == "silent":
+    sys.exit(0)
+"""
+
+
+def _run(mode, n, **kw):
+    out, err = io.StringIO(), io.StringIO()
+
+    class E(object):            # Popen needs a real file for the children's stderr: send it to ours
+        def fileno(self):
+            return sys.stderr.fileno()
+
+        def write(self, s):
+            err.write(s)
+    rc = bench.launch_ranks(n, [], worker_cmd=[sys.executable, "-c", STUB, mode], out=out, err=E(), **kw)
+    return rc, out.getvalue(), err.getvalue()
+
+
+def test_launcher_relays_rank0_line_and_sets_rendezvous():
+    rc, out, err = _run("ok", 3, n_visible=8)
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE JSON line, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["addr"] == "127.0.0.1" and d["local_rank"] == "0" and int(d["port"]) > 0
+    assert d["ipc"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert "chatter" in err                                  # rank 0's other output goes to stderr
+
+
+def test_launcher_fails_fast_when_fewer_gpus_than_ranks():
+    t0 = time.time()
+    rc, out, err = _run("ok", 2, n_visible=1)
+    assert rc != 0 and out == "" and time.time() - t0 < 10
+    assert "--gpus 2" in err and "1 GPU(s) visible" in err
+    rc, out, err = _run("ok", 2, n_visible=0)
+    assert rc != 0 and "no GPU(s) visible" in err
+
+
+def test_launcher_propagates_a_rank_failure_and_ends_the_peers():
+    t0 = time.time()
+    rc, out, err = _run("fail1", 2, n_visible=2, grace_s=1.0)
+    assert rc == 3 and out == ""
+    assert time.time() - t0 < 30                             # the sleeping peer was ended, not waited for
+    assert "rank 1 exited with code 3" in err and "ending rank 0" in err
+
+
+def test_launcher_needs_the_json_line():
+    rc, out, err = _run("silent", 2, n_visible=2)
+    assert rc != 0 and out == "" and "without printing its JSON line" in err
+
+
+def test_gpus_gt_1_without_world_size_takes_the_launcher(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = {}
+
+    def fake(n, argv, **kw):
+        seen["n"], seen["argv"] = n, list(argv)
+        return 7
+    monkeypatch.setattr(bench, "launch_ranks", fake)
+    assert bench.main(["--gpus", "4", "--steps", "5", "--warmup", "1"]) == 7
+    assert seen == {"n": 4, "argv": ["--gpus", "4", "--steps", "5", "--warmup", "1"]}
+
+
+def test_visible_gpu_count_probe_runs_in_a_child_and_reports_zero_here():
+    # this container has no GPU: hipGetDeviceCount fails -> 0 (and -1 only if the library is not built)
+    n = bench.visible_gpu_count()
+    assert n >= 0, "the probe child could not load bipymc_amd/libbipymc_hip.so"
+    if not os.path.exists("/dev/kfd"):
+        assert n == 0

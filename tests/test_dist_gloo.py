@@ -9,7 +9,8 @@ import socket
 import numpy as np
 import pytest
 
-from _oracle_engine import factory
+
+pytestmark = pytest.mark.usefixtures("oracle_engine")      # the oracle engine behind DeMcMpi / DreamMpi (conftest.py)
 
 
 def _free_port():
@@ -32,7 +33,7 @@ def test_dream_two_ranks_equal_one_rank(tmp_path):
     from bipymc_amd.dream import DreamMpi
     from bipymc_amd.utils import d100_gauss
     t = d100_gauss.Gauss_100D(rho=0.5, dim=6)
-    s = DreamMpi(t.ln_like, np.zeros(6), n_chains=12, n_cr_gen=3, burnin_gen=8, engine_factory=factory, seed=1234)
+    s = DreamMpi(t.ln_like, np.zeros(6), n_chains=12, n_cr_gen=3, burnin_gen=8, seed=1234)
     s.run_mcmc(12 * 16)
     full = s.param_est(0)[2]
     assert r0["full"].shape == full.shape == (12 * 16, 6)
@@ -57,7 +58,7 @@ def test_demc_snooker_two_ranks_equal_one_rank(tmp_path):
     r0, r1 = _spawn("demc", tmp_path)
     from bipymc_amd.demc import DeMcMpi
     from bipymc_amd.utils import banana_rv
-    s = DeMcMpi(banana_rv.Banana_2D().ln_like, np.zeros(2), n_chains=8, engine_factory=factory, seed=99, p_snooker=0.2)
+    s = DeMcMpi(banana_rv.Banana_2D().ln_like, np.zeros(2), n_chains=8, seed=99, p_snooker=0.2)
     s.run_mcmc(8 * 21, flip=0.3)
     assert np.array_equal(r0["full"], s.param_est(0)[2])
     assert int(r0["n_accepted"]) == s.n_accepted
@@ -80,4 +81,4 @@ def test_uneven_split_is_rejected():
             pass
 
     with pytest.raises(ValueError):
-        DeMcMpi(banana_rv.Banana_2D().ln_like, np.zeros(2), n_chains=8, mpi_comm=FakeComm(), engine_factory=factory, seed=1)
+        DeMcMpi(banana_rv.Banana_2D().ln_like, np.zeros(2), n_chains=8, mpi_comm=FakeComm(), seed=1)

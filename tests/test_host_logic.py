@@ -7,17 +7,18 @@ import os
 import numpy as np
 import pytest
 
-from _oracle_engine import factory as oracle_factory
 from bipymc_amd.demc import DeMcMpi
 from bipymc_amd.dream import DreamMpi
 from bipymc_amd.utils import banana_rv, d100_gauss, dblgauss_rv, mixture_nd
 from oracle import sampler_ref as R
 
+pytestmark = pytest.mark.usefixtures("oracle_engine")      # the oracle engine behind DeMcMpi / DreamMpi (conftest.py)
+
 
 def test_generation_count_matches_reference_loop():
     """while j < int((n - n_chains) / size): j += local updates   (demc.py:79,107)"""
     t = dblgauss_rv.BimodeGauss_2D()
-    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, engine_factory=oracle_factory, seed=1)
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, seed=1)
     for n, gens in ((10, 0), (11, 1), (20, 1), (21, 2), (100000, 9999), (5, 0)):
         assert s._n_generations(n) == gens
 
@@ -25,8 +26,7 @@ def test_generation_count_matches_reference_loop():
 def test_dream_public_surface_and_row_order():
     np.random.seed(42)
     t = dblgauss_rv.BimodeGauss_2D()
-    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, mpi_comm=None, n_cr_gen=5, burnin_gen=30,
-                 engine_factory=oracle_factory)
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, mpi_comm=None, n_cr_gen=5, burnin_gen=30)
     assert s.uses_device_target and s.dim == 2 and s.n_chains == 10
     assert s.del_pairs == 3 and s.n_cr == 3 and s.burnin_gen == 30 and s.p_cr_update_gen == 5
     np.testing.assert_array_equal(s.CR, [1 / 3, 2 / 3, 1.0])
@@ -61,12 +61,12 @@ def test_seed_from_numpy_global_state_is_reproducible():
     out = []
     for _ in range(2):
         np.random.seed(7)
-        s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, engine_factory=oracle_factory)
+        s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8)
         s.run_mcmc(8 * 20)
         out.append(s.param_est(0)[2])
     assert np.array_equal(out[0], out[1])
     np.random.seed(8)
-    s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, engine_factory=oracle_factory)
+    s = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8)
     s.run_mcmc(8 * 20)
     assert not np.array_equal(out[0], s.param_est(0)[2])
 
@@ -74,12 +74,12 @@ def test_seed_from_numpy_global_state_is_reproducible():
 def test_constructor_contract():
     t = banana_rv.Banana_2D()
     with pytest.raises(AssertionError):
-        DeMcMpi(t.ln_like, np.zeros(2), n_chains=3, engine_factory=oracle_factory)          # samplers.py:249
-    s = DeMcMpi(t.ln_like, None, n_chains=8, dim=2, engine_factory=oracle_factory, seed=3, inflate=10.0)  # unknown kwargs ignored
+        DeMcMpi(t.ln_like, np.zeros(2), n_chains=3)          # samplers.py:249
+    s = DeMcMpi(t.ln_like, None, n_chains=8, dim=2, seed=3, inflate=10.0)  # unknown kwargs ignored
     assert s.dim == 2 and np.allclose(s._get_local_chain_state(), 0, atol=1e-2)
     assert s.h5_file == "sampler_checkpoint.h5" and s.checkpoint == 0 and s.warm_start is False
     # varepsilon per dimension (examples/ex_exp_fit.py:135-141)
-    s = DeMcMpi(t.ln_like, np.array([1.0, 2.0]), varepsilon=np.array([1e-2, 1e-8]), n_chains=64, engine_factory=oracle_factory, seed=3)
+    s = DeMcMpi(t.ln_like, np.array([1.0, 2.0]), varepsilon=np.array([1e-2, 1e-8]), n_chains=64, seed=3)
     X = s._get_local_chain_state()
     assert 0.05 < X[:, 0].std() < 0.2 and X[:, 1].std() < 1e-3
     assert abs(X[:, 0].mean() - 1.0) < 0.05
@@ -119,11 +119,11 @@ def test_targets_match_oracle_param_blocks_and_values():
 def test_checkpoint_round_trip(tmp_path):
     t = dblgauss_rv.BimodeGauss_2D()
     f = str(tmp_path / "ck.npz")
-    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, seed=5,
                  h5_file=f, checkpoint=4)
     s.run_mcmc(8 * 13)                                  # 12 generations, checkpoints at 4, 8, 12
     full = s.param_est(0)[2]
-    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, seed=5,
                   h5_file=f, warm_start=True)
     assert np.array_equal(s2.param_est(0)[2], full)      # chain histories restored (demc.py:217-233)
     np.testing.assert_allclose(s2.p_cr, s.p_cr)           # and what the reference forgets
@@ -218,12 +218,12 @@ def test_checkpoint_round_trip_hdf5_through_the_sampler(tmp_path):
         pytest.skip("neither h5py nor libhdf5 can be loaded on this machine")
     t = dblgauss_rv.BimodeGauss_2D()
     f = str(tmp_path / "sampler_checkpoint.h5")
-    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, n_cr_gen=3, burnin_gen=10, seed=5,
                  h5_file=f, checkpoint=4)
     s.run_mcmc(8 * 13)
     assert checkpoint._is_hdf5(f) and not os.path.exists(f + ".npz")
     full = s.param_est(0)[2]
-    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, engine_factory=oracle_factory, seed=5,
+    s2 = DreamMpi(t.ln_like, None, n_chains=8, dim=2, n_cr_gen=3, burnin_gen=10, seed=5,
                   h5_file=f, warm_start=True)
     assert np.array_equal(s2.param_est(0)[2], full)
     np.testing.assert_allclose(s2.p_cr, s.p_cr)
@@ -234,7 +234,7 @@ def test_checkpoint_round_trip_hdf5_through_the_sampler(tmp_path):
 def test_statistical_cfg1_shape_on_oracle():
     """BASELINE config 1 plumbing (shortened): DREAM N=10 on the bimodal target through the public API."""
     t = dblgauss_rv.BimodeGauss_2D()
-    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, n_cr_gen=50, burnin_gen=500, engine_factory=oracle_factory, seed=11)
+    s = DreamMpi(t.ln_like, np.zeros(2), n_chains=10, n_cr_gen=50, burnin_gen=500, seed=11)
     s.run_mcmc(30000)
     mean, std, _ = s.param_est(n_burn=10000)
     assert abs(mean[0] - 1.5) < 0.25 and abs(mean[1] - 1.5) < 0.25      # both modes visited
@@ -250,9 +250,9 @@ def test_attribute_and_method_surface_of_the_reference_classes():
               "run_mcmc", "param_est", "super_chain_mpi", "gather_all_chains", "iter_local_chains", "iter_all_chains",
               "get_chain", "get_chain_rank", "save_state", "load_state", "init_chains", "init_warmstart_chain"]
     dream_only = ["CR", "p_cr", "n_cr_updates", "delta_m", "gamma_scale", "del_pairs", "burnin_gen", "p_cr_update_gen", "n_cr"]
-    d = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, engine_factory=oracle_factory, seed=2,
+    d = DreamMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, seed=2,
                  ln_kwargs={}, inflate=3.0)                       # unknown kwargs are accepted silently (samplers.py:36-43)
-    m = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, engine_factory=oracle_factory, seed=2)
+    m = DeMcMpi(t.ln_like, np.zeros(2), n_chains=8, mpi_comm=None, seed=2)
     for name in common + dream_only:
         assert hasattr(d, name), name
     for name in common:
@@ -265,4 +265,52 @@ def test_attribute_and_method_surface_of_the_reference_classes():
     for name in ("chain", "current_pos", "global_id", "chain_len", "dim", "append_sample"):   # chain.py:13-124
         assert hasattr(c, name), name
     with pytest.raises(AssertionError):
-        DreamMpi(t.ln_like, np.zeros(2), n_chains=3, mpi_comm=None, engine_factory=oracle_factory)   # samplers.py:249
+        DreamMpi(t.ln_like, np.zeros(2), n_chains=3, mpi_comm=None)   # samplers.py:249
+
+
+def test_default_device_enters_its_collective_before_it_raises(monkeypatch):
+    """A mis-launched rank must not leave the others waiting in an allgather: every rank gathers, then all
+    raise the same error.  (The reference's ranks pick no device, demc.py:15.)"""
+    import bipymc_amd.demc as D
+
+    class Comm(object):
+        size = 2
+
+        def __init__(self, rank, others):
+            self.rank, self.others, self.calls = rank, others, 0
+
+        def allgather(self, obj):
+            self.calls += 1
+            out = list(self.others)
+            out.insert(self.rank, obj)
+            return out
+
+    class Stub(object):
+        pass
+    monkeypatch.setattr(D, "_visible_device_count", lambda: 2)
+    monkeypatch.setattr(D, "_hostname", lambda: "box")
+    for var in ("OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+        monkeypatch.delenv(var, raising=False)
+    # this rank is fine, the other one reports an error: both raise
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    s = Stub()
+    s.comm = Comm(0, [("box", -1, 2, "rank 1: local rank 5 but only 2 visible GPU(s): launch one process per GPU")])
+    with pytest.raises(RuntimeError, match="local rank 5"):
+        D.DeMcMpi._default_device(s)
+    assert s.comm.calls == 1
+    # this rank is the broken one: it still enters the collective first
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    s.comm = Comm(1, [("box", 0, 2, None)])
+    with pytest.raises(RuntimeError, match="local rank 5"):
+        D.DeMcMpi._default_device(s)
+    assert s.comm.calls == 1
+    # a rank that sees one device only (launcher narrowed the view) takes part as well, and duplicates are named
+    monkeypatch.setattr(D, "_visible_device_count", lambda: 1)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    s.comm = Comm(1, [("box", 0, 1, None)])
+    assert D.DeMcMpi._default_device(s) == 0 and s.comm.calls == 1
+    monkeypatch.setattr(D, "_visible_device_count", lambda: 2)
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    s.comm = Comm(1, [("box", 0, 2, None)])
+    with pytest.raises(RuntimeError, match="same GPU"):
+        D.DeMcMpi._default_device(s)
