@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPM_LIB_PATH") or os.path.join(_HERE, "libbipymc_hip.so")   # override: experiment builds (tools/)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ALGO_DEMC, ALGO_DREAM, ALGO_DEMC_SYNC = 0, 1, 2
 TARGET_HOST_CALLBACK, TARGET_GAUSS_EQUICORR, TARGET_MIXTURE_PAIRS, TARGET_BANANA_2D = 0, 1, 2, 3
 MAX_CR = 8
@@ -55,6 +55,8 @@ SIGNATURES = {
     "bpm_get_unique_id": (C.c_int, [C.c_char_p]),
     "bpm_create": (C.c_int, [_P(BpmConfig), _P(_H)]),
     "bpm_destroy": (C.c_int, [_H]),
+    "bpm_debug_destroy_plan": (C.c_int, [C.c_int32, C.c_int32]),
+    "bpm_debug_fail_queue": (C.c_int, [_H, C.c_int32]),
     "bpm_init_chains": (C.c_int, [_H, _dp, _dp]),
     "bpm_set_state": (C.c_int, [_H, _dp]),
     "bpm_get_state": (C.c_int, [_H, _dp]),

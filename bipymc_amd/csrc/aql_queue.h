@@ -15,8 +15,8 @@
 // release-less packets: drain() puts a fenced empty kernel behind them unless a later kernel on every XCD has released since.
 // Ordering against the sampler's HIP stream is by the host: the sampler drains one before it uses the other (transitions happen at
 // the end of burn-in and at the API boundary only).  BPM_QUEUE_INFLIGHT=n bounds the dispatches between two drains (for tools that
-// sit between this queue and the hardware queue: rocprofv3's counter collection stalls behind a few hundred outstanding dispatches;
-// chosen automatically, 64, when ROCPROF_COUNTER_COLLECTION is set in the environment).
+// sit between this queue and the hardware queue: rocprofv3's counter collection, see inflight_cap(); chosen automatically, 64, when
+// ROCPROF_COUNTER_COLLECTION is set in the environment).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
@@ -210,6 +210,23 @@ class DirectQueue {
     bool has_fence_kernel() const { return fence_kernel_.object != 0; }
     bool busy() const { return busy_; }
     bool failed() const { return failed_; }
+    // After a failure (a wait ran into its limit): make sure NOTHING dispatched on this queue can still touch memory, so that its users may
+    // free their buffers.  A kernel that is slow or stalled behind a tool, not dead, is invisible to hipStreamSynchronize / hipFree: it would
+    // go on writing freed memory -- a GPU memory fault on exactly the path that was already in trouble.  hsa_queue_inactivate aborts what
+    // is pending and stops the packet processor from taking more; the queue stays dead for the rest of the process (samplers launch on
+    // their HIP streams from then on).  -> true: quiet (or never failed and drained), false: could not be quiesced -- the caller must
+    // LEAK what the queue's kernels may reference.
+    bool quiesce() {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
+        if (!failed_) return !busy_ || drain() == 0 || quiesce();
+        if (dead_) return true;
+        if (test_refuse_quiesce_) return false;
+        if (q_ && hsa_queue_inactivate(q_) == HSA_STATUS_SUCCESS) { dead_ = true; busy_ = false; n_unpublished_ = 0; return true; }
+        return false;
+    }
+    bool dead() const { return dead_; }
+    // test hook (bpm_debug_fail_queue): behave as if a drain had timed out; refuse != 0: and as if the queue could not be inactivated
+    void test_mark_failed(bool refuse) { std::lock_guard<std::recursive_mutex> lk(mu_); failed_ = true; why_ = "failure injected by the test hook"; test_refuse_quiesce_ = refuse; }
     const std::string& why() const { return why_; }
 
     // end-of-kernel time stamps (ns, one clock) of the dispatches that carried timing signal 0 and 1; call after drain()
@@ -332,13 +349,10 @@ class DirectQueue {
             if (n_unpublished_ >= MAX_UNPUBLISHED - 1 || (widx_ & (q_->size - 1)) == 0) flush();
         }
     }
-    // Packets per doorbell at most: the sampler rings once per generation (2-4 packets).  Ringing per packet (BPM_QUEUE_BATCH=1) measures
-    // the same without a profiler (7.31e8 / 7.79e8 at cfg2 either way) but makes a kernel trace slower: every doorbell is a call into
-    // rocprofv3's intercepting queue (5.44 instead of 5.01 us average kernel duration in the trace of the driver's invocation).
-    static uint32_t batch_cap() {
-        static const uint32_t v = getenv("BPM_QUEUE_BATCH") ? (uint32_t)std::max(1, std::min((int)MAX_UNPUBLISHED, atoi(getenv("BPM_QUEUE_BATCH")))) : MAX_UNPUBLISHED;
-        return v;
-    }
+    // Packets per doorbell at most: the sampler rings once per generation (2-4 packets).  (Ringing per packet measured the same without a
+    // profiler -- 7.31e8 / 7.79e8 at cfg2 either way -- but makes a kernel trace slower: every doorbell is a call into rocprofv3's
+    // intercepting queue, 5.44 instead of 5.01 us average kernel duration in the trace of the driver's invocation.)
+    static constexpr uint32_t batch_cap() { return MAX_UNPUBLISHED; }
     static uint32_t inflight_cap() {
         // under rocprofv3's counter collection (it exports ROCPROF_COUNTER_COLLECTION=1 to the profiled process) 64 unless told otherwise
         static const uint32_t v = getenv("BPM_QUEUE_INFLIGHT") ? (uint32_t)std::max(0, atoi(getenv("BPM_QUEUE_INFLIGHT")))
@@ -364,7 +378,7 @@ class DirectQueue {
     bool epoch_armed_[N_EPOCH] = {};
     bool tsig_armed_[2] = {false, false};
     double tick_ns_ = 10.0;
-    bool busy_ = false, failed_ = false;
+    bool busy_ = false, failed_ = false, dead_ = false, test_refuse_quiesce_ = false;
     uint32_t n_unpublished_ = 0;
     uint32_t pending_header_[MAX_UNPUBLISHED]{};
     uint32_t* pending_packet_[MAX_UNPUBLISHED]{};

@@ -39,6 +39,15 @@
 #define BPM_STAMP(i) do { } while (0)
 #endif
 
+// The last-workgroup tickets below (cr_partial_kernel<.., true>, outlier_select_pass_kernel) publish with relaxed agent-scope atomics,
+// `s_waitcnt vmcnt(0)`, then a relaxed fetch_add on the ticket.  That is NOT release/acquire in the HIP / LLVM memory model; it is
+// correct on gfx942 / gfx950 because (a) stores and atomics are counted in vmcnt there (gfx10+ counts stores in vscnt) and (b) agent-scope
+// atomics are performed at the memory side, past the per-XCD L2s -- an agent-scope release would instead write back the whole L2
+// (buffer_wbl2), which is the cost this form avoids.  Any other target must not compile this file silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "kernels.h: the ticket hand-overs rely on gfx942 / gfx950 memory behaviour (vmcnt counts stores; agent-scope atomics bypass the L2s): use __ATOMIC_RELEASE / __ATOMIC_ACQUIRE tickets on other targets"
+#endif
+
 namespace bpm {
 
 constexpr int ALGO_DEMC = 0, ALGO_DREAM = 1;
@@ -1323,7 +1332,8 @@ __global__ __launch_bounds__(CR_PART_THREADS) void cr_partial_kernel(Layout L, u
         // release fence (the library's own queue: sampler.hip finish_generation)
         __hip_atomic_store(&part[tid * CR_PARTS + blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&part[(MAX_CR + tid) * CR_PARTS + blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (TICKET) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket
+        if (TICKET) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket (gfx942 / gfx950
+                                                                         // only: see the #error at the top of this file)
     }
     if (!TICKET) return;
     __shared__ uint32_t s_last;

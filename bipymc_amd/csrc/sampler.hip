@@ -33,6 +33,22 @@
 
 using namespace bpm;
 
+// The ONE environment variable that changes which kernels / launch shapes the library uses: BPM_TEST_PATHS, a comma-separated list read
+// once per process, for the tests that pin every alternative kernel path to the default one bit for bit
+// (tests/test_gpu_api.py::test_alternative_kernel_paths_on_one_gpu) and for the timing tools:
+//   mode1        one work item per LOCAL chain filtered by its position (what a rank of a world without sorted records launches)
+//   noplan       header block and partner ids drawn in the update kernel (what > 16384 chains per GPU use) instead of plan records
+//   noperm       the shuffle bijection walked in the kernel instead of looked up
+//   planall      plan records whatever the number of chains
+//   nohot        the general kernel instantiation instead of the specialised ones
+//   serial       the emulated ranks of a local group take turns on the GPU (tools/emulate_ranks.py)
+//   hosttiming   host nanoseconds spent preparing generations and inside launch calls, printed by bpm_destroy
+// Operational switches (documented in README.md): BPM_DIRECT_QUEUE=0, BPM_QUEUE_INFLIGHT, BPM_QUEUE_TIMEOUT_S, BPM_EXCHANGE, BPM_VERBOSE.
+static bool test_path(const char* name) {
+    static const std::string all = [] { const char* e = getenv("BPM_TEST_PATHS"); return std::string(",") + (e ? e : "") + ","; }();
+    return all.find(std::string(",") + name + ",") != std::string::npos;
+}
+
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
     g_err = m;
@@ -56,15 +72,12 @@ static int fail(const std::string& m) {
 // for the first few hundred microseconds -- longer than the 6 us the GPU needs per update kernel, so a short bpm_step call
 // issued right after a wait ran HOST-paced (profiles/r02_host_launch_pacing.txt).  A polling wait keeps the core clocked up.
 static int wait_stream(hipStream_t st, double spin_ms = 2000.0) {
-    static const bool no_spin = getenv("BPM_NO_SPIN_WAIT") != nullptr;
-    if (!no_spin) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t q = hipStreamQuery(st);
-            if (q == hipSuccess) return 0;
-            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
-            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms) break;
-        }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms) break;
     }
     HIPCK(hipStreamSynchronize(st));
     return 0;
@@ -155,7 +168,6 @@ static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
 template <class K>
 static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a, unsigned grid, unsigned block, hipStream_t s) {
-    static const bool lean = getenv("BPM_NO_LEAN_LAUNCH") == nullptr;
     if (g_dq) {
         FusedKernarg ka;
         ka.pl_plan = a.rec_tab; ka.pl_upd_off = a.rec_off; ka.pl_n_items = a.n_items; ka.pl_mode = a.mode; ka._pad = 0u;
@@ -170,8 +182,8 @@ static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a
         return;
     }
     ++g_n_stream;
-    if (lean && !fn) { if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); fn = nullptr; } }
-    if (lean && fn) {
+    if (!fn) { if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kernel)) != hipSuccess) { (void)hipGetLastError(); fn = nullptr; } }
+    if (fn) {
         FusedKernarg ka;
         ka.pl_plan = a.rec_tab; ka.pl_upd_off = a.rec_off; ka.pl_n_items = a.n_items; ka.pl_mode = a.mode; ka._pad = 0u;
         ka.a = a;
@@ -196,7 +208,7 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
         constexpr bool CAN_PLAN = (LPC == WAVE && DPL == 2);               // the shape that can read plan records
         const bool wp = CAN_PLAN && a.rec_tab != nullptr;
         constexpr bool DREAM_ = ALGO == ALGO_DREAM;
-        static const bool no_hot = getenv("BPM_NO_HOT") != nullptr;
+        static const bool no_hot = test_path("nohot");
         if (!no_hot && phase_args_hot(a, DREAM_, wp, false)) {
             if (wp) launch_hot<ALGO, T, NP, LPC, DPL, (CAN_PLAN ? 1 : 2)>(a, s); else launch_hot<ALGO, T, NP, LPC, DPL, 2>(a, s);
             return;
@@ -349,8 +361,6 @@ struct bpm_sampler {
     int cur = -1;                       // buffer the update stream is using
     int win_K = 0;                      // generations per window (<= PERM_CHUNK)
     bool plan_on = false, sorted_on = false;   // sorted_on: world > 1 with owner-sorted records
-    hipStream_t aux = nullptr;          // optional second build stream (BPM_TAB_AUX=1); default: the update stream builds, one window ahead
-    hipEvent_t ev_main = nullptr;       // "everything enqueued on the update stream so far": a build may not overwrite a buffer before it
     // the current window (aliases into tb[cur])
     uint32_t* perm_tab = nullptr;
     uint32_t* inv_tab = nullptr;
@@ -385,13 +395,6 @@ struct bpm_sampler {
     uint32_t* ckpt_acc = nullptr;
     unsigned long long* ckpt_counters = nullptr;
     int64_t n_sparse_chunks = 0, n_sparse_replays = 0;
-    // steady-state generations on one GPU are replayed as a HIP graph (a chain of 2 K kernel nodes per chunk of K generations)
-    // (a ring of executable graphs: refreshing the arguments of one that is still running would wait for it)
-    static constexpr int GRAPH_RING = 3;
-    hipGraphExec_t gexec[GRAPH_RING] = {nullptr, nullptr, nullptr};
-    int64_t gexec_gens[GRAPH_RING] = {0, 0, 0};       // generations each instantiated graph holds
-    int gexec_next = 0;
-    int64_t n_graph_chunks = 0;
     // direct mode: the generation loop's kernels go through the library's own AQL queue (aql_queue.h) instead of the HIP stream.
     // dq_active: work may be in flight on that queue -- every entry point that uses the stream or reads device memory drains
     // it first (check_handle); run_generations waits for the stream before it enters direct mode.
@@ -476,15 +479,20 @@ static int dev_alloc(T** p, size_t n) {
 }
 
 // Buffers that one update kernel writes and the next one reads (state matrix, ln-like cache, accept counters, Welford moments): ordinary
-// device memory, or -- coherent == true, the experimental mode of bpm_create -- the GPU's EXTENDED-SCOPE FINE-GRAINED pool
+// device memory, or -- coherent == true, ONLY in the experiment build -DBPM_EXPERIMENT_COHERENT -- the GPU's EXTENDED-SCOPE FINE-GRAINED pool
 // (hipDeviceMallocUncached on this runtime): local HBM mapped with the cached-coherent memory type, i.e. the XCDs' L2s stay coherent on
 // these lines by themselves (tools/micro/aql_direct.cpp: a dependent chain of kernels is correct on it with NO release fence between
 // the dispatches, wrong on hipMalloc memory).  Gathers from it cost 1-5 % more than from ordinary device memory.
 template <class T>
 static int dev_alloc_state(T** p, size_t n, bool coherent) {
-    if (!coherent) return dev_alloc(p, n);
-    HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T), hipDeviceMallocUncached));
-    return 0;
+#ifdef BPM_EXPERIMENT_COHERENT
+    if (coherent) {
+        HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T), hipDeviceMallocUncached));
+        return 0;
+    }
+#endif
+    (void)coherent;
+    return dev_alloc(p, n);
 }
 
 // Does memory from dev_alloc_state really stay coherent across the XCDs without a release fence?  What hipDeviceMallocUncached maps
@@ -515,6 +523,7 @@ static long long coherence_probe(bpm::DirectQueue* dq, bool coherent_alloc) {
     if (x) (void)hipFree(x);
     return wrong;
 }
+#ifdef BPM_EXPERIMENT_COHERENT
 static bool state_memory_is_coherent(bpm::DirectQueue* dq, int device) {
     static std::mutex mu;
     static std::map<int, bool> known;
@@ -525,6 +534,7 @@ static bool state_memory_is_coherent(bpm::DirectQueue* dq, int device) {
     known[device] = ok;
     return ok;
 }
+#endif
 
 static int ensure_history(bpm_sampler* s, int64_t rows) {
     if (!s->cfg.keep_history) rows = std::min<int64_t>(rows, 1);
@@ -585,12 +595,13 @@ static int reset_history(bpm_sampler* s) {
     return 0;
 }
 
-// BPM_HOST_TIMING=1 (diagnostic): host nanoseconds spent preparing generations and inside the launch calls, printed by bpm_destroy
-static bool g_host_timing = getenv("BPM_HOST_TIMING") != nullptr;
+// BPM_TEST_PATHS=hosttiming (diagnostic): host nanoseconds spent preparing generations and inside the launch calls, printed by bpm_destroy
+static bool g_host_timing = test_path("hosttiming");
 static long long g_ns_prepare = 0, g_ns_launch = 0, g_n_launch = 0;
 static std::vector<long long> g_launch_log;       // (start, end) of every launch call of the current bpm_step_timed
 static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+extern "C" int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);
 extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
 extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
 extern "C" int bpm_device_count(int32_t* out) {
@@ -618,26 +629,46 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
         g_ns_prepare = g_ns_launch = g_n_launch = 0;
     }
     (void)hipSetDevice(s->cfg.device);
-    (void)leave_direct(s);
+    // What the library's own queue still holds must be finished -- or aborted -- before the buffers its kernels use are freed: the raw
+    // HSA queue is invisible to hipStreamSynchronize and hipFree.  After a drain that ran into its time limit (a tool stalling the
+    // queue: DESIGN.md section 5 "Dispatch") the kernels may be slow, not dead; DirectQueue::quiesce then inactivates the queue, and if
+    // even that is refused the device buffers are deliberately LEAKED and the call reports it.
+    const int drained = leave_direct(s);
+    const bool queue_failed = s->dq != nullptr && (drained != 0 || s->dq->failed());
+    const bool quiet = !queue_failed || s->dq->quiesce();
+    const bool free_buffers = bpm_debug_destroy_plan(queue_failed ? 1 : 0, quiet ? 1 : 0) == 1;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    for (auto& ge : s->gexec) if (ge) (void)hipGraphExecDestroy(ge);
     void* ptrs[] = {s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    if (free_buffers)
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
     }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->ev_main) (void)hipEventDestroy(s->ev_main);
-    if (s->aux) (void)hipStreamDestroy(s->aux);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+    if (!free_buffers)
+        return fail("bpm_destroy: the library's AQL queue failed and could not be quiesced; the sampler's device buffers were leaked "
+                    "rather than freed under kernels that may still run");
+    return 0;
+}
+
+// The decision bpm_destroy takes about the sampler's device buffers, as a pure function (CPU-testable: tests/test_abi.py):
+// 1 = free them, 0 = leak them.  Buffers are freed unless the queue that may still run kernels on them failed AND could not be quiesced.
+extern "C" int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced) { return (queue_failed != 0 && quiesced == 0) ? 0 : 1; }
+
+// Test hook: put the handle's queue into the state a timed-out drain leaves (refuse_quiesce != 0: and make quiesce() fail as if
+// hsa_queue_inactivate had been refused).  The queue of this device is then unusable for the rest of the PROCESS -- run in a child process.
+extern "C" int bpm_debug_fail_queue(bpm_handle_t s, int32_t refuse_quiesce) {
+    if (!s) return fail("null handle");
+    if (!s->dq) return fail("bpm_debug_fail_queue: this sampler has no queue of its own");
+    s->dq->test_mark_failed(refuse_quiesce != 0);
     return 0;
 }
 
@@ -700,45 +731,35 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     } while (0)
     HIPCKD(hipSetDevice(cfg->device));
     HIPCKD(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    // Where the per-generation tables are built.  Default: on the update stream itself, ONE WINDOW AHEAD (on entering window W
-    // the build of W + 1 is enqueued in front of W's first update kernel): 16 us per 64 generations at cfg2, and no bpm_step
-    // call ever starts with a table build.  BPM_TAB_AUX=1 builds on a second stream beside the update kernels instead --
-    // measured SLOWER on MI355X: 13.7 vs 12.3 us per generation at cfg2 (~90 us per window: the cross-queue dependencies and
-    // the concurrent build cost the latency-bound update kernels far more than the 23 us they hide;
-    // profiles/r02_table_build_modes.txt), lowest stream priority no different.
-    if (getenv("BPM_TAB_AUX") != nullptr) HIPCKD(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    // The per-generation tables are built on the update stream itself, ONE WINDOW AHEAD (on entering window W the build of W + 1 is
+    // enqueued in front of W's first update kernel): 16 us per 64 generations at cfg2, and no bpm_step call ever starts with a table
+    // build.  (A second stream for the build measured SLOWER on MI355X, 13.7 vs 12.3 us per generation at cfg2:
+    // profiles/r02_table_build_modes.txt; removed in round 3.)
     // the library's own AQL queue for the steady state of a single-GPU sampler (aql_queue.h); without it (no large BAR, a runtime
     // without the loader extension, BPM_DIRECT_QUEUE=0) the same kernels are launched on the stream
     if (s->world == 1 && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
-        // BPM_LAUNCH_PATH=stream: the sampler keeps its queue but launches on the HIP stream, like bpm_set_launch_path(h, 0, -1)
-        if (const char* lp = getenv("BPM_LAUNCH_PATH")) s->dq_enabled = strcmp(lp, "stream") != 0;
     }
     // The state lives in ordinary device memory; the steady-state packets of the generation loop carry the acquire fence only and the
     // update kernel writes what its successor reads with agent-scope stores (g_dq_update_fence above).  Without the fence kernel (not
-    // found among the loaded code objects) or with BPM_DQ_FENCE=full: acquire + release on every packet, like a HIP stream.
-    // EXPERIMENTAL, opt-in (BPM_COHERENT_STATE=1): state, ln-like cache, accept counters, Welford moments and CR
-    // state in the GPU's hardware-coherent memory type (dev_alloc_state) with acquire-ONLY packets -- the end-of-kernel L2 write-back,
-    // 0.7 us of a 6.1 us launch period at cfg2, goes (10.8 instead of 12.0 us per generation).  NOT the default because it is not safe:
-    // with that memory type in use, history rows (and once whole histories) came back holding older contents in a sequence of
-    // samplers created and destroyed in one process (a row rewritten after bpm_set_state in the middle of a run, buffers reused by the
-    // next sampler) -- with acquire-only AND with full fences, with uploads by DMA or by kernels, never with ordinary memory
-    // (tools/coherent_memory_hazard.py, profiles/r02_coherent_memory_hazard.txt).  The cause was not found in this round.
+    // found among the loaded code objects): acquire + release on every packet, like a HIP stream; bpm_set_launch_path chooses per handle.
+    // The round-2 experiment that kept the state in the GPU's hardware-coherent memory type with acquire-only packets is NOT part of
+    // this library: histories came back with older contents in sequences of samplers created and destroyed in one process, cause not
+    // found (profiles/r02_coherent_memory_hazard.txt).  It builds only as `make variant NAME=coherent DEFS=-DBPM_EXPERIMENT_COHERENT`.
     {
-        const char* c = getenv("BPM_COHERENT_STATE");
-        // (BPM_COHERENT_STATE=2: take the memory type on trust, without the probe -- diagnostics)
+#ifdef BPM_EXPERIMENT_COHERENT
+        const char* c = getenv("BPM_COHERENT_STATE");      // (=2: take the memory type on trust, without the probe)
         s->coherent = s->dq != nullptr && c && atoi(c) != 0 && (atoi(c) == 2 || state_memory_is_coherent(s->dq, cfg->device));
+#endif
         const bool fence_kernel = s->dq != nullptr && s->dq->set_fence_kernel(reinterpret_cast<const void*>(queue_fence_kernel));
         s->dq_fence = fence_kernel ? bpm::DirectQueue::ACQUIRE : bpm::DirectQueue::FENCED;
-        if (const char* f = getenv("BPM_DQ_FENCE")) {
-            if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
-            else if (!strcmp(f, "full")) s->dq_fence = bpm::DirectQueue::FENCED;
-        }
+#ifdef BPM_EXPERIMENT_COHERENT
+        if (const char* f = getenv("BPM_DQ_FENCE")) if (s->coherent && !strcmp(f, "none")) s->dq_fence = 0;
+#endif
     }
     HIPCKD(hipEventCreate(&s->ev0));
     HIPCKD(hipEventCreate(&s->ev1));
-    HIPCKD(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
     for (auto& B : s->tb) HIPCKD(hipEventCreateWithFlags(&B.built, hipEventDisableTiming));
     s->L.blk = (uint64_t)s->n_local * (s->ld + 2);
     s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
@@ -777,16 +798,15 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
     // 25.3 at 16384; from 32768 chains per GPU the records' extra 64 B per update cost more than the shorter critical
     // path gains (42.7 vs 41.6, 77.9 vs 75.8 at 65536).
-    static const bool no_plan = getenv("BPM_NO_PLAN") != nullptr || getenv("BPM_NO_PERM_TAB") != nullptr;
-    const uint32_t plan_max_local = getenv("BPM_PLAN_MAX") ? (uint32_t)atoi(getenv("BPM_PLAN_MAX")) : 16384u;     // tuning switch
+    static const bool no_plan = test_path("noplan") || test_path("noperm");
+    const uint32_t plan_max_local = test_path("planall") ? 0xFFFFFFFFu : 16384u;
     s->win_K = PERM_CHUNK;
-    if (const char* e = getenv("BPM_WIN_K")) s->win_K = std::max(1, std::min(PERM_CHUNK, atoi(e)));     // tuning switch: generations per table window
     s->plan_on = !no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local &&
                  (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) && tid != BPM_TARGET_HOST_CALLBACK;
     if (s->plan_on) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
         s->win_K = (int)std::max<size_t>(1, std::min<size_t>((size_t)s->win_K, ((size_t)512 << 20) / per_gen));
-        s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG && getenv("BPM_NO_PLAN_LOCAL") == nullptr;
+        s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG;
     }
     for (auto& B : s->tb) {
         CKD(dev_alloc(&B.perm, (size_t)s->win_K * s->N));
@@ -831,9 +851,9 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     }
     // (a one-rank communicator takes the same path, so a one-GPU box can time and test it through RCCL)
     if ((s->world > 1 || s->comm) && cfg->algo != BPM_ALGO_DEMC_SYNC && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
-        // BPM_EXCHANGE = dense | rows | replay (default replay); BPM_DENSE_EXCHANGE=1 is the older spelling of dense
+        // BPM_EXCHANGE = dense | rows | replay (default replay): the initial value of bpm_set_exchange
         const char* xe = getenv("BPM_EXCHANGE");
-        const bool want_dense = getenv("BPM_DENSE_EXCHANGE") != nullptr || (xe && std::strcmp(xe, "dense") == 0);
+        const bool want_dense = xe && std::strcmp(xe, "dense") == 0;
         const bool want_rows = xe && std::strcmp(xe, "rows") == 0;
         s->replay_enabled = !want_dense && !want_rows;
         s->sparse_enabled = !want_dense && want_rows;
@@ -843,8 +863,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         // 4 sub-blocks: ~175 acceptances per counter and half generation at cfg2 cost the same on one GPU as 16
         // sub-blocks (23.2 vs 23.0 us/generation through a one-rank communicator; ONE counter: 34 us), and the
         // capacity margin, hence the bytes on the wire, shrinks with the count per sub-block (1.5 x instead of 2.2 x)
-        uint32_t nsub_max = 4u;
-        if (const char* e = getenv("BPM_XNSUB")) nsub_max = (uint32_t)std::max(1, std::min(64, atoi(e)));     // tuning switch
+        const uint32_t nsub_max = 4u;
         while (2u * s->xnsub <= nsub_max && 2u * s->xnsub * 8u <= s->n_local) s->xnsub *= 2u;      // power of two, >= 8 chains each
         s->xcap_max = ((s->n_local + s->xnsub - 1u) / s->xnsub + 1u) & ~1u;    // every chain of a sub-block accepted
         s->xcap = s->xcap_max;                               // first chunk: cannot overflow; then sized from the counts seen
@@ -975,12 +994,7 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     bpm_sampler::TabBuf& B = s->tb[b];
     const int K = s->win_K;
     const int64_t t0 = W * K;
-    hipStream_t bs = s->aux ? s->aux : s->stream;
-    if (s->aux) {
-        // the update stream may still read what this buffer holds (an older window): the build starts behind everything enqueued there so far
-        HIPCK(hipEventRecord(s->ev_main, s->stream));
-        HIPCK(hipStreamWaitEvent(s->aux, s->ev_main, 0));
-    }
+    hipStream_t bs = s->stream;
     PermKeys keys;
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
@@ -1036,7 +1050,6 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
     const int b = (int)(W & 1);
     bpm_sampler::TabBuf& B = s->tb[b];
     if (B.W != W || B.shuffle != shuffle) CK(build_window(s, b, W, shuffle));
-    if (s->aux) HIPCK(hipStreamWaitEvent(s->stream, B.built, 0));
     if (B.sidx) HIPCK(hipEventSynchronize(B.built));              // the window's launch sizes (count_h)
     s->cur = b;
     s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_count_h = B.count_h;
@@ -1105,7 +1118,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.plan = (s->plan_tab && !s->sorted_on) ? s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS : nullptr;   // records BY POSITION
         a.rec_tab = a.plan;
-        { static const bool no_tab = getenv("BPM_NO_PERM_TAB") != nullptr;   // experiment switch
+        { static const bool no_tab = test_path("noperm");
           if (no_tab) { a.perm_tab = nullptr; a.inv_tab = nullptr; } }
         a.gamma_tab = s->gamma_tab;
         a.stamps = s->stamps;
@@ -1121,8 +1134,8 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.pool_off = ph == 0 ? b_off : a_off;
         a.M = ph == 0 ? b_n : a_n;
         // mode 1 (work item = local chain, filtered by its position) is what world_size > 1 uses;
-        // BPM_FORCE_MODE1 selects it on one GPU so the sharded kernel path can be tested there
-        static const bool force_mode1 = getenv("BPM_FORCE_MODE1") != nullptr;
+        // BPM_TEST_PATHS=mode1 selects it on one GPU so the sharded kernel path can be tested there
+        static const bool force_mode1 = test_path("mode1");
         const bool by_chain = s->world > 1 || force_mode1;
         a.mode = by_chain ? 1u : 0u;
         a.n_items = by_chain ? s->n_local : a.n_upd;
@@ -1229,10 +1242,10 @@ struct Group {
 };
 constexpr int64_t SPARSE_CHUNK = 64;
 
-// BPM_LOCAL_SERIAL=1 (tools/emulate_ranks.py): the emulated ranks of a local group take turns on the GPU, so that a kernel
+// BPM_TEST_PATHS=serial (tools/emulate_ranks.py): the emulated ranks of a local group take turns on the GPU, so that a kernel
 // trace shows each rank's kernels as they would run on a GPU of their own
 static bool local_serial(const Group& g) {
-    static const bool on = getenv("BPM_LOCAL_SERIAL") != nullptr;
+    static const bool on = test_path("serial");
     return on && g.R > 1;
 }
 
@@ -1433,87 +1446,23 @@ struct HostCkpt {
     int64_t k_gen, t_abs, hist_rows, rows_logical, w_rows;
 };
 
-// Up to one table window of steady-state generations (single GPU) as one graph launch.  *done_gens = 0: not applicable
-// here (too few generations left in the window), the caller runs a plain generation.
-constexpr int64_t GRAPH_MIN_GENS = 4;
-static int graph_chunk(bpm_sampler* s, int64_t n_left, PhaseLaunch fn, int64_t* done_gens) {
-    *done_gens = 0;
-    CK(ensure_perm_table(s, s->t_abs, n_left));                       // table / record kernels run outside the capture
-    static const int64_t chunk_cap = getenv("BPM_GRAPH_CHUNK") ? std::max(1, atoi(getenv("BPM_GRAPH_CHUNK"))) : PERM_CHUNK;
-    const int64_t K = std::min<int64_t>(std::min<int64_t>(n_left, chunk_cap), s->tab_t0 + s->tab_K - s->t_abs);
-    if (K < std::min<int64_t>(GRAPH_MIN_GENS, chunk_cap)) return 0;
-    if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + K));  // (a reallocation cannot be captured)
-    hipGraph_t graph = nullptr;
-    HIPCK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int rc = 0;
-    for (int64_t i = 0; i < K && rc == 0; ++i) {
-        s->sparse_active = false;
-        rc = prepare_generation(s, n_left - i);
-        if (rc == 0) {
-            for (int ph = 0; ph < 2; ++ph)
-                if (s->cur_args[ph].n_items > 0) fn(s->cur_args[ph], s->stream);
-            rc = finish_generation(s);                                 // host counters only in the steady state
-        }
-    }
-    const hipError_t ec = hipStreamEndCapture(s->stream, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ec != hipSuccess) return fail(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ec));
-    const int slot = s->gexec_next;
-    s->gexec_next = (slot + 1) % bpm_sampler::GRAPH_RING;
-    hipGraphExec_t& ge = s->gexec[slot];
-    if (ge && s->gexec_gens[slot] == K) {                              // same topology: refresh the arguments in place
-        hipGraphNode_t err_node = nullptr;
-        hipGraphExecUpdateResult res;
-        if (hipGraphExecUpdate(ge, graph, &err_node, &res) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipGraphExecDestroy(ge);
-            ge = nullptr;
-        }
-    } else if (ge) {
-        (void)hipGraphExecDestroy(ge);
-        ge = nullptr;
-    }
-    if (!ge) {
-        const hipError_t ei = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
-        if (ei != hipSuccess) { (void)hipGraphDestroy(graph); ge = nullptr; return fail(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ei)); }
-        s->gexec_gens[slot] = K;
-    }
-    const hipError_t el = hipGraphLaunch(ge, s->stream);
-    (void)hipGraphDestroy(graph);
-    if (el != hipSuccess) return fail(std::string("hipGraphLaunch failed: ") + hipGetErrorString(el));
-    s->n_graph_chunks += 1;
-    *done_gens = K;
-    return 0;
-}
-
 static int run_generations(const Group& g, int64_t n_gens) {
     bpm_sampler* s0 = g.h[0];
     PhaseLaunch fn = pick_fused(s0);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
     int64_t done = 0;
-    static const bool use_graph = getenv("BPM_GRAPH") != nullptr;      // opt-in: measured slower than stream launches here, see below
     while (done < n_gens) {
         const bool adapting = dream && s0->cfg.burnin_gen > s0->k_gen;          // dream.py:92: CR statistics travel in the dense block
         if (!(s0->sparse_enabled && !adapting)) {
-            // One GPU, no exchange, nothing but the two update kernels per generation (after burn-in: no cr_adapt, no
-            // outlier check, no moment rebuild): the launches of a whole chunk can be captured and replayed as ONE graph
-            // launch.  For empty kernels a dependent graph node costs 0.65 us less than a dependent stream launch
-            // (tools/micro/launch_overhead.hip: 1.92 vs 2.63 us), but with the update kernel and its 440-byte argument
-            // block the replay measured SLOWER: 13.1 vs 12.5 us/generation at cfg2 (host side 180 us per 64-generation
-            // chunk, fully hidden; a ring of executable graphs so that no update waits for a running one).  Hence opt-in
-            // (BPM_GRAPH=1), kept bit-identical by tests/test_gpu_api.py::test_alternative_kernel_paths_on_one_gpu.
-            if (use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !adapting && s0->cfg.algo != BPM_ALGO_DEMC_SYNC) {
-                int64_t Kg = 0;
-                CK(graph_chunk(s0, n_gens - done, fn, &Kg));
-                if (Kg > 0) { done += Kg; continue; }
-            }
+            // (HIP-graph replay of steady-state chunks was built and measured in round 1 -- 13.1 vs 12.5 us per generation at cfg2 -- and
+            // removed in round 3: DESIGN.md section 5 item 6)
             const bool replay = s0->replay_enabled && !adapting;       // burn-in: delta / cr_idx of every chain travel in the dense block
             // Direct mode: a single GPU's generation loop (the two update kernels, during burn-in the CR reduction, once per window
             // the table build) is dispatched through the library's own AQL queue.  The outlier check and the moment rebuild (rare) run
             // on the HIP stream between two drains (StreamSection); the synchronous mode, tracing and everything with an exchange
             // stay on the stream altogether.
-            const bool direct = s0->dq && s0->dq_enabled && !use_graph && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group && !s0->aux &&
+            const bool direct = s0->dq && s0->dq_enabled && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group &&
                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed();
             if (direct && !s0->dq_active) {
                 CK(wait_stream(s0->stream));                            // what the stream still holds (burn-in, table builds) comes first
@@ -1527,9 +1476,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // (half a generation rewrites at most N/2 + 1 rows)
             const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
-            // (BPM_WT_STORES=1: the same stores on HIP-stream launches -- the rocprofv3 counter passes, which cannot run on the queue)
-            static const bool wt_on_stream = getenv("BPM_WT_STORES") != nullptr;
-            g_wt_stores = !plain_stores && !s0->coherent && (direct ? !(g_dq_update_fence & bpm::DirectQueue::RELEASE) : (wt_on_stream && g.R == 1 && s0->world == 1));
+            g_wt_stores = !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
             g_dq_call_last_gen = direct && done == n_gens - 1;
             const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
             g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false;
@@ -1672,6 +1619,9 @@ extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc,
     bpm::DirectQueue* dq = bpm::DirectQueue::for_device(device);
     *wrong = -1;
     if (!dq) return 0;
+#ifndef BPM_EXPERIMENT_COHERENT
+    if (coherent_alloc != 0) return fail("bpm_debug_coherence_probe: the hardware-coherent memory type is not compiled into this library (experiment build only)");
+#endif
     *wrong = coherence_probe(dq, coherent_alloc != 0);
     return 0;
 }
@@ -1679,7 +1629,7 @@ extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc,
 extern "C" int bpm_set_launch_path(bpm_handle_t s, int32_t direct, int32_t fence) {
     CK(check_handle(s));
     if (fence != -1 && fence != 0 && fence != 1 && fence != 3) return fail("bpm_set_launch_path: fence must be -1 (keep), 0 (none), 1 (acquire) or 3 (acquire + release)");
-    if (fence == 0 && !s->coherent) return fail("bpm_set_launch_path: packets without an acquire fence need the state in cached-coherent memory");
+    if (fence == 0 && !s->coherent) return fail("bpm_set_launch_path: packets without an acquire fence are not available in this library");
     if (fence == 1 && (!s->dq || !s->dq->has_fence_kernel())) return fail("bpm_set_launch_path: acquire-only packets need the library's queue and its fence kernel");
     s->dq_enabled = direct != 0;
     if (fence >= 0) s->dq_fence = fence;
@@ -1703,10 +1653,7 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
     s->timed_l0 = s->timed_l1 = -1;
     g_launch_log.clear();
     const long long tt0 = g_host_timing ? now_ns() : 0;
-    static const bool graph_mode = getenv("BPM_GRAPH") != nullptr;      // (graph replay: the launches are not ours to tag -- a classic event pair)
-    if (graph_mode && n_gens > 0) HIPCK(hipEventRecord(s->ev0, s->stream));
     const int rc = bpm_step(s, n_gens);
-    if (graph_mode && n_gens > 0 && rc == 0) { HIPCK(hipEventRecord(s->ev1, s->stream)); s->timed_l0 = 0; s->timed_l1 = 2 * n_gens; }
     s->timed_want_first = false;
     s->timed_last_gen = -1;
     g_stop_event = nullptr;

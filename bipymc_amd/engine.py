@@ -65,8 +65,8 @@ class HipEngine(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self.lib.bpm_destroy(self._h)
-            self._h = C.c_void_p()
+            h, self._h = self._h, C.c_void_p()
+            L.check(self.lib.bpm_destroy(h))         # non-zero: the queue failed and buffers were leaked (include/bipymc_hip.h)
 
     def __del__(self):
         try:

@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define BPM_ABI_VERSION 1
+/* 2: bpm_step_timed gained n_launches (round 2) and the entry points below it were added; a caller built against version 1 is
+ * refused by bpm_create / by the binding's bpm_abi_version check instead of passing a short argument list. */
+#define BPM_ABI_VERSION 2
 
 /* algo */
 #define BPM_ALGO_DEMC 0  /* bipymc/demc.py:153-196 */
@@ -117,6 +119,8 @@ int bpm_device_count(int32_t* out);
 int bpm_get_unique_id(char out[BPM_UID_BYTES]);
 
 int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out);
+/* Non-zero when the library's own AQL queue had failed (a wait ran into its limit) and could not be quiesced: the handle is gone, but
+ * its device buffers were deliberately leaked instead of freed under kernels that may still run (bpm_last_error says so). */
 int bpm_destroy(bpm_handle_t h);
 
 /* McmcChain.__init__ for every chain (chain.py:25-27): state0 = theta_0 + N(0, diag(varepsilon)),
@@ -212,6 +216,10 @@ int bpm_get_stats(bpm_handle_t h, bpm_stats_t* out);
 int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_m, const double* n_cr_updates,
                         int64_t t_abs);
 
+/* test hooks: bpm_destroy's decision about the device buffers as a pure function (1 free, 0 leak), and the injection of a failed
+ * queue (the device's queue is unusable for the rest of the process afterwards: child processes only) */
+int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);
+int bpm_debug_fail_queue(bpm_handle_t h, int32_t refuse_quiesce);
 /* test hooks (no sampler state involved) */
 int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* test hook: the order statistics, first argmax and cut (Q1 - 2 IQR) the outlier check would select from `omega` (n_chains values) */
 int bpm_debug_outlier_select(bpm_handle_t h, const double* omega, double out[6]);

@@ -86,3 +86,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(text), os.path.join(dirpath, f)
+
+
+def test_destroy_plan_never_frees_under_a_failed_queue(built):
+    """bpm_destroy's decision about the sampler's device buffers (sampler.hip: bpm_debug_destroy_plan): freed unless the library's own
+    queue failed AND could not be quiesced (kernels that are slow, not dead, would write freed memory).  The reference
+    has no counterpart: its chains are NumPy arrays (chain.py:13-29)."""
+    from bipymc_amd import _lib
+    lib = _lib.load()
+    assert lib.bpm_debug_destroy_plan(0, 1) == 1        # healthy queue, drained: free
+    assert lib.bpm_debug_destroy_plan(0, 0) == 1        # (no failure: nothing can still run)
+    assert lib.bpm_debug_destroy_plan(1, 1) == 1        # failed, then inactivated: free
+    assert lib.bpm_debug_destroy_plan(1, 0) == 0        # failed and not quiesced: LEAK

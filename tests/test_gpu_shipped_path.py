@@ -1,0 +1,87 @@
+"""The launch path that SHIPS -- no trace, the library's own AQL queue, acquire-only packets with agent-scope stores of what the
+next kernel reads, the specialised (`HOT`) kernel instantiations -- compared DIRECTLY with the CPU oracle at the sizes BASELINE.json
+names (VERDICT r02 "what's weak" item 1: until now the oracle met the traced, general kernel at N <= 64 and the shipped path met
+the stream path: a self-comparison).
+
+Reference arithmetic restated by the oracle: bipymc/dream.py:32-140 (DREAM update + CR adaptation), bipymc/demc.py:63-151,153-196
+(generation driver, DE-MC update), bipymc/samplers.py:328-336 (Metropolis).  Integer outcomes (accept counts) must be equal; floats
+after G generations: rtol 1e-10 / atol 1e-12 (libm exp/log, reduction order and the float32 Box-Muller of the 1e-12-scale jitter;
+one generation agrees to 1e-12, tests/test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import sampler_ref as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-10, 1e-12
+
+
+def _run_both(algo, N, d, target_id, params, seed, X0, gens, okw, hist_rows):
+    from bipymc_amd.engine import HipEngine
+    eng = HipEngine(algo=algo, n_chains=N, dim=d, target_id=target_id, target_params=params, seed=seed, **okw)
+    ora = R.OracleSampler(algo, N, d, target_id, params, seed, **okw)
+    ls0 = eng.launch_stats()
+    assert ls0["has_queue"], "no direct AQL queue on this box: " + str(ls0)
+    assert ls0["fence"] == "acquire" and not ls0["coherent_state"], ls0
+    eng.set_state(X0)
+    ora.set_state(X0)
+    eng.begin_run()
+    eng.step(gens)                         # NO trace: phase_args_hot() holds, the HOT instantiations run
+    eng.synchronize()
+    ls = eng.launch_stats()
+    assert ls["direct"] - ls0["direct"] == 2 * gens and ls["stream"] == ls0["stream"], (ls0, ls)   # every update kernel through the own queue
+    ora.run(gens)
+    st = eng.stats()
+    # ---- integers: exact
+    assert st["local_n_accepted"] == ora.local_n_accepted, (st["local_n_accepted"], ora.local_n_accepted)
+    assert st["local_n_rejected"] == ora.local_n_rejected
+    assert st["n_nan_alpha"] == ora.n_nan == 0
+    # ---- floats
+    X = eng.get_state()
+    np.testing.assert_allclose(X, ora.X, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=RTOL, atol=1e-9)
+    for g in hist_rows:                    # two history rows, straight out of the device history
+        np.testing.assert_allclose(eng.get_history(g, g + 1)[0], ora.history[g], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(eng.get_loglike_history(g, g + 1)[0], ora.ll_history[g], rtol=RTOL, atol=1e-9)
+    if algo == R.ALGO_DREAM:
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+        np.testing.assert_allclose(st["delta_m"], ora.cr.delta_m, rtol=1e-6)        # divides by per-chain history variances: see test_gpu_parity
+        assert np.array_equal(st["n_cr_updates"], ora.cr.n_cr_updates)
+    frac_bit_equal = float(np.mean(X == ora.X))
+    eng.close()
+    return frac_bit_equal
+
+
+def test_cfg2_shape_on_the_shipped_path_equals_the_oracle():
+    """BASELINE configs[1]: DREAM, 100-D Gaussian, N = 8192, del_pairs 3, n_cr 3 -- 4 burn-in generations (CR adaptation: HOT = 3,
+    gate open from generation 3) + 8 steady-state ones (HOT = 1: plan records, write-through stores, acquire-only packets)."""
+    N, d = 8192, 100
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
+    rs = np.random.RandomState(11)
+    X0 = np.sqrt(np.arange(d) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
+    f = _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 42, X0, 12,
+                  dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2), hist_rows=(3, 12))
+    assert f > 0.5          # (most entries are bit-identical; the rest differ in the last ulps)
+
+
+def test_cfg3_shape_on_the_shipped_path_equals_the_oracle():
+    """BASELINE configs[2]: DE-MC, banana, N = 65536, snooker probability 0.1 (extension: oracle parity only) -- 11 generations, so
+    that k = 0 and k = 10 (gamma = 1 jumps w.p. 0.9, demc.py:174-177) are both inside."""
+    N = 65536
+    bp = R.banana_params()
+    rs = np.random.RandomState(5)
+    X0 = rs.normal(size=(N, 2)) + np.array([0.0, 1.0])
+    _run_both(R.ALGO_DEMC, N, 2, R.TARGET_BANANA_2D, bp, 7, X0, 11, dict(p_snooker=0.1), hist_rows=(1, 11))
+
+
+def test_cfg5_share_on_the_shipped_path_equals_the_oracle():
+    """BASELINE configs[4], one GPU's share: DREAM, 8-D pairwise mixture (extension of dblgauss_rv.py:11-32), N = 32768 -- 3 burn-in
+    generations with CR adaptation + 7 steady-state ones (4 lanes per chain, HOT = 4 / 2)."""
+    N, d = 32768, 8
+    mp = R.mixture_pairs_params(0.25, 0.75, [0, 0], [2, 2], [0.25, 0.25], [0.25, 0.25], 0.8, -0.8)
+    rs = np.random.RandomState(9)
+    X0 = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
+    _run_both(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, mp, 3, X0, 10,
+              dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1), hist_rows=(2, 10))
