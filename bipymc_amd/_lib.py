@@ -14,6 +14,7 @@ ALGO_DEMC, ALGO_DREAM, ALGO_DEMC_SYNC = 0, 1, 2
 TARGET_HOST_CALLBACK, TARGET_GAUSS_EQUICORR, TARGET_MIXTURE_PAIRS, TARGET_BANANA_2D = 0, 1, 2, 3
 MAX_CR = 8
 UID_BYTES = 128
+PUSH_BLOB_BYTES = 256
 TRACE_I32, TRACE_F64, MAX_PARTNERS = 32, 4, 23
 
 
@@ -71,6 +72,9 @@ SIGNATURES = {
     "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),
     "bpm_set_exchange": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bpm_get_exchange_stats": (C.c_int, [_H, _P(C.c_int64)]),
+    "bpm_push_export": (C.c_int, [_H, C.c_void_p]),
+    "bpm_push_connect": (C.c_int, [_H, C.c_void_p]),
+    "bpm_push_selftest": (C.c_int, [_P(_H), C.c_int32, _P(C.c_int32)]),
     "bpm_get_launch_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_set_launch_path": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bpm_debug_coherence_probe": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_int64)]),

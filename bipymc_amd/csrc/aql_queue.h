@@ -45,7 +45,9 @@ struct DqKernel {
 class DirectQueue {
   public:
     static constexpr uint32_t QUEUE_PACKETS = 1024, SLOT_BYTES = 3072, N_SLOTS = QUEUE_PACKETS;
-    enum : int { ACQUIRE = 1, RELEASE = 2, FENCED = 3 };
+    // SYSTEM: the fences named by ACQUIRE / RELEASE are system scope instead of agent scope (push exchange: rows written into other
+    // ranks' memory must have been performed before the completion is announced, and rows peers wrote here must be seen)
+    enum : int { ACQUIRE = 1, RELEASE = 2, FENCED = 3, SYSTEM = 4 };
 
     // one queue per HIP device of the process; nullptr when the queue cannot be had (reason in why())
     static DirectQueue* for_device(int hip_dev) {
@@ -131,9 +133,10 @@ class DirectQueue {
         hsa_signal_t none{0};
         if (sig == 0 || sig == 1) { hsa_signal_store_relaxed(tsig_[sig], 1); tsig_armed_[sig] = true; }
         p->completion_signal = (sig == 0 || sig == 1) ? tsig_[sig] : none;
+        const int scope = (fence & SYSTEM) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
         const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                        (((fence & ACQUIRE) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-                                        (((fence & RELEASE) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+                                        (((fence & ACQUIRE) ? scope : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                        (((fence & RELEASE) ? scope : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         pending_header_[n_unpublished_] = (uint32_t)hdr | ((uint32_t)(3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16);
         pending_packet_[n_unpublished_] = reinterpret_cast<uint32_t*>(p);
         // (the packet's first word still says INVALID: the packet processor stops in front of it until flush() publishes it)

@@ -106,6 +106,20 @@ __device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
 
 constexpr int PLAN_WORDS = 16;    // chain id | header block (4 words) | up to 10 partner ids | pad
 constexpr int MAX_SEG = 16;       // ranks the owner-sorted record table serves (more: records by position, a wavefront per position replays)
+constexpr int MAX_PEERS = MAX_SEG - 1;   // other ranks an owner pushes its accepted rows to (push exchange)
+
+// Push exchange (world > 1): the OWNER of a chain writes an accepted row straight into every other rank's replica of
+// the state matrix -- peer memory mapped into this process (hipIpcOpenMemHandle; over xGMI on a multi-GPU node) -- where the reference
+// has MPI_Allgather (demc.py:93-94,116-117).  What orders the half generations across ranks is one small block per rank:
+//   flag[p]   last barrier sequence number rank p has ANNOUNCED to this rank (written by p's push_sync_kernel, read by this rank's)
+//   err       set by this rank's push_sync_kernel when a wait ran into its time limit: 1 + the rank it was waiting for
+//   probe[p]  connection self-test pattern written by rank p
+struct PushCtrl {
+    unsigned long long flag[MAX_SEG];
+    unsigned long long err;
+    unsigned long long pad[7];
+    unsigned long long probe[MAX_SEG];
+};
 struct PhaseArgs {
     Layout L;
     double* ll;            // [n_local] cached ln_like of the local chains (samplers.py:330 re-evaluates it)
@@ -150,6 +164,11 @@ struct PhaseArgs {
     uint32_t seg_off[MAX_SEG + 1];
     uint32_t n_seg, seg_me;     // number of ranks, this rank
     uint32_t acc_by_item;       // accept bytes indexed by the owner's item number (sorted records) instead of its local chain index
+    // push exchange (world > 1): base addresses of the OTHER ranks' exchange buffers (their `L.G`), a device table of MAX_PEERS entries
+    // (unused ones repeat the first), and how many are real.  An accepted row -- during CR adaptation also every update's (delta, cr)
+    // slots -- is stored at the same offset in each of them with system-scope stores; n_peers == 0: no push
+    const unsigned long long* peer_tab;
+    uint32_t n_peers;
     uint32_t wt;                // 1: the dispatch packet of this launch carries NO release fence -- what a later kernel reads (accepted state
                                 // rows, ln-like cache, accept counters) leaves through agent-scope (write-through) stores (store_row_wt)
     uint64_t seed;
@@ -444,6 +463,21 @@ __device__ __forceinline__ void store_row_wt(double* row, int q, uint32_t ld, co
         if (2 * pi < ld) {
             __hip_atomic_store(row + 2 * pi, v[2 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(row + 2 * pi + 1, v[2 * u + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Push exchange: a row into ANOTHER rank's replica (peer device memory over xGMI, or another process's buffer on the same GPU):
+// relaxed system-scope stores -- written through to the memory that owns the line, visible to the peer's next kernel once this
+// kernel's completion has been announced (push_sync_kernel) and that kernel's packet has acquired.
+template <int LPC, int DPL>
+__device__ __forceinline__ void store_row_sys(double* row, int q, uint32_t ld, const double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        if (2 * pi < ld) {
+            __hip_atomic_store(row + 2 * pi, v[2 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(row + 2 * pi + 1, v[2 * u + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -962,6 +996,22 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
             store_row<LPC, DPL>(sub + 2 + a.pack_cap + (uint32_t)(slot * ld), q, ld, nv);
         }
     }
+    if (a.n_peers) {
+        // push exchange: the owner writes what changed into every other rank's replica (same offsets: the replicas have one layout)
+        const uint32_t row_off = (uint32_t)(row_ptr(a.L, c) - a.L.G);
+        const bool slots = ALGO == ALGO_DREAM && a.adapt_on && q == 0;       // CR statistics of EVERY update travel during burn-in (dream.py:92)
+        const uint32_t d_off = (uint32_t)(delta_ptr(a.L, c) - a.L.G), c_off = (uint32_t)(cridx_ptr(a.L, c) - a.L.G);
+        const bool gated = a.adapt_on && a.cr_gate;
+#pragma unroll 1
+        for (uint32_t p = 0; p < a.n_peers; ++p) {
+            double* pg = reinterpret_cast<double*>(a.peer_tab[p]);
+            if (accepted) store_row_sys<LPC, DPL>(pg + row_off, q, ld, nv);
+            if (slots) {
+                __hip_atomic_store(pg + d_off, gated ? wk.delta : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pg + c_off, gated ? (double)wk.cr_idx : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
     if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
     if (ALGO == ALGO_DREAM) {
@@ -1033,11 +1083,11 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 __host__ inline bool phase_args_hot_sharded(const PhaseArgs& a, bool dream, bool with_plan) {
     return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            a.adapt_on == 0 && a.epsilon > 0.0 && a.L.world > 1 &&
-           a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && a.accbits != nullptr && a.replay == 0 &&
+           a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && (a.accbits != nullptr || a.n_peers > 0) && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
-    return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+    return a.n_peers == 0 && a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            (a.adapt_on != 0) == adapting && a.epsilon > 0.0 && a.L.world == 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr && a.accbits == nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
@@ -1065,7 +1115,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
         a_hot = a_in;
         a_hot.mode = 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
         a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
-        if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; a_hot.acc_by_item = 0u; }
+        if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; a_hot.acc_by_item = 0u; a_hot.n_peers = 0u; a_hot.peer_tab = nullptr; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
         if (NOPLAN) { a_hot.plan = nullptr; a_hot.rec_tab = nullptr; }
     }
@@ -1156,7 +1206,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const Phas
     if (LPC == WAVE) {
         a_rep = a_in;
         a_rep.replay = 1u; a_rep.adapt_on = 0u; a_rep.trace_i32 = nullptr; a_rep.trace_f64 = nullptr; a_rep.trace_mask = nullptr;
-        a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u;
+        a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u; a_rep.n_peers = 0u;
     }
     const PhaseArgs& a = (LPC == WAVE) ? a_rep : a_in;
     __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
@@ -1384,6 +1434,52 @@ __global__ __launch_bounds__(WAVE) void exchange_scatter_kernel(Layout L, double
 // end of any HIP kernel would (DirectQueue::drain).
 __global__ __launch_bounds__(WAVE) void queue_fence_kernel(uint32_t* sink) {
     if (sink && threadIdx.x == 0xffffu) *sink = blockIdx.x;        // (never true: a kernel that is not optimised away)
+}
+
+// Push exchange, the cross-rank hand-over between two half generations (and at the head of every bpm_step call): ONE wavefront.
+// notify: lane p != me stores `seq` into flag[me] of rank p's control block -- this dispatch sits behind the update kernel whose packet
+// released at system scope, so every row that kernel pushed has been performed before the flag; wait: lane p polls flag[p] of THIS
+// rank's block until rank p has announced `seq` too.  The next packet of the queue (barrier bit, system-scope acquire) then starts with
+// every rank's pushes of the finished half generation in this replica -- the lock-step of the reference's Allgather
+// (demc.py:93-94,116-117) without a collective.  Sequence numbers only grow; a peer is never more than one barrier ahead.
+// Every wait is bounded by `timeout_ticks` of the 100 MHz constant clock: on expiry err = 1 + p and the lane leaves (the host reports it).
+__global__ __launch_bounds__(WAVE) void push_sync_kernel(PushCtrl* mine, const unsigned long long* ctrl_tab, uint32_t world, uint32_t me,
+                                                         unsigned long long seq, uint32_t do_notify, uint32_t do_wait,
+                                                         unsigned long long timeout_ticks) {
+    const uint32_t p = threadIdx.x;
+    if (p >= world || p == me) return;
+    if (do_notify) {
+        PushCtrl* pc = reinterpret_cast<PushCtrl*>(ctrl_tab[p]);
+        __hip_atomic_store(&pc->flag[me], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (do_wait) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&mine->flag[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(&mine->err, 1ull + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+// Push exchange for the rare dense blocks (outlier check: the (omega | ln-like) block of this rank's chains): n doubles from `src` to
+// the same offset `off` (in doubles, from the peer buffers' bases in tab) of every other rank.
+__global__ void push_copy_kernel(const double* src, const unsigned long long* tab, uint32_t world, uint32_t me, uint64_t off, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = src[i];
+    for (uint32_t p = 0; p < world; ++p)
+        if (p != me) __hip_atomic_store(reinterpret_cast<double*>(tab[p]) + off + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Connection self-test of the push exchange: every rank writes (seed + me) into probe[me] of every other rank's control block.
+__global__ __launch_bounds__(WAVE) void push_probe_kernel(const unsigned long long* ctrl_tab, uint32_t world, uint32_t me, unsigned long long seed) {
+    const uint32_t p = threadIdx.x;
+    if (p >= world || p == me) return;
+    PushCtrl* pc = reinterpret_cast<PushCtrl*>(ctrl_tab[p]);
+    __hip_atomic_store(&pc->probe[me], seed + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Probe of the memory type the sampler's state is allocated from (sampler.hip: state_memory_is_coherent): launch number `shift` lets

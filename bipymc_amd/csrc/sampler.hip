@@ -8,6 +8,7 @@
 // packed accepted rows, or of whole rank blocks (burn-in, synchronous mode).
 #include <dlfcn.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
@@ -375,6 +376,19 @@ struct bpm_sampler {
     size_t scratch_doubles = 0;
     ncclComm_t comm = nullptr;
     bool local_group = false;     // test mode: ranks are handles of ONE process, exchanged by device copies
+    // push exchange (world > 1): the exchange buffer G, the outlier block om and the control block live in ONE
+    // allocation (the arena) that the other ranks map (hipIpcOpenMemHandle); owners push accepted rows into every replica from the
+    // update kernel, push_sync_kernel orders the half generations across ranks.  No collective, no replay kernel.
+    void* arena = nullptr;
+    size_t arena_bytes = 0, off_om = 0, off_ctrl = 0;
+    PushCtrl* ctrl = nullptr;
+    bool push_connected = false, push_enabled = false, push_no_rccl = false;
+    void* peer_base[MAX_SEG] = {};          // every rank's arena as THIS process addresses it (own entry: arena)
+    bool peer_opened[MAX_SEG] = {};         // mapped with hipIpcOpenMemHandle (to be closed)
+    unsigned long long* tab_peerG = nullptr;    // device [MAX_PEERS]: G of the other ranks (PhaseArgs::peer_tab)
+    unsigned long long* tab_all = nullptr;      // device [3][MAX_SEG]: G | ctrl | om of every rank by rank
+    unsigned long long push_seq = 0;            // barrier sequence number (the same on every rank: lock-step call sequences)
+    int64_t n_push_gens = 0;
     // sparse exchange (world > 1, outside CR adaptation): only accepted rows travel, in fixed-capacity packed blocks;
     // a chunk whose capacity was exceeded is rolled back to its checkpoint and replayed with the dense all-gather
     bool sparse_enabled = false;
@@ -382,6 +396,7 @@ struct bpm_sampler {
     // other rank recomputes the accepted proposals into its replica (phase_replay_kernel)
     bool replay_enabled = false;
     bool replay_active = false;   // the generation being prepared writes accept bytes
+    bool push_active = false;     // the generation being prepared pushes its accepted rows into the other ranks' replicas
     uint8_t* accbits_all = nullptr;   // [N] accept bytes by global chain id; this rank's block at rank * n_local
     int64_t n_replay_gens = 0;
     bool sparse_active = false;   // the generation being prepared packs its accepted rows
@@ -639,7 +654,10 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     const bool free_buffers = bpm_debug_destroy_plan(queue_failed ? 1 : 0, quiet ? 1 : 0) == 1;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    void* ptrs[] = {s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p)
+        if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
+    if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
+    void* ptrs[] = {s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -737,8 +755,9 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // profiles/r02_table_build_modes.txt; removed in round 3.)
     // the library's own AQL queue for the steady state of a single-GPU sampler (aql_queue.h); without it (no large BAR, a runtime
     // without the loader extension, BPM_DIRECT_QUEUE=0) the same kernels are launched on the stream
-    if (s->world == 1 && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
+    if (cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
+        if (s->dq && s->dq->failed()) s->dq = nullptr;       // (a queue that failed earlier in this process is not adopted: HIP stream launches)
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
     }
     // The state lives in ordinary device memory; the steady-state packets of the generation loop carry the acquire fence only and the
@@ -765,8 +784,27 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->L.magic = (uint32_t)((1ull << 32) / s->n_local) + 1u;
     s->L.n_local = s->n_local; s->L.ld = s->ld; s->L.dim = s->dim; s->L.world = s->world;
     const size_t row_d = (size_t)s->n_local * s->ld;
-    CKD(dev_alloc_state(&s->G, (size_t)s->world * s->L.blk, s->coherent));
-    HIPCKD(hipMemsetAsync(s->G, 0, (size_t)s->world * s->L.blk * sizeof(double), s->stream));
+    const bool want_om = cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0;
+    if (s->world > 1 && s->world <= (uint32_t)MAX_SEG && cfg->algo != BPM_ALGO_DEMC_SYNC && cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
+        // the arena of the push exchange: [G | om | control block], one allocation = one IPC handle
+        auto up = [](size_t b) { return (b + 255u) & ~(size_t)255u; };
+        const size_t g_bytes = up((size_t)s->world * s->L.blk * sizeof(double));
+        const size_t om_bytes = want_om ? up((size_t)s->world * 2 * s->n_local * sizeof(double)) : 0;
+        s->off_om = g_bytes; s->off_ctrl = g_bytes + om_bytes;
+        s->arena_bytes = s->off_ctrl + up(sizeof(PushCtrl));
+        HIPCKD(hipMalloc(&s->arena, s->arena_bytes));
+        HIPCKD(hipMemsetAsync(s->arena, 0, s->arena_bytes, s->stream));
+        s->G = reinterpret_cast<double*>(s->arena);
+        if (want_om) s->om = reinterpret_cast<double*>(reinterpret_cast<char*>(s->arena) + s->off_om);
+        s->ctrl = reinterpret_cast<PushCtrl*>(reinterpret_cast<char*>(s->arena) + s->off_ctrl);
+        CKD(dev_alloc(&s->tab_peerG, (size_t)MAX_PEERS));
+        CKD(dev_alloc(&s->tab_all, (size_t)3 * MAX_SEG));
+        HIPCKD(hipMemsetAsync(s->tab_peerG, 0, MAX_PEERS * sizeof(unsigned long long), s->stream));
+        HIPCKD(hipMemsetAsync(s->tab_all, 0, 3 * MAX_SEG * sizeof(unsigned long long), s->stream));
+    } else {
+        CKD(dev_alloc_state(&s->G, (size_t)s->world * s->L.blk, s->coherent));
+        HIPCKD(hipMemsetAsync(s->G, 0, (size_t)s->world * s->L.blk * sizeof(double), s->stream));
+    }
     s->L.G = s->G;
     CKD(dev_alloc_state(&s->ll, s->n_local, s->coherent));
     CKD(dev_alloc_state(&s->w_mean, row_d, s->coherent));
@@ -788,8 +826,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc_state(&s->acc_count, s->n_local, s->coherent));
     HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
-    if (cfg->algo == BPM_ALGO_DREAM && cfg->outlier_every > 0) {
-        CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
+    if (want_om) {
+        if (!s->om) CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
         CKD(dev_alloc(&s->sel, 8));
         CKD(dev_alloc(&s->sel_state, sizeof(SelState)));
         HIPCKD(hipMemsetAsync(s->sel_state, 0, sizeof(SelState), s->stream));
@@ -841,6 +879,12 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // very kernels, layouts and host logic of a multi-GPU run (everything but RCCL) where only one GPU exists.
     if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMLOCAL", 8) == 0) {
         s->local_group = true;
+    } else if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMPUSH", 7) == 0) {
+        // ranks in processes of their own WITHOUT an RCCL communicator: the push exchange is the only one (bpm_push_connect before the
+        // first step).  What N processes sharing one GPU can use -- RCCL refuses two ranks on one device -- and what a caller without
+        // RCCL on its nodes can use.
+        if (!s->arena) { bpm_destroy(s); return fail("bpm_create: the push exchange needs a device target, 2..16 ranks and the pool-based samplers"); }
+        s->push_no_rccl = true;
     } else
     if (cfg->nccl_uid) {      // world_size == 1 with a uid: a one-rank communicator (exercises the RCCL path on one GPU)
         CKD(load_rccl());
@@ -1170,6 +1214,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.u_epsilon = s->opts.u_epsilon;
         a.p_snooker = s->cfg.p_snooker;
         if (s->replay_active) a.accbits = s->accbits_all + (uint64_t)s->rank * s->n_local;
+        if (s->push_active) { a.peer_tab = s->tab_peerG; a.n_peers = s->world - 1u; }
         if (s->sparse_active) {
             a.pack = s->PK + (uint64_t)s->rank * s->xnsub * s->xstride();
             a.pack_cap = s->xcap;
@@ -1254,6 +1299,53 @@ static int group_sync(const Group& g) {
     return 0;
 }
 
+// ---- push exchange ---------------------------------------------------------------------------------------------------------
+// bound of every cross-rank wait inside push_sync_kernel, in ticks of the 100 MHz constant clock (BPM_PUSH_TIMEOUT_S, default 30 s:
+// ranks of a world start their step calls within seconds of each other -- the host-side classes put a communicator barrier in front)
+static unsigned long long push_timeout_ticks() {
+    static const double v = getenv("BPM_PUSH_TIMEOUT_S") ? atof(getenv("BPM_PUSH_TIMEOUT_S")) : 30.0;
+    return (unsigned long long)(std::max(0.001, v) * 1e8);
+}
+// one push_sync_kernel of rank s: on the library's own queue when the generation loop runs there, else on the sampler's stream
+static int launch_push_sync(bpm_sampler* s, unsigned long long seq, bool notify, bool wait) {
+    const unsigned long long* ctab = s->tab_all + MAX_SEG;
+    if (g_dq) {
+        struct { PushCtrl* mine; const unsigned long long* ctab; uint32_t world, me; unsigned long long seq; uint32_t nf, wf; unsigned long long to; } ka{
+            s->ctrl, ctab, s->world, s->rank, seq, notify ? 1u : 0u, wait ? 1u : 0u, push_timeout_ticks()};
+        const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(push_sync_kernel));
+        // (acquire + release at SYSTEM scope: the flags of the peers were written by other agents, and what follows must see their rows)
+        if (!k || g_dq->launch(*k, 1, 1, WAVE, &ka, sizeof(ka), bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM) != 0)
+            return fail("direct AQL queue: push_sync_kernel: " + g_dq->why());
+        g_dq_need_acquire = true;
+        return 0;
+    }
+    hipLaunchKernelGGL(push_sync_kernel, dim3(1), dim3(WAVE), 0, s->stream, s->ctrl, ctab, s->world, s->rank, seq, notify ? 1u : 0u, wait ? 1u : 0u,
+                       push_timeout_ticks());
+    HIPCK(hipGetLastError());
+    return 0;
+}
+// The cross-rank barrier of the push exchange: "every rank has finished -- and pushed -- everything it enqueued before this point".
+// A process per rank: one kernel announces and waits.  A local group (R handles of one process on one GPU, possibly sharing hardware
+// queues): all ranks announce, the host joins the streams, all ranks wait -- the waits then find their flags set, no kernel ever
+// spins on a kernel queued behind it.
+static int push_barrier(const Group& g) {
+    for (int r = 0; r < g.R; ++r) g.h[r]->push_seq += 1;
+    if (g.R == 1) return launch_push_sync(g.h[0], g.h[0]->push_seq, true, true);
+    for (int r = 0; r < g.R; ++r) CK(launch_push_sync(g.h[r], g.h[r]->push_seq, true, false));
+    CK(group_sync(g));
+    for (int r = 0; r < g.R; ++r) CK(launch_push_sync(g.h[r], g.h[r]->push_seq, false, true));
+    return 0;
+}
+// has a wait of this rank's sync kernels run into its limit? (read with the queue / stream drained)
+static int push_check_error(bpm_sampler* s) {
+    if (!s->push_connected) return 0;
+    unsigned long long e = 0;
+    HIPCK(hipMemcpy(&e, &s->ctrl->err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0) return fail("push exchange: rank " + std::to_string(s->rank) + " waited longer than the limit for rank " + std::to_string((long long)e - 1) +
+                            " (a rank that died, or ranks that entered bpm_step more than BPM_PUSH_TIMEOUT_S apart); the replicas are no longer consistent");
+    return 0;
+}
+
 // DREAM outlier-chain reset (Vrugt et al. 2009; extension): chains whose mean ln_like over the last half of their history
 // lies below Q1 - 2 IQR (quartiles over all N chains, np.percentile's interpolation) restart from the best chain's state.
 // Everything stays on the device and on the samplers' streams: omega of the local chains, all-gather of the (omega | ln_like)
@@ -1270,7 +1362,17 @@ static int group_outlier_check(const Group& g) {
                            s->om + (size_t)s->rank * 2 * s->n_local);
         HIPCK(hipGetLastError());
     }
-    if (g.rccl) {
+    if (s0->push_active) {
+        // push exchange: every rank writes its (omega | ln-like) block into the others' om buffers, then the cross-rank barrier
+        for (int r = 0; r < g.R; ++r) {
+            bpm_sampler* s = g.h[r];
+            const uint32_t n = 2u * s->n_local;
+            hipLaunchKernelGGL(push_copy_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, s->om + (size_t)s->rank * n,
+                               (const unsigned long long*)(s->tab_all + 2 * MAX_SEG), s->world, s->rank, (uint64_t)s->rank * n, n);
+            HIPCK(hipGetLastError());
+        }
+        CK(push_barrier(g));
+    } else if (g.rccl) {
         if (s0->world > 1 || s0->comm)
             NCCLCK(g_rccl.AllGather(s0->om + (size_t)s0->rank * 2 * s0->n_local, s0->om, (size_t)2 * s0->n_local, ncclDouble, s0->comm, s0->stream));
     } else if (g.R > 1) {
@@ -1305,6 +1407,8 @@ static int group_outlier_check(const Group& g) {
         HIPCK(hipGetLastError());
         if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
     }
+    // push exchange: nobody starts the next generation (whose accepted rows land in THIS replica) while a reset kernel still writes
+    if (s0->push_active) CK(push_barrier(g));
     return 0;
 }
 
@@ -1387,12 +1491,14 @@ static int exchange_replay(const Group& g, int ph) {
     return 0;
 }
 
-// xmode: how the half generations' updates reach the other ranks: 0 dense all-gather, 1 accepted rows, 2 accept bytes + replay
+// xmode: how the half generations' updates reach the other ranks: 0 dense all-gather, 1 accepted rows, 2 accept bytes + replay,
+// 3 pushed by their owners from inside the update kernel (then only the cross-rank barrier follows a half generation)
 static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLaunch fn) {
     const long long tp0 = g_host_timing ? now_ns() : 0;
     for (int r = 0; r < g.R; ++r) {
         g.h[r]->sparse_active = xmode == 1;
         g.h[r]->replay_active = xmode == 2;
+        g.h[r]->push_active = xmode == 3;
         CK(prepare_generation(g.h[r], n_ahead));
     }
     if (g_host_timing) g_ns_prepare += now_ns() - tp0;
@@ -1429,14 +1535,21 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
                 if (local_serial(g)) HIPCK(hipStreamSynchronize(g.h[r]->stream));
             }
             HIPCK(hipGetLastError());
-            CK(xmode == 2 ? exchange_replay(g, ph) : (xmode == 1 ? exchange_sparse(g) : exchange_dense(g)));
+            CK(xmode == 3 ? push_barrier(g) : (xmode == 2 ? exchange_replay(g, ph) : (xmode == 1 ? exchange_sparse(g) : exchange_dense(g))));
         }
     }
     for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
+    // push exchange during CR adaptation: the next generation's updates write their (delta, cr) slots into every replica; no rank may
+    // get there while another rank's reduction kernels still read this generation's slots
+    if (xmode == 3 && g.h[0]->gen_adapt_on) CK(push_barrier(g));
     if (g.h[0]->outlier_due) {
         StreamSection sec(g.h[0]);
         CK(sec.rc);
-        CK(group_outlier_check(g));
+        bpm::DirectQueue* const dq_saved = g_dq;      // (everything of the check, its cross-rank barriers included, runs on the HIP stream)
+        g_dq = nullptr;
+        const int rc_out = group_outlier_check(g);
+        g_dq = dq_saved;
+        CK(rc_out);
         CK(sec.end());
     }
     return 0;
@@ -1452,9 +1565,12 @@ static int run_generations(const Group& g, int64_t n_gens) {
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
     int64_t done = 0;
+    const bool push = s0->push_enabled && s0->push_connected;
+    if (s0->world > 1 && !push && !g.rccl && g.R == 1) return fail("bpm_step: this rank has no exchange yet: call bpm_push_connect (and bpm_set_exchange(h, 3, 0)) on every rank first");
+    bool push_entered = false;
     while (done < n_gens) {
         const bool adapting = dream && s0->cfg.burnin_gen > s0->k_gen;          // dream.py:92: CR statistics travel in the dense block
-        if (!(s0->sparse_enabled && !adapting)) {
+        if (push || !(s0->sparse_enabled && !adapting)) {
             // (HIP-graph replay of steady-state chunks was built and measured in round 1 -- 13.1 vs 12.5 us per generation at cfg2 -- and
             // removed in round 3: DESIGN.md section 5 item 6)
             const bool replay = s0->replay_enabled && !adapting;       // burn-in: delta / cr_idx of every chain travel in the dense block
@@ -1462,7 +1578,8 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // the table build) is dispatched through the library's own AQL queue.  The outlier check and the moment rebuild (rare) run
             // on the HIP stream between two drains (StreamSection); the synchronous mode, tracing and everything with an exchange
             // stay on the stream altogether.
-            const bool direct = s0->dq && s0->dq_enabled && g.R == 1 && !g.rccl && s0->world == 1 && !s0->local_group &&
+            // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
+            const bool direct = s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && !s0->local_group &&
                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed();
             if (direct && !s0->dq_active) {
                 CK(wait_stream(s0->stream));                            // what the stream still holds (burn-in, table builds) comes first
@@ -1476,9 +1593,18 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // (half a generation rewrites at most N/2 + 1 rows)
             const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
-            g_wt_stores = !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
+            // push exchange: every update packet acquires and releases at SYSTEM scope (rows go to and come from other agents)
+            if (push) g_dq_update_fence = bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM;
+            g_wt_stores = !push && !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
             g_dq_call_last_gen = direct && done == n_gens - 1;
-            const int rc_gen = group_generation(g, n_gens - done, replay ? 2 : 0, fn);
+            if (push && !push_entered) {
+                // entry barrier of the call: a peer's first update kernel may push into THIS replica only after this rank has finished
+                // whatever its host did to the replica before the call (bpm_set_state, a warm start, ...) -- and vice versa
+                for (int r = 0; r < g.R; ++r) g.h[r]->push_active = true;
+                CK(push_barrier(g));
+                push_entered = true;
+            }
+            const int rc_gen = group_generation(g, n_gens - done, push ? 3 : (replay ? 2 : 0), fn);
             g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false;
             if (direct) {
                 s0->dq->flush();                                        // one doorbell per generation
@@ -1486,7 +1612,8 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 if (g_dq_error || s0->dq->failed()) return fail("direct AQL queue: " + (s0->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s0->dq->why()));
             }
             CK(rc_gen);
-            if (replay) for (int r = 0; r < g.R; ++r) g.h[r]->n_replay_gens += 1;
+            if (push) for (int r = 0; r < g.R; ++r) g.h[r]->n_push_gens += 1;
+            else if (replay) for (int r = 0; r < g.R; ++r) g.h[r]->n_replay_gens += 1;
             ++done;
             continue;
         }
@@ -1541,7 +1668,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
         }
         done += K;
     }
-    for (int r = 0; r < g.R; ++r) { g.h[r]->sparse_active = false; g.h[r]->replay_active = false; }
+    for (int r = 0; r < g.R; ++r) { g.h[r]->sparse_active = false; g.h[r]->replay_active = false; g.h[r]->push_active = false; }
     return 0;
 }
 
@@ -1578,8 +1705,11 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
 // generation; rounded up to even, clamped to [2, all chains of a sub-block]).  The same values on every rank of a world.
 extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     CK(check_handle(s));
-    if (mode < 0 || mode > 2) return fail("bpm_set_exchange: mode must be 0 (dense), 1 (rows) or 2 (replay)");
+    if (mode < 0 || mode > 3) return fail("bpm_set_exchange: mode must be 0 (dense), 1 (rows), 2 (replay) or 3 (push)");
+    if (mode == 3 && !s->push_connected) return fail("bpm_set_exchange: the push exchange needs bpm_push_connect first");
+    if (mode != 3 && s->push_no_rccl) return fail("bpm_set_exchange: this sampler was created without an RCCL communicator: the push exchange is its only one");
     if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
+    s->push_enabled = mode == 3;
     s->sparse_enabled = mode == 1;
     s->replay_enabled = mode == 2;
     if (cap > 0) s->xcap = std::min<uint32_t>(s->xcap_max, ((uint32_t)cap + 1u) & ~1u);
@@ -1591,11 +1721,124 @@ extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
 extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     CK(check_handle(s));
     if (!out) return fail("bpm_get_exchange_stats: null argument");
-    out[0] = s->replay_enabled ? 2 : (s->sparse_enabled ? 1 : 0);
+    out[0] = (s->push_enabled && s->push_connected) ? 3 : (s->replay_enabled ? 2 : (s->sparse_enabled ? 1 : 0));
     out[1] = (int64_t)s->xcap;
     out[2] = s->n_sparse_chunks;
     out[3] = s->n_sparse_replays;
     out[4] = s->n_replay_gens;
+    out[5] = s->n_push_gens;
+    out[6] = s->push_connected ? 1 : 0;
+    out[7] = (int64_t)s->push_seq;
+    return 0;
+}
+
+// ---- push exchange: connection ---------------------------------------------------------------------------------------------
+// What a rank publishes about its arena (bpm_push_export), BPM_PUSH_BLOB_BYTES in all.  The blobs of all ranks, in rank order, are what
+// bpm_push_connect takes: the caller moves them with whatever it has (mpi4py allgather, torch.distributed, a file).
+struct PushBlob {
+    uint64_t magic;
+    int64_t pid;
+    int32_t rank, world, device, has_ipc;
+    uint64_t arena_addr, arena_bytes, off_om, off_ctrl, n_chains, dim;
+    hipIpcMemHandle_t handle;
+};
+static_assert(sizeof(PushBlob) <= BPM_PUSH_BLOB_BYTES, "blob size");
+static constexpr uint64_t PUSH_MAGIC = 0x4850555350504D42ull;      // "BPMPUSPH"
+
+extern "C" int bpm_push_export(bpm_handle_t s, void* blob) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!blob) return fail("bpm_push_export: null argument");
+    if (!s->arena) return fail("bpm_push_export: this sampler has no push exchange (world_size 1, more than 16 ranks, synchronous DE-MC or host callback)");
+    PushBlob b;
+    std::memset(&b, 0, sizeof(b));
+    b.magic = PUSH_MAGIC; b.pid = (int64_t)getpid(); b.rank = (int32_t)s->rank; b.world = (int32_t)s->world; b.device = s->cfg.device;
+    b.arena_addr = (uint64_t)(uintptr_t)s->arena; b.arena_bytes = s->arena_bytes; b.off_om = s->off_om; b.off_ctrl = s->off_ctrl;
+    b.n_chains = s->N; b.dim = s->dim;
+    if (hipIpcGetMemHandle(&b.handle, s->arena) == hipSuccess) b.has_ipc = 1;
+    else { (void)hipGetLastError(); b.has_ipc = 0; }      // (ranks of ONE process need no handle; another process will be told)
+    std::memset(blob, 0, BPM_PUSH_BLOB_BYTES);
+    std::memcpy(blob, &b, sizeof(b));
+    return 0;
+}
+
+extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!blobs) return fail("bpm_push_connect: null argument");
+    if (!s->arena) return fail("bpm_push_connect: this sampler has no push exchange");
+    if (s->push_connected) return fail("bpm_push_connect: already connected");
+    HIPCK(hipStreamSynchronize(s->stream));
+    std::vector<unsigned long long> all(3 * MAX_SEG, 0ull), others(MAX_PEERS, 0ull);
+    uint32_t n_others = 0;
+    for (uint32_t p = 0; p < s->world; ++p) {
+        PushBlob b;
+        std::memcpy(&b, static_cast<const char*>(blobs) + (size_t)p * BPM_PUSH_BLOB_BYTES, sizeof(b));
+        if (b.magic != PUSH_MAGIC || b.rank != (int32_t)p || b.world != (int32_t)s->world)
+            return fail("bpm_push_connect: blob " + std::to_string(p) + " is not the export of rank " + std::to_string(p) + " of this world");
+        if (b.arena_bytes != s->arena_bytes || b.off_om != s->off_om || b.off_ctrl != s->off_ctrl || b.n_chains != s->N || b.dim != s->dim)
+            return fail("bpm_push_connect: rank " + std::to_string(p) + " has another sampler shape");
+        void* base = nullptr;
+        if (p == s->rank) {
+            if (b.arena_addr != (uint64_t)(uintptr_t)s->arena || b.pid != (int64_t)getpid()) return fail("bpm_push_connect: the blob of this rank is not its own export");
+            base = s->arena;
+        } else if (b.pid == (int64_t)getpid()) {
+            base = reinterpret_cast<void*>((uintptr_t)b.arena_addr);          // a rank of the same process (local test group): the pointer itself
+        } else {
+            if (!b.has_ipc) return fail("bpm_push_connect: rank " + std::to_string(p) + " could not export an IPC handle of its buffer");
+            const hipError_t e = hipIpcOpenMemHandle(&base, b.handle, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(std::string("bpm_push_connect: hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s buffer failed: " + hipGetErrorString(e) +
+                            " (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank? peer access between the devices?)");
+            }
+            s->peer_opened[p] = true;
+        }
+        s->peer_base[p] = base;
+        const unsigned long long a = (unsigned long long)(uintptr_t)base;
+        all[p] = a; all[MAX_SEG + p] = a + s->off_ctrl; all[2 * MAX_SEG + p] = a + s->off_om;
+        if (p != s->rank) others[n_others++] = a;
+    }
+    for (uint32_t i = n_others; i < (uint32_t)MAX_PEERS; ++i) others[i] = others[0];
+    HIPCK(hipMemcpy(s->tab_all, all.data(), all.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(s->tab_peerG, others.data(), others.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    s->push_connected = true;
+    s->push_enabled = true;               // connected: the default exchange from here on (bpm_set_exchange chooses another)
+    return 0;
+}
+
+// Collective over the ranks (all processes call it together; a local group passes its R handles): every rank writes a pattern into
+// every other rank's control block through the mapped pointers, one cross-rank barrier, every rank checks what it received.
+// *ok = 1: this rank (every rank of the group) saw the pattern of all peers.
+extern "C" int bpm_push_selftest(bpm_handle_t* handles, int32_t R, int32_t* ok) {
+    if (!handles || R < 1 || !ok) return fail("bpm_push_selftest: bad argument");
+    *ok = 0;
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        CK(check_handle(s));
+        if (!s->push_connected) return fail("bpm_push_selftest: call bpm_push_connect first");
+        if (R > 1 && (!s->local_group || (int)s->world != R || (int)s->rank != r)) return fail("bpm_push_selftest: handles are not ranks 0..R-1 of one local group");
+    }
+    CK(set_device(handles[0]));
+    Group g{handles, R, false};
+    const unsigned long long seed = 0xB1900000ull + handles[0]->push_seq;
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        hipLaunchKernelGGL(push_probe_kernel, dim3(1), dim3(WAVE), 0, s->stream, (const unsigned long long*)(s->tab_all + MAX_SEG), s->world, s->rank, seed);
+        HIPCK(hipGetLastError());
+    }
+    CK(push_barrier(g));
+    CK(group_sync(g));
+    bool all_ok = true;
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        PushCtrl c;
+        HIPCK(hipMemcpy(&c, s->ctrl, sizeof(c), hipMemcpyDeviceToHost));
+        if (c.err != 0) all_ok = false;
+        for (uint32_t p = 0; p < s->world; ++p)
+            if (p != s->rank && c.probe[p] != seed + p) all_ok = false;
+    }
+    *ok = all_ok ? 1 : 0;
     return 0;
 }
 
@@ -1816,7 +2059,8 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
 extern "C" int bpm_synchronize(bpm_handle_t s) {
     CK(check_handle(s));
     CK(set_device(s));
-    return wait_stream(s->stream);
+    CK(wait_stream(s->stream));
+    return push_check_error(s);
 }
 
 extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, int32_t* n_out) {

@@ -91,10 +91,21 @@ class DeMcMpi(object):
             self._target_id, self._target_params, self.target_rule = L.TARGET_HOST_CALLBACK, None, "host-callback"
         factory = _engine_factory
         uid = None
+        # How the ranks exchange state where the reference calls comm.Allgather twice per generation (demc.py:93-94,116-117):
+        # exchange="auto" (default): an RCCL communicator is created AND the ranks' buffers are mapped into each other; when the
+        # mapping works on every rank, owners push accepted rows straight into the peers' replicas ("push"), else accept bytes
+        # travel through RCCL and are replayed ("replay").  "push": no RCCL communicator at all (ranks sharing one GPU, nodes
+        # without RCCL).  "replay" / "rows" / "dense": the RCCL exchanges of include/bipymc_hip.h.
+        self.exchange = kwargs.get("exchange", "auto")
+        if self.exchange not in ("auto", "push", "replay", "rows", "dense"):
+            raise ValueError("exchange must be one of auto, push, replay, rows, dense")
         if self.comm.size > 1:
             if self.comm.rank == 0:
                 from .engine import HipEngine
-                uid = HipEngine.unique_id() if factory is _default_engine_factory else b"\0" * L.UID_BYTES
+                if factory is not _default_engine_factory:
+                    uid = b"\0" * L.UID_BYTES
+                else:
+                    uid = HipEngine.push_uid() if self.exchange == "push" else HipEngine.unique_id()
             uid = self.comm.bcast(uid, root=0)
         self._engine = factory(
             algo=self._ALGO, n_chains=self.n_chains, dim=self.dim, target_id=self._target_id,
@@ -103,6 +114,7 @@ class DeMcMpi(object):
             nccl_uid=uid, p_snooker=kwargs.get("p_snooker", 0.0), outlier_every=kwargs.get("outlier_every", 0),
             keep_history=kwargs.get("keep_history", True), **self._engine_kwargs(kwargs))
         self.n_local = self.n_chains // self.comm.size
+        self._connect_exchange()
         self._hist_cache = None
         self._hist_cache_rows = -1
         self.am_chains = []
@@ -114,6 +126,50 @@ class DeMcMpi(object):
     # ---- hooks for DreamMpi --------------------------------------------
     def _engine_kwargs(self, kwargs):
         return {}
+
+    def _connect_exchange(self):
+        """world > 1: every rank publishes what the others need to map its exchange buffer (bpm_push_export), the communicator
+        moves the blobs (the one collective the reference's constructor has no counterpart for), every rank maps its peers
+        (bpm_push_connect) and the connection is tested (bpm_push_selftest).  The decision is collective: push only when it
+        works on EVERY rank; an engine without the entry points (host-callback target, the CPU test engine) skips it."""
+        eng = self._engine
+        self.exchange_used = None
+        if self.comm.size == 1 or not hasattr(eng, "push_export"):
+            return
+        if self.exchange in ("auto", "push") and self.uses_device_target:
+            err = None
+            try:
+                blob = eng.push_export()
+            except Exception as e:                                    # noqa: BLE001 -- reported through the collective below
+                blob, err = None, str(e)
+            blobs = self.comm.allgather((blob, err))
+            ok = all(b[0] is not None for b in blobs)
+            if ok:
+                try:
+                    eng.push_connect([b[0] for b in blobs])
+                except Exception as e:                                # noqa: BLE001
+                    ok, err = False, str(e)
+            oks = self.comm.allgather((ok, err))
+            ok = all(o[0] for o in oks)
+            if ok:
+                self.comm.Barrier()
+                ok = bool(eng.push_selftest())
+                ok = all(self.comm.allgather(ok))
+            if ok:
+                eng.set_exchange("push")
+                self.exchange_used = "push"
+                return
+            why = "; ".join("rank %d: %s" % (i, o[1]) for i, o in enumerate(oks) if o[1]) or "the connection self-test failed"
+            if self.exchange == "push":
+                raise RuntimeError("the push exchange could not be connected: " + why)
+            import warnings
+            warnings.warn("bipymc_amd: push exchange not available (%s); accept bytes travel through RCCL instead" % why)
+            eng.set_exchange("replay")
+            self.exchange_used = "replay"
+            return
+        if self.uses_device_target:
+            eng.set_exchange(self.exchange)
+            self.exchange_used = self.exchange
 
     def _default_device(self):
         """One process per GPU: the node-local rank as the launcher exports it (torchrun: LOCAL_RANK; Open MPI, MVAPICH,
@@ -226,6 +282,7 @@ class DeMcMpi(object):
             raise RuntimeError("ERROR: chains not initilized")       # demc.py:65-66
         n_gens = self._n_generations(n)
         eng = self._engine
+        self.comm.Barrier()            # ranks enter the run together (the push exchange bounds how long a rank waits for its peers)
         eng.begin_run(**self._run_opts(kwargs))
         eng.reserve_history(eng.history_rows() + n_gens)
         done = 0

@@ -176,18 +176,46 @@ class HipEngine(object):
                     p_cr=np.array(st.p_cr[:n]), delta_m=np.array(st.delta_m[:n]),
                     n_cr_updates=np.array(st.n_cr_updates[:n]))
 
-    EXCHANGE_MODES = {"dense": 0, "rows": 1, "replay": 2}
+    EXCHANGE_MODES = {"dense": 0, "rows": 1, "replay": 2, "push": 3}
 
     def set_exchange(self, mode="replay", cap=0):
-        """world_size > 1: "replay" (accept bytes + recomputation, default), "rows" (accepted rows in packed blocks; cap =
-        rows per sub-block per half generation) or "dense" (all-gather of whole blocks)"""
+        """world_size > 1: "push" (owners store accepted rows straight into the peers' replicas; the default once connected),
+        "replay" (accept bytes through RCCL + recomputation), "rows" (accepted rows in packed blocks; cap = rows per sub-block
+        per half generation) or "dense" (all-gather of whole blocks)"""
         L.check(self.lib.bpm_set_exchange(self._h, self.EXCHANGE_MODES[mode], int(cap)))
 
     def exchange_stats(self):
-        out = (C.c_int64 * 5)()
+        out = (C.c_int64 * 8)()
         L.check(self.lib.bpm_get_exchange_stats(self._h, out))
-        return dict(mode=["dense", "rows", "replay"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
-                    replay_gens=int(out[4]))
+        return dict(mode=["dense", "rows", "replay", "push"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
+                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), barriers=int(out[7]))
+
+    # ---- push exchange (world_size > 1): map the ranks' buffers into each other ------------------------------------------
+    def push_export(self):
+        """-> bytes: what the other ranks need to map this rank's exchange buffer (bpm_push_export)"""
+        buf = C.create_string_buffer(L.PUSH_BLOB_BYTES)
+        L.check(self.lib.bpm_push_export(self._h, buf))
+        return buf.raw
+
+    def push_connect(self, blobs):
+        """blobs: the exports of ALL ranks in rank order (bpm_push_connect)"""
+        blobs = [bytes(b) for b in blobs]
+        if len(blobs) != self.world_size or any(len(b) != L.PUSH_BLOB_BYTES for b in blobs):
+            raise ValueError("push_connect needs one export per rank")
+        buf = C.create_string_buffer(b"".join(blobs), L.PUSH_BLOB_BYTES * self.world_size)
+        L.check(self.lib.bpm_push_connect(self._h, buf))
+
+    def push_selftest(self):
+        """collective over the ranks (one engine per process): -> True when this rank received every peer's pattern"""
+        arr = (C.c_void_p * 1)(self._h)
+        ok = C.c_int32(0)
+        L.check(self.lib.bpm_push_selftest(arr, 1, C.byref(ok)))
+        return bool(ok.value)
+
+    @staticmethod
+    def push_uid():
+        """the nccl_uid of a world WITHOUT an RCCL communicator: the push exchange is its only one"""
+        return b"BPMPUSH" + bytes(L.UID_BYTES - 7)
 
     def launch_stats(self):
         """How the update kernels were dispatched: the library's own AQL queue or the HIP stream (bpm_get_launch_stats)."""

@@ -55,6 +55,7 @@ extern "C" {
 
 #define BPM_MAX_CR 8
 #define BPM_UID_BYTES 128
+#define BPM_PUSH_BLOB_BYTES 256
 
 typedef struct bpm_sampler* bpm_handle_t;
 
@@ -168,9 +169,26 @@ int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
  * sets the capacity (rows per sub-block per half generation) of the next chunk, afterwards it follows the largest
  * count seen.  mode 0: the dense all-gather of whole blocks.  The same values on every rank. */
 int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
-/* out[5] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
- *           generations exchanged by replay} */
+/* out[8] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
+ *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected, barriers so far} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
+/* mode 3, "push" (the default once connected): where the reference's ranks meet in MPI_Allgather twice per generation
+ * (demc.py:93-94,116-117), the OWNER of a chain stores an accepted row -- during CR adaptation also every update's (delta, cr)
+ * statistic, dream.py:92 -- straight into every other rank's replica of the state matrix from inside the update kernel: the ranks'
+ * exchange buffers are mapped into each other's address space (hipIpcOpenMemHandle; peer memory over xGMI on a multi-GPU node).  A
+ * one-wavefront kernel per half generation announces "done" in every peer's control block and waits for the peers' announcements; no
+ * collective, no recomputation, and the rank's kernels run on the library's own queue like a single-GPU sampler's.
+ *   bpm_push_export   blob[BPM_PUSH_BLOB_BYTES]: what the other ranks need to map this rank's buffer
+ *   bpm_push_connect  blobs = the exports of ALL ranks in rank order (world_size x BPM_PUSH_BLOB_BYTES), moved by the caller's own
+ *                     communicator (the reference's counterpart is mpi_comm itself, demc.py:15)
+ *   bpm_push_selftest collective: every rank writes a pattern into every peer, one barrier, every rank checks (*ok); handles = this
+ *                     process's ranks (one, or the R ranks of a local test group)
+ * A sampler created with a nccl_uid that starts with "BPMPUSH" has no RCCL communicator at all (ranks sharing one GPU, which RCCL
+ * refuses; nodes without RCCL): the push exchange is then its only one.  Every rank must enter bpm_step within BPM_PUSH_TIMEOUT_S
+ * (default 30) seconds of the others; a rank that waited longer reports it at the next bpm_synchronize. */
+int bpm_push_export(bpm_handle_t h, void* blob);
+int bpm_push_connect(bpm_handle_t h, const void* blobs);
+int bpm_push_selftest(bpm_handle_t* handles, int32_t R, int32_t* ok);
 /* How the generation loop's kernels reach the GPU (no counterpart in the reference: its loop is the Python interpreter,
  * demc.py:79-140).  A single-GPU sampler with a device target dispatches its steady state through the library's own
  * user-mode AQL queue (packets written by the library, bipymc_amd/csrc/aql_queue.h) -- update kernels, table builds, during

@@ -1,0 +1,70 @@
+"""One rank of a world whose ranks are PROCESSES SHARING ONE GPU (tests/test_gpu_push.py): the push exchange through IPC-mapped
+buffers, no RCCL.  usage: _push_worker.py <dir> <rank> <world> <case>"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def case_spec(case):
+    from bipymc_amd import _lib as L
+    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    if case == "dream_gauss100":
+        return d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 64, dict(burnin_gen=8, n_cr_gen=3), 20
+    if case == "dream_mix8_outlier":
+        return (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 480,
+                dict(burnin_gen=30, n_cr_gen=3, del_pairs=2, outlier_every=10), 45)
+    if case == "demc_banana_snooker":
+        return banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 40, dict(p_snooker=0.3), 25
+    if case == "cfg4_shape":          # BASELINE configs[3] per-rank shape: 8192 chains of the 100-D Gaussian per rank
+        return d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, None, dict(burnin_gen=4, n_cr_gen=2), 12
+    raise ValueError(case)
+
+
+def start_state(case, N, d):
+    return np.random.RandomState(3).normal(size=(N, d)) + 0.5
+
+
+def main():
+    d_, rank, world, case = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    from _file_comm import FileComm
+    from bipymc_amd.engine import HipEngine
+    comm = FileComm(d_, rank, world)
+    spec, algo, N, kw, G = case_spec(case)
+    if N is None:
+        N = 8192 * world
+    tid, tp, d = spec
+    if case.startswith("class_"):
+        raise ValueError
+    e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=rank, world_size=world,
+                  nccl_uid=HipEngine.push_uid(), **kw)
+    e.push_connect(comm.allgather(e.push_export()))
+    comm.Barrier()
+    assert e.push_selftest(), "push self-test failed on rank %d" % rank
+    e.set_state(start_state(case, N, d))
+    e.begin_run(flip=0.4)
+    comm.Barrier()
+    e.step(G // 2)
+    e.step(G - G // 2)                  # (a second call: another entry barrier)
+    e.synchronize()
+    st = e.stats()
+    xs = e.exchange_stats()
+    ls = e.launch_stats()
+    rows = (1, G)
+    np.savez(os.path.join(d_, "out_rank%d.npz" % rank), state=e.get_state(), ll=e.get_loglike(),
+             hist_a=e.get_history(rows[0], rows[0] + 1)[0], hist_b=e.get_history(rows[1], rows[1] + 1)[0],
+             hist=e.get_history() if N <= 1024 else np.zeros(0), p_cr=st["p_cr"], n_cr_updates=st["n_cr_updates"],
+             acc=np.array([st["local_n_accepted"], st["local_n_rejected"], st["n_outlier_resets"]]),
+             xmode=np.array([xs["mode"] == "push", xs["push_gens"], ls["direct"], ls["stream"]], dtype=np.int64))
+    comm.Barrier()                      # nobody unmaps while a peer may still be reading its results
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

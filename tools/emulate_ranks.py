@@ -3,7 +3,10 @@
 multi-GPU run, the all-gathers done by device copies) at BASELINE config 4's per-rank shape (8192 chains of the 100-D
 Gaussian per rank).  Run under `rocprofv3 --kernel-trace --stats` to read the per-rank kernel times of an R-GPU run --
 update kernel in the sharded mode, replay / scatter kernels -- which is everything but the RCCL transfer.
-usage: emulate_ranks.py R [replay|rows|dense] [generations] [cfg4|cfg5]
+usage: emulate_ranks.py R [push|replay|rows|dense] [generations] [cfg4|cfg5]
+push: owners store accepted rows into the other ranks' replicas from the update kernel (here: seven more buffers of the SAME GPU's HBM
+instead of peer memory over xGMI), a one-wavefront kernel orders the ranks; no replay kernel.  BPM_TEST_PATHS=serial makes the emulated
+ranks take turns, so a kernel trace shows each rank's kernels alone.
 cfg5: BASELINE config 5's per-rank shape instead (32768 chains of the 8-D mixture per rank, 4 lanes per chain, steady state)."""
 import ctypes as C
 import os
@@ -19,7 +22,7 @@ from bipymc_amd.engine import HipEngine   # noqa: E402
 from bipymc_amd.utils import d100_gauss, mixture_nd   # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-mode = sys.argv[2] if len(sys.argv) > 2 else "replay"
+mode = sys.argv[2] if len(sys.argv) > 2 else "push"
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg4"
 g = d100_gauss.Gauss_100D() if cfg == "cfg4" else mixture_nd.BimodeGauss_ND(8)
@@ -30,6 +33,10 @@ x0 = g.rvs(N)
 uid = b"BPMLOCAL" + bytes(120)
 ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
                    nccl_uid=uid, burnin_gen=0) for r in range(R)]
+if mode == "push":
+    blobs = [e.push_export() for e in ranks]
+    for e in ranks:
+        e.push_connect(blobs)
 for e in ranks:
     e.set_state(x0)
     e.begin_run()
@@ -47,4 +54,5 @@ print("R=%d mode=%s N=%d: %d generations, %.1f us per generation for ALL ranks s
 # the update kernel and the replay kernel of rank 0's last half generation, re-launched back to back (destructive)
 upd, rep = C.c_float(0.0), C.c_float(0.0)
 L.check(ranks[0].lib.bpm_debug_time_kernels(ranks[0]._h, 200, C.byref(upd), C.byref(rep)))
-print("rank 0 alone, 200 launches each: update kernel %.2f us, replay kernel %.2f us per half generation" % (upd.value, rep.value))
+print("rank 0 alone, 200 launches each: update kernel %.2f us%s, replay kernel %.2f us per half generation"
+      % (upd.value, " (pushes to %d peers included)" % (R - 1) if mode == "push" else "", rep.value))
