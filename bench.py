@@ -295,6 +295,74 @@ def other_configs(device, budget_s=6.0):
     return out
 
 
+def connect_exchange(eng, dist, rank, world, want):
+    """-> dict(mode=..., why=...).  Every decision is taken on all ranks together (all_gather_object of what each rank saw)."""
+    def everyone(v):
+        box = [None] * world
+        dist.all_gather_object(box, v)
+        return box
+    if want in ("replay", "rows", "dense"):
+        eng.set_exchange(mode=want)
+        return dict(mode=want, why="--exchange")
+    err = None
+    try:
+        blob = eng.push_export()
+    except Exception as e:                                             # noqa: BLE001 -- reported collectively
+        blob, err = None, "export: %s" % e
+    blobs = everyone((blob, err))
+    ok = all(b[0] is not None for b in blobs)
+    if ok:
+        try:
+            eng.push_connect([b[0] for b in blobs])
+        except Exception as e:                                         # noqa: BLE001
+            ok, err = False, "connect: %s" % e
+    seen = everyone((ok, err))
+    ok = all(o[0] for o in seen)
+    if ok:
+        dist.barrier()
+        try:
+            mine = bool(eng.push_selftest())
+        except Exception as e:                                         # noqa: BLE001
+            mine, err = False, "self-test: %s" % e
+        seen = everyone((mine, err))
+        ok = all(o[0] for o in seen)
+    if ok:
+        eng.set_exchange(mode="push")
+        return dict(mode="push", why="every rank mapped every peer and the self-test passed", ranks_connected=world)
+    why = "; ".join("rank %d: %s" % (i, o[1]) for i, o in enumerate(seen) if o[1]) or "self-test failed on some rank"
+    if want == "push":
+        raise SystemExit("bench.py: --exchange push but the push exchange is not available: " + why)
+    if eng.exchange_stats()["push_connected"]:
+        eng.set_exchange(mode="replay")
+    return dict(mode="replay", why="push exchange not available (%s)" % why)
+
+
+def validate_push_fence_scope(eng, dist, X0, gens=150):
+    """The push exchange's update packets may fence at agent scope instead of system scope (6 us less per half generation); whether
+    that suffices between the GPUs of THIS node is checked before anything is timed: the same `gens` generations (CR adaptation on, so
+    the per-update statistics travel too) from the same start under both settings must leave every rank with the same replica, bit for
+    bit -- and the replicas of all ranks must agree with each other.  -> the setting the timed run uses."""
+    import hashlib
+    shas = {}
+    for scope in ("system", "agent"):
+        eng.set_exchange(mode="push" if scope == "system" else "push-agent")
+        eng.set_state(X0)
+        eng.set_adapt_state(t_abs=0)
+        eng.begin_run()
+        dist.barrier()
+        eng.step(gens)
+        eng.synchronize()
+        mine = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, mine)
+        shas[scope] = box
+    agent_ok = len(set(shas["system"])) == 1 and shas["agent"] == shas["system"]
+    eng.set_exchange(mode="push-agent" if agent_ok else "push")
+    eng.set_adapt_state(t_abs=0)
+    return dict(fence_scope="agent" if agent_ok else "system", fence_scope_validation=dict(
+        generations=gens, replicas_identical_system=len(set(shas["system"])) == 1, agent_equals_system=shas["agent"] == shas["system"]))
+
+
 def main(argv=None):
     global CHAINS_PER_GPU
     ap = argparse.ArgumentParser()
@@ -307,13 +375,15 @@ def main(argv=None):
     ap.add_argument("--preheat", type=float, default=0.5, help="seconds of untimed steady-state generations before burn-in (0: none)")
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU, help="experiments only; the default is the BASELINE workload")
     ap.add_argument("--exchange", default=None, help="N > 1: push (default) | replay | rows | dense")
+    ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL ONLY (never a benchmark number): the N ranks share GPU 0 (push exchange "
+                    "between processes, no RCCL: it refuses two ranks on one device; torch.distributed over gloo) -- runs every line of the N > 1 path on a one-GPU box")
     args = ap.parse_args(argv)
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the parent of the N ranks.  Nothing of torch.cuda / HIP has been touched.
-        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv), n_visible=args.gpus if args.share_gpu else None)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -327,6 +397,8 @@ def main(argv=None):
     if ndev <= 0:
         sys.stderr.write("bench.py: no GPU visible (this benchmark has no CPU path)\n")
         return 2
+    if args.share_gpu:
+        local_rank = 0
     if world > 1 and local_rank >= ndev and ndev > 1:
         sys.stderr.write("bench.py: local rank %d but only %d visible GPU(s): one process per GPU\n" % (local_rank, ndev))
         return 2
@@ -340,7 +412,11 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if args.share_gpu else "cuda"
 
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
@@ -352,14 +428,19 @@ def main(argv=None):
     tid, tparams, _ = target._bpm_target_spec()
     uid = None
     if use_dist:
-        box = [HipEngine.unique_id() if rank == 0 else None]
+        box = [(HipEngine.push_uid() if args.share_gpu else HipEngine.unique_id()) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
     eng = HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42,
                     device=local_rank, rank=rank, world_size=world, nccl_uid=uid,
                     del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
-    if use_dist and args.exchange:
-        eng.set_exchange(mode=args.exchange)
+    # ---- N > 1: how the ranks exchange state where the reference calls comm.Allgather (demc.py:93-94,116-117).  Default: the push
+    # exchange (owners store accepted rows straight into the peers' replicas through IPC-mapped buffers; include/bipymc_hip.h), chosen
+    # COLLECTIVELY -- only when every rank could map every peer and the connection self-test passed everywhere; otherwise accept bytes
+    # through RCCL + replay.  --exchange forces one.
+    exchange_info = None
+    if use_dist:
+        exchange_info = connect_exchange(eng, dist, rank, world, args.exchange)
     # Synthetic start: exact draws of the target (x_i = sigma_i (sqrt(rho) g + sqrt(1-rho) e_i)), so the
     # timed region is the stationary regime and the moment gate below tests invariance.  (From the
     # reference's default start -- theta_0 = 0 + 1e-3 jitter, SURVEY 8(d) -- or an independent over-dispersed one the
@@ -367,8 +448,10 @@ def main(argv=None):
     rs = np.random.RandomState(1234)
     X0 = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((n_chains, 1))
                                           + np.sqrt(0.5) * rs.standard_normal((n_chains, DIM)))
-    eng.set_state(X0)
     total_gens = BURNIN_GEN + max(args.warmup + args.steps + 32, POSTERIOR_MIN_GENS) + 64
+    if exchange_info is not None and exchange_info["mode"] == "push" and args.exchange in (None, "push"):
+        exchange_info.update(validate_push_fence_scope(eng, dist, X0))
+    eng.set_state(X0)
     eng.reserve_history(1 + total_gens)
 
     def fence():
@@ -416,7 +499,7 @@ def main(argv=None):
     el = time.perf_counter() - t0
     ev_ms, ev_launches = eng.last_step_time()
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     value = n_chains * args.steps / el
@@ -448,7 +531,7 @@ def main(argv=None):
         n_burn = (1 + BURNIN_GEN) * n_chains
         cnt, s1, s2, sh = eng.reduce_moments(n_burn)
         if dist is not None:
-            pack = torch.tensor(np.concatenate([[cnt], s1, s2]), dtype=torch.float64, device="cuda")
+            pack = torch.tensor(np.concatenate([[cnt], s1, s2]), dtype=torch.float64, device=coll_dev)
             dist.all_reduce(pack)
             pack = pack.cpu().numpy()
             cnt, s1, s2 = pack[0], pack[1:1 + DIM], pack[1 + DIM:]
@@ -482,7 +565,8 @@ def main(argv=None):
     if rank == 0:
         copy_gbs = measured_copy_bandwidth(torch, local_rank)
         out = {
-            "metric": "chain-updates/sec", "value": value, "unit": "chain-updates/s",
+            "metric": "chain-updates/sec" if not args.share_gpu else "REHEARSAL (ranks share one GPU): not a benchmark number",
+            "value": value, "unit": "chain-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             # the same K generations by the time stamps of the first / last update dispatch (no host launch / wake-up latency)
@@ -498,7 +582,7 @@ def main(argv=None):
                        "start": "exact draws of the target", "n_chains": n_chains, "dim": DIM,
                        "parallelism": "chains sharded x%d" % world,
                        "burnin_updates_per_s": n_chains * BURNIN_GEN / burn_s,
-                       "exchange": xstat,
+                       "exchange": dict(xstat or {}, **(exchange_info or {})) if use_dist else None,
                        # how the update kernels were dispatched: packets written by the library into its own AQL queue
                        # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (BPM_DIRECT_QUEUE=0)
                        "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"],

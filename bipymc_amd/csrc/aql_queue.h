@@ -68,6 +68,22 @@ class DirectQueue {
         return q;
     }
     static std::string& last_reason() { static std::string r; return r; }
+    // A queue of its own for ONE sampler (the ranks of a local test group: R handles of one process whose kernels must be able to wait
+    // for each other across queues, like the ranks of a multi-GPU world do).  The caller owns it: destroy_private().
+    static DirectQueue* create_private(int hip_dev) {
+        DirectQueue* q = new DirectQueue();
+        if (!q->init(hip_dev)) { last_reason() = q->why_; delete q; return nullptr; }
+        q->private_ = true;
+        return q;
+    }
+    static void destroy_private(DirectQueue* q) {
+        if (!q || !q->private_) return;
+        if (q->q_) (void)hsa_queue_destroy(q->q_);
+        for (hsa_signal_t sg : {q->done_, q->tsig_[0], q->tsig_[1]}) if (sg.handle) (void)hsa_signal_destroy(sg);
+        for (auto& es : q->epoch_sig_) if (es.handle) (void)hsa_signal_destroy(es);
+        if (q->kernarg_) (void)hsa_amd_memory_pool_free(q->kernarg_);
+        delete q;
+    }
 
     // the kernel HIP would launch for this host function, as the dispatch packet names it; nullptr if it cannot be located
     const DqKernel* kernel(const void* host_fn) {
@@ -381,7 +397,7 @@ class DirectQueue {
     bool epoch_armed_[N_EPOCH] = {};
     bool tsig_armed_[2] = {false, false};
     double tick_ns_ = 10.0;
-    bool busy_ = false, failed_ = false, dead_ = false, test_refuse_quiesce_ = false;
+    bool busy_ = false, failed_ = false, dead_ = false, test_refuse_quiesce_ = false, private_ = false;
     uint32_t n_unpublished_ = 0;
     uint32_t pending_header_[MAX_UNPUBLISHED]{};
     uint32_t* pending_packet_[MAX_UNPUBLISHED]{};

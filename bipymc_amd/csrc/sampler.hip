@@ -42,6 +42,7 @@ using namespace bpm;
 //   noperm       the shuffle bijection walked in the kernel instead of looked up
 //   planall      plan records whatever the number of chains
 //   nohot        the general kernel instantiation instead of the specialised ones
+//   groupqueues  every rank of a local group on an AQL queue of its own (the ranks' barrier kernels wait for each other across queues)
 //   serial       the emulated ranks of a local group take turns on the GPU (tools/emulate_ranks.py)
 //   hosttiming   host nanoseconds spent preparing generations and inside launch calls, printed by bpm_destroy
 // Operational switches (documented in README.md): BPM_DIRECT_QUEUE=0, BPM_QUEUE_INFLIGHT, BPM_QUEUE_TIMEOUT_S, BPM_EXCHANGE, BPM_VERBOSE.
@@ -167,6 +168,10 @@ static thread_local bool g_dq_release_this = false;       // ... whose last upda
 static thread_local bool g_wt_stores = false;             // this generation's update kernels store through (PhaseArgs::wt)
 static thread_local bool g_dq_need_acquire = false;
 static thread_local int64_t g_n_direct = 0, g_n_stream = 0;   // update-kernel dispatches of this thread by path (bpm_get_launch_stats)
+// A local group whose ranks each have a queue of their own (BPM_TEST_PATHS=groupqueues) runs in direct mode rank by rank: g_dq is
+// re-bound to the rank a piece of work belongs to (bind_rank_queue); the ranks' kernels then wait for each other ACROSS queues the way
+// the ranks of a multi-GPU world do.
+static thread_local bool g_group_direct = false;
 template <class K>
 static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a, unsigned grid, unsigned block, hipStream_t s) {
     if (g_dq) {
@@ -383,6 +388,7 @@ struct bpm_sampler {
     size_t arena_bytes = 0, off_om = 0, off_ctrl = 0;
     PushCtrl* ctrl = nullptr;
     bool push_connected = false, push_enabled = false, push_no_rccl = false;
+    bool push_agent_scope = false;          // update packets fence at agent scope instead of system scope (bpm_set_exchange(h, 3, 1))
     void* peer_base[MAX_SEG] = {};          // every rank's arena as THIS process addresses it (own entry: arena)
     bool peer_opened[MAX_SEG] = {};         // mapped with hipIpcOpenMemHandle (to be closed)
     unsigned long long* tab_peerG = nullptr;    // device [MAX_PEERS]: G of the other ranks (PhaseArgs::peer_tab)
@@ -414,6 +420,7 @@ struct bpm_sampler {
     // dq_active: work may be in flight on that queue -- every entry point that uses the stream or reads device memory drains
     // it first (check_handle); run_generations waits for the stream before it enters direct mode.
     bpm::DirectQueue* dq = nullptr;
+    bool dq_private = false;          // a queue of this sampler's own (rank of a local group under BPM_TEST_PATHS=groupqueues)
     bool dq_active = false;
     bool dq_enabled = true;           // bpm_set_launch_path
     bool coherent = false;            // state buffers live in cached-coherent device memory (dev_alloc_state)
@@ -670,6 +677,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->dq_private && free_buffers) bpm::DirectQueue::destroy_private(s->dq);
     delete s;
     if (!free_buffers)
         return fail("bpm_destroy: the library's AQL queue failed and could not be quiesced; the sampler's device buffers were leaked "
@@ -879,6 +887,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // very kernels, layouts and host logic of a multi-GPU run (everything but RCCL) where only one GPU exists.
     if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMLOCAL", 8) == 0) {
         s->local_group = true;
+        if (test_path("groupqueues") && s->dq) {
+            bpm::DirectQueue* q = bpm::DirectQueue::create_private(cfg->device);
+            if (q && q->kernel(reinterpret_cast<const void*>(perm_table_kernel)) && q->set_fence_kernel(reinterpret_cast<const void*>(queue_fence_kernel))) { s->dq = q; s->dq_private = true; }
+            else if (q) bpm::DirectQueue::destroy_private(q);
+        }
     } else if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMPUSH", 7) == 0) {
         // ranks in processes of their own WITHOUT an RCCL communicator: the push exchange is the only one (bpm_push_connect before the
         // first step).  What N processes sharing one GPU can use -- RCCL refuses two ranks on one device -- and what a caller without
@@ -1043,8 +1056,8 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
     const uint64_t n = (uint64_t)K * s->N;
-    if (g_dq) {
-        // direct mode (single GPU, no second build stream): the same two kernels as packets on the library's queue, in order with
+    if (g_dq && !B.sidx) {
+        // direct mode, records by position: the same two kernels as packets on the library's queue, in order with
         // the update kernels around them
         struct { PermKeys keys; uint32_t n_gens, N; uint32_t* tab; uint32_t* inv; } pa{keys, (uint32_t)K, s->N, B.perm, B.inv};
         static_assert(offsetof(decltype(pa), tab) == sizeof(PermKeys) + 8, "kernarg layout of perm_table_kernel");
@@ -1063,6 +1076,13 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
         g_dq_need_acquire = true;
         return 0;
     }
+    // A rank of a world with owner-sorted records (B.sidx) builds on the HIP stream even while its generation loop runs on the library's
+    // own queue (push exchange): the slot table comes from plan_slot_kernel and the launch sizes of the window must reach the HOST
+    // (pinned copy + event), neither of which the queue path above does -- it once took a window with an unbuilt slot table (records
+    // scattered to garbage slots: a memory fault after 64 generations, the first window built inside direct mode).  Queue drained
+    // before, stream drained after: once per 64 generations.
+    StreamSection sec(s);
+    CK(sec.rc);
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
     if (B.plan) {
@@ -1078,6 +1098,7 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
         HIPCK(hipGetLastError());
     }
     HIPCK(hipEventRecord(B.built, bs));
+    CK(sec.end());
     B.W = W;
     B.shuffle = shuffle;
     return 0;
@@ -1313,8 +1334,11 @@ static int launch_push_sync(bpm_sampler* s, unsigned long long seq, bool notify,
         struct { PushCtrl* mine; const unsigned long long* ctab; uint32_t world, me; unsigned long long seq; uint32_t nf, wf; unsigned long long to; } ka{
             s->ctrl, ctab, s->world, s->rank, seq, notify ? 1u : 0u, wait ? 1u : 0u, push_timeout_ticks()};
         const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(push_sync_kernel));
-        // (acquire + release at SYSTEM scope: the flags of the peers were written by other agents, and what follows must see their rows)
-        if (!k || g_dq->launch(*k, 1, 1, WAVE, &ka, sizeof(ka), bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM) != 0)
+        // NO fences on this packet (the barrier bit orders it behind the update kernel, whose own packet released): the kernel reads and
+        // writes nothing but the flags, with system-scope atomics that pass the caches; the update kernel that follows acquires.
+        // (With acquire + release at system scope here as well a hand-over measured 10.0 us instead of 3.8 with agent-scope fences:
+        // profiles/r03_push_barrier_cost.txt.)
+        if (!k || g_dq->launch(*k, 1, 1, WAVE, &ka, sizeof(ka), 0) != 0)
             return fail("direct AQL queue: push_sync_kernel: " + g_dq->why());
         g_dq_need_acquire = true;
         return 0;
@@ -1328,9 +1352,14 @@ static int launch_push_sync(bpm_sampler* s, unsigned long long seq, bool notify,
 // A process per rank: one kernel announces and waits.  A local group (R handles of one process on one GPU, possibly sharing hardware
 // queues): all ranks announce, the host joins the streams, all ranks wait -- the waits then find their flags set, no kernel ever
 // spins on a kernel queued behind it.
+static inline void bind_rank_queue(bpm_sampler* s) { if (g_group_direct) g_dq = s->dq; }
 static int push_barrier(const Group& g) {
     for (int r = 0; r < g.R; ++r) g.h[r]->push_seq += 1;
     if (g.R == 1) return launch_push_sync(g.h[0], g.h[0]->push_seq, true, true);
+    if (g_group_direct) {          // every rank on a queue of its own: the kernels wait for each other across the queues
+        for (int r = 0; r < g.R; ++r) { bind_rank_queue(g.h[r]); CK(launch_push_sync(g.h[r], g.h[r]->push_seq, true, true)); g.h[r]->dq->flush(); }
+        return 0;
+    }
     for (int r = 0; r < g.R; ++r) CK(launch_push_sync(g.h[r], g.h[r]->push_seq, true, false));
     CK(group_sync(g));
     for (int r = 0; r < g.R; ++r) CK(launch_push_sync(g.h[r], g.h[r]->push_seq, false, true));
@@ -1499,6 +1528,7 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
         g.h[r]->sparse_active = xmode == 1;
         g.h[r]->replay_active = xmode == 2;
         g.h[r]->push_active = xmode == 3;
+        bind_rank_queue(g.h[r]);
         CK(prepare_generation(g.h[r], n_ahead));
     }
     if (g_host_timing) g_ns_prepare += now_ns() - tp0;
@@ -1515,6 +1545,7 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
         for (int ph = 0; ph < 2; ++ph) {
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
+                bind_rank_queue(s);
                 if (s->cur_args[ph].n_items > 0) {
                     g_dq_release_this = g_dq && g_dq_call_last_gen && (ph == 1 || s->cur_args[1].n_items == 0);
                     if (g_dq && s->timed_last_gen >= 0) {
@@ -1538,19 +1569,21 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
             CK(xmode == 3 ? push_barrier(g) : (xmode == 2 ? exchange_replay(g, ph) : (xmode == 1 ? exchange_sparse(g) : exchange_dense(g))));
         }
     }
-    for (int r = 0; r < g.R; ++r) CK(finish_generation(g.h[r]));
+    for (int r = 0; r < g.R; ++r) { bind_rank_queue(g.h[r]); CK(finish_generation(g.h[r])); }
     // push exchange during CR adaptation: the next generation's updates write their (delta, cr) slots into every replica; no rank may
     // get there while another rank's reduction kernels still read this generation's slots
     if (xmode == 3 && g.h[0]->gen_adapt_on) CK(push_barrier(g));
     if (g.h[0]->outlier_due) {
-        StreamSection sec(g.h[0]);
-        CK(sec.rc);
-        bpm::DirectQueue* const dq_saved = g_dq;      // (everything of the check, its cross-rank barriers included, runs on the HIP stream)
-        g_dq = nullptr;
+        // everything of the check, its cross-rank barriers included, runs on the HIP streams: queues drained before, streams after
+        std::vector<StreamSection> secs;
+        for (int r = 0; r < (g_group_direct ? g.R : 1); ++r) { bind_rank_queue(g.h[r]); secs.emplace_back(g.h[r]); CK(secs.back().rc); }
+        bpm::DirectQueue* const dq_saved = g_dq;
+        const bool gd_saved = g_group_direct;
+        g_dq = nullptr; g_group_direct = false;
         const int rc_out = group_outlier_check(g);
-        g_dq = dq_saved;
+        g_dq = dq_saved; g_group_direct = gd_saved;
         CK(rc_out);
-        CK(sec.end());
+        for (auto& sec : secs) CK(sec.end());
     }
     return 0;
 }
@@ -1579,22 +1612,30 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // on the HIP stream between two drains (StreamSection); the synchronous mode, tracing and everything with an exchange
             // stay on the stream altogether.
             // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
-            const bool direct = s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && !s0->local_group &&
-                                s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed();
-            if (direct && !s0->dq_active) {
-                CK(wait_stream(s0->stream));                            // what the stream still holds (burn-in, table builds) comes first
-                s0->dq_active = true;
-                g_dq_need_acquire = true;
-            } else if (!direct && s0->dq_active) {
-                CK(leave_direct(s0));
+            bool group_direct = push && g.R > 1 && !g_host_timing && !local_serial(g);
+            for (int r = 0; r < g.R && group_direct; ++r)
+                group_direct = g.h[r]->dq_private && g.h[r]->dq_enabled && !g.h[r]->dq->failed() && !g.h[r]->trace_i32 && !g.h[r]->stamps;
+            const bool direct = group_direct ||
+                                (s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && (!s0->local_group || s0->dq_private) &&
+                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed());
+            for (int r = 0; r < g.R; ++r) {
+                bpm_sampler* s = g.h[r];
+                if (direct && !s->dq_active) {
+                    CK(wait_stream(s->stream));                         // what the stream still holds (burn-in, table builds) comes first
+                    s->dq_active = true;
+                    g_dq_need_acquire = true;
+                } else if (!direct && s->dq_active) {
+                    CK(leave_direct(s));
+                }
             }
+            g_group_direct = group_direct;
             g_dq = direct ? s0->dq : nullptr;
             g_dq_error = false;
             // (half a generation rewrites at most N/2 + 1 rows)
             const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
             // push exchange: every update packet acquires and releases at SYSTEM scope (rows go to and come from other agents)
-            if (push) g_dq_update_fence = bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM;
+            if (push) g_dq_update_fence = bpm::DirectQueue::FENCED | (s0->push_agent_scope ? 0 : (int)bpm::DirectQueue::SYSTEM);
             g_wt_stores = !push && !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
             g_dq_call_last_gen = direct && done == n_gens - 1;
             if (push && !push_entered) {
@@ -1606,10 +1647,14 @@ static int run_generations(const Group& g, int64_t n_gens) {
             }
             const int rc_gen = group_generation(g, n_gens - done, push ? 3 : (replay ? 2 : 0), fn);
             g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false;
+            g_group_direct = false;
             if (direct) {
-                s0->dq->flush();                                        // one doorbell per generation
                 g_dq = nullptr;
-                if (g_dq_error || s0->dq->failed()) return fail("direct AQL queue: " + (s0->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s0->dq->why()));
+                for (int r = 0; r < (group_direct ? g.R : 1); ++r) {
+                    bpm_sampler* s = g.h[r];
+                    s->dq->flush();                                     // one doorbell per generation
+                    if (g_dq_error || s->dq->failed()) return fail("direct AQL queue: " + (s->dq->why().empty() ? std::string("update kernel not found among the loaded code objects") : s->dq->why()));
+                }
             }
             CK(rc_gen);
             if (push) for (int r = 0; r < g.R; ++r) g.h[r]->n_push_gens += 1;
@@ -1685,13 +1730,17 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
     CK(set_device(handles[0]));
     Group g{handles, R, false};
     CK(run_generations(g, n_gens));
+    for (int r = 0; r < R; ++r) CK(leave_direct(handles[r]));      // (ranks with queues of their own: everything is enqueued on all of them by now)
     return group_sync(g);
 }
 
 extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     CK(check_handle_keep_direct(s));
     CK(set_device(s));
-    if (s->local_group) return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step");
+    // (a rank of a local group with a queue of its own and the push exchange is as independent as a process of its own: one host
+    // thread per rank may drive it through bpm_step, the ranks then meet in the cross-rank barrier kernels like the ranks of a world)
+    if (s->local_group && !(s->dq_private && s->push_connected && s->push_enabled))
+        return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step");
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
@@ -1710,9 +1759,10 @@ extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     if (mode != 3 && s->push_no_rccl) return fail("bpm_set_exchange: this sampler was created without an RCCL communicator: the push exchange is its only one");
     if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
     s->push_enabled = mode == 3;
+    if (mode == 3) s->push_agent_scope = (cap & 1) != 0;
     s->sparse_enabled = mode == 1;
     s->replay_enabled = mode == 2;
-    if (cap > 0) s->xcap = std::min<uint32_t>(s->xcap_max, ((uint32_t)cap + 1u) & ~1u);
+    if (mode == 1 && cap > 0) s->xcap = std::min<uint32_t>(s->xcap_max, ((uint32_t)cap + 1u) & ~1u);
     return 0;
 }
 
@@ -1728,7 +1778,7 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     out[4] = s->n_replay_gens;
     out[5] = s->n_push_gens;
     out[6] = s->push_connected ? 1 : 0;
-    out[7] = (int64_t)s->push_seq;
+    out[7] = (int64_t)s->push_seq | (s->push_agent_scope ? (1ll << 62) : 0);
     return 0;
 }
 

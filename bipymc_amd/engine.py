@@ -182,13 +182,16 @@ class HipEngine(object):
         """world_size > 1: "push" (owners store accepted rows straight into the peers' replicas; the default once connected),
         "replay" (accept bytes through RCCL + recomputation), "rows" (accepted rows in packed blocks; cap = rows per sub-block
         per half generation) or "dense" (all-gather of whole blocks)"""
+        if mode == "push-agent":          # the push exchange with agent-scope packet fences (include/bipymc_hip.h: bpm_set_exchange)
+            mode, cap = "push", 1
         L.check(self.lib.bpm_set_exchange(self._h, self.EXCHANGE_MODES[mode], int(cap)))
 
     def exchange_stats(self):
         out = (C.c_int64 * 8)()
         L.check(self.lib.bpm_get_exchange_stats(self._h, out))
         return dict(mode=["dense", "rows", "replay", "push"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
-                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), barriers=int(out[7]))
+                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), barriers=int(out[7]) & ((1 << 62) - 1),
+                    push_fence_scope="agent" if int(out[7]) >> 62 & 1 else "system")
 
     # ---- push exchange (world_size > 1): map the ranks' buffers into each other ------------------------------------------
     def push_export(self):

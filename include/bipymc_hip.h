@@ -170,7 +170,8 @@ int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
  * count seen.  mode 0: the dense all-gather of whole blocks.  The same values on every rank. */
 int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
 /* out[8] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
- *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected, barriers so far} */
+ *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected,
+ *           barriers so far | bit 62 when the push exchange fences at agent scope} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 /* mode 3, "push" (the default once connected): where the reference's ranks meet in MPI_Allgather twice per generation
  * (demc.py:93-94,116-117), the OWNER of a chain stores an accepted row -- during CR adaptation also every update's (delta, cr)
@@ -178,6 +179,10 @@ int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
  * exchange buffers are mapped into each other's address space (hipIpcOpenMemHandle; peer memory over xGMI on a multi-GPU node).  A
  * one-wavefront kernel per half generation announces "done" in every peer's control block and waits for the peers' announcements; no
  * collective, no recomputation, and the rank's kernels run on the library's own queue like a single-GPU sampler's.
+ * cap (mode 3): 0 = the update kernels' packets acquire and release at SYSTEM scope, what the HSA memory model asks for between agents
+ * (default); 1 = at AGENT scope, 6 us less per half generation on MI355X -- the pushed rows themselves are system-scope write-through
+ * stores either way; whether the cheaper fences suffice between the GPUs of a node is a property of the platform that a caller
+ * verifies by comparing the ranks' replicas (bench.py does, before it times anything).
  *   bpm_push_export   blob[BPM_PUSH_BLOB_BYTES]: what the other ranks need to map this rank's buffer
  *   bpm_push_connect  blobs = the exports of ALL ranks in rank order (world_size x BPM_PUSH_BLOB_BYTES), moved by the caller's own
  *                     communicator (the reference's counterpart is mpi_comm itself, demc.py:15)

@@ -17,6 +17,8 @@ def case_spec(case):
     from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
     if case == "dream_gauss100":
         return d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 64, dict(burnin_gen=8, n_cr_gen=3), 20
+    if case == "dream_gauss100_long":      # crosses two 64-generation table windows: the windows built INSIDE the generation loop
+        return d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 64, dict(burnin_gen=8, n_cr_gen=3), 150
     if case == "dream_mix8_outlier":
         return (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 480,
                 dict(burnin_gen=30, n_cr_gen=3, del_pairs=2, outlier_every=10), 45)
@@ -66,5 +68,72 @@ def main():
     e.close()
 
 
+def single_rank_reference(case, world=1):
+    from bipymc_amd.engine import HipEngine
+    spec, algo, N, kw, G = case_spec(case)
+    if N is None:
+        N = 8192 * world
+    tid, tp, d = spec
+    one = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
+    one.set_state(start_state(case, N, d))
+    one.begin_run(flip=0.4)
+    one.step(G // 2)
+    one.step(G - G // 2)
+    st = one.stats()
+    res = dict(state=one.get_state(), ll=one.get_loglike(), hist_a=one.get_history(1, 2)[0], hist_b=one.get_history(G, G + 1)[0],
+               hist=one.get_history() if N <= 1024 else None, p_cr=st["p_cr"], n_cr_updates=st["n_cr_updates"],
+               acc=np.array([st["local_n_accepted"], st["local_n_rejected"], st["n_outlier_resets"]]), N=N, d=d, G=G)
+    one.close()
+    return res
+
+
+def local_group_check(case, R):
+    """R ranks as handles of THIS process (bpm_local_group_step) over the push exchange == the single-rank run, bit for bit.
+    -> (update launches through the ranks' own queues, through HIP streams)"""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    spec, algo, N, kw, G = case_spec(case)
+    tid, tp, d = spec
+    ref = single_rank_reference(case)
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, **kw)
+             for r in range(R)]
+    ls0 = ranks[0].launch_stats()
+    blobs = [e.push_export() for e in ranks]
+    for e in ranks:
+        e.push_connect(blobs)
+    arr = (C.c_void_p * R)(*[e._h for e in ranks])
+    ok = C.c_int32(0)
+    L.check(ranks[0].lib.bpm_push_selftest(arr, R, C.byref(ok)))
+    assert ok.value == 1
+    x0 = start_state(case, N, d)
+    for e in ranks:
+        assert e.exchange_stats()["mode"] == "push"
+        e.set_state(x0)
+        e.begin_run(flip=0.4)
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G // 2))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G - G // 2))
+    n_local = N // R
+    H = np.concatenate([e.get_history() for e in ranks], axis=1)
+    assert np.array_equal(H, ref["hist"])                                  # every chain's whole history, bit for bit
+    for r, e in enumerate(ranks):
+        st = e.stats()
+        assert np.array_equal(e.get_state(), ref["state"])                 # every replica
+        assert np.array_equal(e.get_loglike(), ref["ll"][r * n_local:(r + 1) * n_local])
+        assert np.array_equal(st["p_cr"], ref["p_cr"]) and np.array_equal(st["n_cr_updates"], ref["n_cr_updates"])
+        assert st["n_outlier_resets"] == ref["acc"][2]
+        assert e.exchange_stats()["push_gens"] == G
+    assert sum(e.stats()["local_n_accepted"] for e in ranks) == ref["acc"][0]
+    ls = ranks[0].launch_stats()
+    for e in ranks:
+        e.close()
+    return ls["direct"] - ls0["direct"], ls["stream"] - ls0["stream"]
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1] == "--group":
+        nd, ns = local_group_check(sys.argv[2], int(sys.argv[3]))
+        print("GROUP ok direct=%d stream=%d" % (nd, ns))
+    else:
+        main()

@@ -19,64 +19,35 @@ if HERE not in sys.path:
 
 
 def _single(case, world=1):
-    from _push_worker import case_spec, start_state
-    from bipymc_amd.engine import HipEngine
-    spec, algo, N, kw, G = case_spec(case)
-    if N is None:
-        N = 8192 * world
-    tid, tp, d = spec
-    one = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, **kw)
-    one.set_state(start_state(case, N, d))
-    one.begin_run(flip=0.4)
-    one.step(G // 2)
-    one.step(G - G // 2)
-    st = one.stats()
-    res = dict(state=one.get_state(), ll=one.get_loglike(), hist_a=one.get_history(1, 2)[0], hist_b=one.get_history(G, G + 1)[0],
-               hist=one.get_history() if N <= 1024 else None, p_cr=st["p_cr"], n_cr_updates=st["n_cr_updates"],
-               acc=np.array([st["local_n_accepted"], st["local_n_rejected"], st["n_outlier_resets"]]), N=N, d=d, G=G)
-    one.close()
-    return res
+    from _push_worker import single_rank_reference
+    return single_rank_reference(case, world)
 
 
-@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker"])
+@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8_outlier", "demc_banana_snooker", "dream_gauss100_long"])
 @pytest.mark.parametrize("R", [2, 4, 8])
 def test_push_exchange_local_group_equals_single_rank(case, R):
-    from _push_worker import case_spec, start_state
-    from bipymc_amd import _lib as L
-    from bipymc_amd.engine import HipEngine
-    spec, algo, N, kw, G = case_spec(case)
-    tid, tp, d = spec
-    ref = _single(case)
-    uid = b"BPMLOCAL" + bytes(120)
-    ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, **kw)
-             for r in range(R)]
-    blobs = [e.push_export() for e in ranks]
-    for e in ranks:
-        e.push_connect(blobs)
-    arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    ok = C.c_int32(0)
-    L.check(ranks[0].lib.bpm_push_selftest(arr, R, C.byref(ok)))
-    assert ok.value == 1
-    x0 = start_state(case, N, d)
-    for e in ranks:
-        assert e.exchange_stats()["mode"] == "push"
-        e.set_state(x0)
-        e.begin_run(flip=0.4)
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G // 2))
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G - G // 2))
-    n_local = N // R
-    H = np.concatenate([e.get_history() for e in ranks], axis=1)
-    assert np.array_equal(H, ref["hist"])                                  # every chain's whole history, bit for bit
-    for r, e in enumerate(ranks):
-        st = e.stats()
-        assert np.array_equal(e.get_state(), ref["state"])                 # every replica
-        assert np.array_equal(e.get_loglike(), ref["ll"][r * n_local:(r + 1) * n_local])
-        assert np.array_equal(st["p_cr"], ref["p_cr"]) and np.array_equal(st["n_cr_updates"], ref["n_cr_updates"])
-        assert st["n_outlier_resets"] == ref["acc"][2]
-        assert e.exchange_stats()["push_gens"] == G
-    assert sum(e.stats()["local_n_accepted"] for e in ranks) == ref["acc"][0]
-    for e in ranks:
-        e.close()
+    """R handles of this process on HIP streams; the cross-rank barrier as announce-all / join / wait-all."""
+    from _push_worker import local_group_check
+    nd, ns = local_group_check(case, R)
+    assert nd == 0 and ns > 0
+
+
+@pytest.mark.parametrize("case,R", [("dream_gauss100", 2), ("dream_gauss100_long", 4), ("dream_mix8_outlier", 4), ("dream_gauss100", 8),
+                                    ("demc_banana_snooker", 8)])
+def test_push_exchange_local_group_with_a_queue_per_rank(case, R):
+    """The same with every rank on an AQL queue of its own (BPM_TEST_PATHS=groupqueues, read at library load: a child process): the
+    ranks' one-wavefront barrier kernels announce and WAIT FOR EACH OTHER across queues inside one process -- what the ranks of a
+    multi-GPU world do across GPUs."""
+    env = dict(os.environ)
+    env["BPM_TEST_PATHS"] = "groupqueues"
+    env["BPM_PUSH_TIMEOUT_S"] = "20"
+    env["BPM_QUEUE_TIMEOUT_S"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_push_worker.py"), "--group", case, str(R)], env=env, capture_output=True,
+                         text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("GROUP ok")][0]
+    nd, ns = (int(t.split("=")[1]) for t in line.split()[2:4])
+    assert nd > 0 and ns == 0, line                                          # every update kernel through the rank's own queue
 
 
 def _run_processes(case, R, tmp_path):
@@ -99,7 +70,7 @@ def _run_processes(case, R, tmp_path):
     return [np.load(os.path.join(str(tmp_path), "out_rank%d.npz" % r)) for r in range(R)]
 
 
-@pytest.mark.parametrize("case,R", [("dream_gauss100", 2), ("dream_gauss100", 4), ("dream_mix8_outlier", 4), ("demc_banana_snooker", 2),
+@pytest.mark.parametrize("case,R", [("dream_gauss100", 2), ("dream_gauss100", 4), ("dream_gauss100_long", 2), ("dream_mix8_outlier", 4), ("demc_banana_snooker", 2),
                                     ("cfg4_shape", 4)])
 def test_push_exchange_between_processes_sharing_the_gpu(case, R, tmp_path):
     """R processes, one GPU, buffers mapped with hipIpcOpenMemHandle, every rank's kernels on its own AQL queue."""
