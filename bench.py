@@ -392,6 +392,12 @@ def main(argv=None):
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d in the environment\n" % (args.gpus, world))
         return 2
 
+    # stdout carries ONE JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's version banner at communicator
+    # creation) are sent to stderr for the whole run; the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
     ndev = torch.cuda.device_count()
     if ndev <= 0:
@@ -604,8 +610,8 @@ def main(argv=None):
             out["configs"] = other_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-        sys.stdout.flush()
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -332,7 +332,8 @@ def test_errors_are_reported_not_thrown():
         eng.get_history(0, 5)
     # exchange policy: a single-GPU sampler only has the dense (no-op) exchange; bad modes are refused
     import ctypes as C
-    assert eng.exchange_stats() == dict(mode="dense", cap=0, chunks=0, replays=0, replay_gens=0)
+    xs = eng.exchange_stats()
+    assert (xs["mode"], xs["cap"], xs["chunks"], xs["replays"], xs["replay_gens"], xs["push_gens"], xs["push_connected"]) == ("dense", 0, 0, 0, 0, 0, False)
     eng.set_exchange(mode="dense")
     with pytest.raises(BpmError, match="dense exchange"):
         eng.set_exchange(mode="replay")
