@@ -44,7 +44,10 @@ struct DqKernel {
 
 class DirectQueue {
   public:
-    static constexpr uint32_t QUEUE_PACKETS = 1024, SLOT_BYTES = 3072, N_SLOTS = QUEUE_PACKETS;
+#ifndef BPM_QUEUE_PACKETS
+#define BPM_QUEUE_PACKETS 1024          // (experiment builds change it: the rocprofv3 --pmc threshold follows it, see inflight_cap())
+#endif
+    static constexpr uint32_t QUEUE_PACKETS = BPM_QUEUE_PACKETS, SLOT_BYTES = 3072, N_SLOTS = QUEUE_PACKETS;
     // SYSTEM: the fences named by ACQUIRE / RELEASE are system scope instead of agent scope (push exchange: rows written into other
     // ranks' memory must have been performed before the completion is announced, and rows peers wrote here must be seen)
     enum : int { ACQUIRE = 1, RELEASE = 2, FENCED = 3, SYSTEM = 4 };
@@ -373,7 +376,11 @@ class DirectQueue {
     // intercepting queue, 5.44 instead of 5.01 us average kernel duration in the trace of the driver's invocation.)
     static constexpr uint32_t batch_cap() { return MAX_UNPUBLISHED; }
     static uint32_t inflight_cap() {
-        // under rocprofv3's counter collection (it exports ROCPROF_COUNTER_COLLECTION=1 to the profiled process) 64 unless told otherwise
+        // under rocprofv3's counter collection (it exports ROCPROF_COUNTER_COLLECTION=1 to the profiled process) 64 unless told otherwise.
+        // Why (profiles/r03_pmc_queue_stall.txt): with a TCC-derived counter (FETCH_SIZE, WRITE_SIZE) the profiler stops completing
+        // dispatches once a queue is several hundred profiled dispatches ahead of it -- no progress in 170 s; with SQ counters nothing
+        // stalls however far ahead the queue runs, with a 1024- or a 4096-packet ring: the threshold does NOT follow QUEUE_PACKETS / EPOCH,
+        // it is the profiler's handling of that counter set.  A HIP stream never gets that far ahead (its launch calls block).
         static const uint32_t v = getenv("BPM_QUEUE_INFLIGHT") ? (uint32_t)std::max(0, atoi(getenv("BPM_QUEUE_INFLIGHT")))
                                   : (getenv("ROCPROF_COUNTER_COLLECTION") && atoi(getenv("ROCPROF_COUNTER_COLLECTION")) != 0 ? 64u : 0u);
         return v;

@@ -6,27 +6,26 @@
 #   cp gpurun_out/prof_<tag>/summary/* profiles/
 # the rocpd databases stay in gpurun_out/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD; O=$R/gpurun_out/prof_$TAG; P=$O/summary; mkdir -p $O $P
 ARGS="--steps 20 --warmup 5"
 for i in 1 2 3; do python bench.py $ARGS 2>/dev/null | tail -1 >> $O/bench_driver.jsonl; done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
 cd /tmp; export TMPDIR=/tmp
 echo "kernel trace" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --preheat 0.1 > $O/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --no-other-configs --preheat 0.1 > $O/kt.log 2>&1
 # The counter passes run on the library's own queue like everything else, throttled to 64 dispatches between two drains
 # (BPM_QUEUE_INFLIGHT): rocprofv3's counter collection serialises every dispatch behind packets of its own and stops forwarding the
 # packets of a queue that has more than a few hundred dispatches outstanding (fine with 256, a drain timeout with 600 or without a
 # limit; a HIP stream never gets that far ahead of the profiler because its launch calls block).  The library applies this bound by itself
-# when ROCPROF_COUNTER_COLLECTION is in its environment; it is spelled out here.  BPM_LAUNCH_PATH=stream BPM_WT_STORES=1
-# is the alternative: same kernels, same stores, launched on the HIP stream.
+# when ROCPROF_COUNTER_COLLECTION is in its environment; it is spelled out here.
 export BPM_QUEUE_INFLIGHT=64 BPM_QUEUE_TIMEOUT_S=30
 echo "pmc FETCH_SIZE" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/f.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/f -o f -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --no-other-configs --preheat 0 > $O/f.log 2>&1
 echo "pmc WRITE_SIZE" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/w.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/w -o w -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --no-other-configs --preheat 0 > $O/w.log 2>&1
 echo "pmc SQ" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0 > $O/sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -d $O/sq -o sq -- python $R/bench.py $ARGS --no-cpu-baseline --no-moments --no-other-configs --preheat 0 > $O/sq.log 2>&1
 unset BPM_QUEUE_INFLIGHT
 echo "summaries" >> $O/progress.txt
 cd $R
