@@ -27,6 +27,7 @@ class BpmConfig(C.Structure):
         ("gamma_scale", C.c_double), ("del_pairs", C.c_int32), ("burnin_gen", C.c_int32),
         ("n_cr_gen", C.c_int32), ("n_cr", C.c_int32),
         ("p_snooker", C.c_double), ("outlier_every", C.c_int32), ("keep_history", C.c_int32),
+        ("running_moments", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 

@@ -330,6 +330,14 @@ struct bpm_sampler {
     int64_t hist_cap = 0;      // rows allocated
     int64_t hist_rows = 0;     // rows stored (0 when keep_history == 0 and nothing stored)
     int64_t rows_logical = 0;  // len(chain.chain) of the reference: 1 + generations since (re)initialisation
+    // running population sums (cfg.running_moments): per history row g the 2 ld doubles [sum_i (x_ij - shift_j) | sum_i (x_ij - shift_j)^2]
+    // over this rank's chains, shift = chain 0's state at the last (re)initialisation.  bpm_reduce_moments answers from them when
+    // the history is not resident: param_est (demc.py:235-248) of 10^5 generations of config 2 without 660 GB of history.
+    double* gen_sums = nullptr;
+    int64_t gen_sums_cap = 0;      // rows allocated
+    double* gs_shift = nullptr;    // [ld]
+    double* gs_part = nullptr;     // per-block partial sums of one row
+    uint32_t gs_nb = 0;
     double* w_mean = nullptr;
     double* w_m2 = nullptr;
     int64_t w_rows = 0;        // history rows folded into the Welford moments
@@ -596,6 +604,49 @@ static int eval_local_ll(bpm_sampler* s) {
     return 0;
 }
 
+// ---- running population sums (cfg.running_moments) -------------------------------------------------------------------------
+static int ensure_gen_sums(bpm_sampler* s, int64_t rows) {
+    if (!s->cfg.running_moments || rows <= s->gen_sums_cap) return 0;
+    const bool was_direct = s->dq_active;
+    CK(leave_direct(s));
+    const int64_t cap = std::max<int64_t>(std::max<int64_t>(rows, 1024), s->gen_sums_cap + s->gen_sums_cap / 2);
+    double* n = nullptr;
+    CK(dev_alloc(&n, (size_t)cap * 2 * s->ld));
+    if (s->gen_sums && s->rows_logical > 0)
+        HIPCK(hipMemcpyAsync(n, s->gen_sums, (size_t)std::min<int64_t>(s->rows_logical, s->gen_sums_cap) * 2 * s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (s->gen_sums) HIPCK(hipFree(s->gen_sums));
+    s->gen_sums = n;
+    s->gen_sums_cap = cap;
+    s->dq_active = was_direct && g_dq != nullptr;
+    return 0;
+}
+// the sums of history row `row` from this rank's block of the state matrix as it stands (two dispatches: per-block partial sums, a
+// fixed-order fold -- the kernels of bpm_reduce_moments, hence the same bits for the same rows)
+static int push_gen_sums(bpm_sampler* s, int64_t row, const double* src = nullptr) {
+    if (!s->cfg.running_moments) return 0;
+    const double* Xl = src ? src : s->G + (uint64_t)s->rank * s->L.blk;
+    double* out = s->gen_sums + (size_t)row * 2 * s->ld;
+    if (g_dq) {
+        struct { const double* H; uint64_t lo, hi; uint32_t ld, _pad; const double* shift; double* part; } pa{Xl, 0, s->n_local, s->ld, 0u, s->gs_shift, s->gs_part};
+        struct { const double* part; uint32_t nb, ld; double* out; } fa{s->gs_part, s->gs_nb, s->ld, out};
+        const bpm::DqKernel* kp = g_dq->kernel(reinterpret_cast<const void*>(moments_partial_kernel));
+        const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(moments_final_kernel));
+        // (reads rows that update kernels wrote, possibly with agent-scope stores behind release-less packets: acquire; writes what only
+        // bpm_reduce_moments reads, behind a drain: plain stores, release left to the drain's fence kernel)
+        if (!kp || !kf || g_dq->launch(*kp, s->gs_nb, 1, MOM_THREADS, &pa, sizeof(pa), bpm::DirectQueue::FENCED) != 0 ||
+            g_dq->launch(*kf, s->ld, 1, MOM_THREADS, &fa, sizeof(fa), bpm::DirectQueue::FENCED) != 0)
+            return fail("direct AQL queue: running-moment kernels: " + g_dq->why());
+        g_dq_need_acquire = true;
+        return 0;
+    }
+    hipLaunchKernelGGL(moments_partial_kernel, dim3(s->gs_nb), dim3(MOM_THREADS), 0, s->stream, Xl, (uint64_t)0, (uint64_t)s->n_local, s->ld,
+                       (const double*)s->gs_shift, s->gs_part);
+    hipLaunchKernelGGL(moments_final_kernel, dim3(s->ld), dim3(MOM_THREADS), 0, s->stream, (const double*)s->gs_part, s->gs_nb, s->ld, out);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
 // after the state matrix was (re)initialised: history := [state], moments reset
 static int reset_history(bpm_sampler* s) {
     CK(eval_local_ll(s));
@@ -611,6 +662,11 @@ static int reset_history(bpm_sampler* s) {
     HIPCK(hipMemcpyAsync(s->w_mean, s->hist, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIPCK(hipMemsetAsync(s->w_m2, 0, row_d * sizeof(double), s->stream));
     s->w_rows = 1;
+    if (s->cfg.running_moments) {      // shift := chain 0's state; sums of row 0
+        HIPCK(hipMemcpyAsync(s->gs_shift, s->G, s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        CK(ensure_gen_sums(s, 1));
+        CK(push_gen_sums(s, 0));
+    }
     s->state_set = true;
     s->phase = 0;
     s->proposed = false;
@@ -664,7 +720,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p)
         if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -829,6 +885,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         for (int m = 0; m < s->cfg.n_cr; ++m) init[m] = 1.0 / s->cfg.n_cr;   // dream.py:114
         HIPCKD(hipMemcpyAsync(s->cr_state, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
         HIPCKD(hipStreamSynchronize(s->stream));
+    }
+    if (s->cfg.running_moments) {
+        s->gs_nb = (uint32_t)std::max<uint32_t>(1u, std::min<uint32_t>(256u, (s->n_local + 63u) / 64u));
+        CKD(dev_alloc(&s->gs_shift, (size_t)s->ld));
+        CKD(dev_alloc(&s->gs_part, (size_t)s->gs_nb * 2 * s->ld));
     }
     CKD(dev_alloc(&s->counters, 8));      // [2] NaN ratios of this run; [4] outlier resets since creation
     CKD(dev_alloc_state(&s->acc_count, s->n_local, s->coherent));
@@ -1152,6 +1213,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         CK(sec.end());
         s->w_rows = s->rows_logical;
     }
+    CK(ensure_gen_sums(s, s->rows_logical + 1));
     double* hist_row = nullptr;
     double* llhist_row = nullptr;
     if (s->cfg.keep_history) {
@@ -1288,6 +1350,7 @@ static int finish_generation(bpm_sampler* s) {
         }
         s->w_rows += 1;
     }
+    if (s->cfg.running_moments) CK(push_gen_sums(s, s->rows_logical));      // (the row this generation appended: index rows_logical)
     if (s->cfg.keep_history) s->hist_rows += 1;
     s->rows_logical += 1;
     s->k_gen += 1;      // demc.py:134
@@ -1436,6 +1499,8 @@ static int group_outlier_check(const Group& g) {
         HIPCK(hipGetLastError());
         if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
     }
+    // (a reset rewrites rows of the generation just appended: its population sums follow)
+    for (int r = 0; r < g.R; ++r) CK(push_gen_sums(g.h[r], g.h[r]->rows_logical - 1));
     // push exchange: nobody starts the next generation (whose accepted rows land in THIS replica) while a reset kernel still writes
     if (s0->push_active) CK(push_barrier(g));
     return 0;
@@ -1726,6 +1791,7 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
         if (!s->local_group || (int)s->world != R || (int)s->rank != r) return fail("bpm_local_group_step: handles are not ranks 0..R-1 of one local group");
         if (!s->run_open) return fail("bpm_local_group_step: call bpm_begin_run on every rank first");
         if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    CK(ensure_gen_sums(s, s->rows_logical + n_gens));
     }
     CK(set_device(handles[0]));
     Group g{handles, R, false};
@@ -1744,6 +1810,7 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    CK(ensure_gen_sums(s, s->rows_logical + n_gens));
     bpm_sampler* one[1] = {s};
     Group g{one, 1, s->comm != nullptr};
     return run_generations(g, n_gens);
@@ -1935,6 +2002,7 @@ extern "C" int bpm_step_timed(bpm_handle_t s, int64_t n_gens, float* elapsed_ms,
     CK(set_device(s));
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_timed: not available for the synchronous DE-MC mode");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    CK(ensure_gen_sums(s, s->rows_logical + n_gens));
     if (elapsed_ms) *elapsed_ms = 0.f;
     if (n_launches) *n_launches = 0;
     s->timed_want_first = n_gens > 0;
@@ -1999,6 +2067,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_profiled: not available for the synchronous DE-MC mode");
     if (n_gens <= 0 || n_gens > 4096) return fail("bpm_step_profiled: 1 <= n_gens <= 4096");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
+    CK(ensure_gen_sums(s, s->rows_logical + n_gens));
     std::vector<hipEvent_t> ev((size_t)n_gens * 4);
     for (auto& e : ev) HIPCK(hipEventCreate(&e));
     PhaseLaunch fn = pick_fused(s);
@@ -2061,6 +2130,10 @@ extern "C" int bpm_set_history(bpm_handle_t s, int64_t rows, const double* hist_
         s->hist_rows = rows;
         s->rows_logical = rows;
         s->w_rows = 0;      // moments are rebuilt from the rows when adaptation next needs them
+        if (s->cfg.running_moments) {      // population sums of every installed row
+            CK(ensure_gen_sums(s, rows));
+            for (int64_t g = 0; g < rows; ++g) CK(push_gen_sums(s, g, s->hist + (uint64_t)g * s->n_local * s->ld));
+        }
         HIPCK(hipStreamSynchronize(s->stream));
     }
     return 0;
@@ -2076,6 +2149,29 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
     CK(set_device(s));
     if (!sum || !sumsq || !shift || !count) return fail("bpm_reduce_moments: null argument");
     if (n_burn < 0) n_burn = 0;
+    if (s->cfg.running_moments && (!s->cfg.keep_history || s->hist_rows != s->rows_logical)) {
+        // no resident history: answer from the per-generation population sums -- exact for a burn-in of whole generations
+        if (n_burn % s->N != 0)
+            return fail("bpm_reduce_moments: without a resident history n_burn must be a multiple of n_chains (whole generations)");
+        const int64_t g0 = std::min<int64_t>(n_burn / s->N, s->rows_logical), g1 = s->rows_logical;
+        std::vector<double> h(3 * (size_t)s->ld, 0.0);
+        HIPCK(hipMemcpyAsync(h.data() + 2 * s->ld, s->gs_shift, s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        *count = (g1 - g0) * (int64_t)s->n_local;
+        if (g1 > g0) {
+            double* out = nullptr;
+            CK(dev_alloc(&out, 2 * (size_t)s->ld));
+            hipLaunchKernelGGL(moments_final_kernel, dim3(s->ld), dim3(MOM_THREADS), 0, s->stream, (const double*)(s->gen_sums + (size_t)g0 * 2 * s->ld),
+                               (uint32_t)(g1 - g0), s->ld, out);
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(h.data(), out, 2 * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            HIPCK(hipStreamSynchronize(s->stream));
+            HIPCK(hipFree(out));
+        } else {
+            HIPCK(hipStreamSynchronize(s->stream));
+        }
+        for (uint32_t j = 0; j < s->dim; ++j) { sum[j] = h[j]; sumsq[j] = h[s->ld + j]; shift[j] = h[2 * s->ld + j]; }
+        return 0;
+    }
     const int64_t g0 = n_burn / s->N;
     int64_t first = n_burn % s->N - (int64_t)s->lo;      // first local chain of generation g0 that counts
     first = std::max<int64_t>(0, std::min<int64_t>(first, s->n_local));

@@ -112,7 +112,9 @@ class DeMcMpi(object):
             target_params=self._target_params, seed=self.seed,
             device=kwargs.get("device", self._default_device()), rank=self.comm.rank, world_size=self.comm.size,
             nccl_uid=uid, p_snooker=kwargs.get("p_snooker", 0.0), outlier_every=kwargs.get("outlier_every", 0),
-            keep_history=kwargs.get("keep_history", True), **self._engine_kwargs(kwargs))
+            keep_history=kwargs.get("keep_history", True),
+            # without a history param_est_moments answers from per-generation population sums (whole-generation burn-ins)
+            running_moments=kwargs.get("running_moments", not kwargs.get("keep_history", True)), **self._engine_kwargs(kwargs))
         self.n_local = self.n_chains // self.comm.size
         self._connect_exchange()
         self._hist_cache = None

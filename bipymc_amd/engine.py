@@ -22,7 +22,7 @@ def _iptr(a):
 class HipEngine(object):
     def __init__(self, algo, n_chains, dim, target_id, target_params, seed, device=0, rank=0, world_size=1,
                  nccl_uid=None, gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
-                 p_snooker=0.0, outlier_every=0, keep_history=True):
+                 p_snooker=0.0, outlier_every=0, keep_history=True, running_moments=False):
         self._h = C.c_void_p()
         self.lib = L.load()
         self.n_chains, self.dim = int(n_chains), int(dim)
@@ -53,6 +53,7 @@ class HipEngine(object):
         cfg.p_snooker = float(p_snooker)
         cfg.outlier_every = int(outlier_every)
         cfg.keep_history = 1 if keep_history else 0
+        cfg.running_moments = 1 if running_moments else 0
         L.check(self.lib.bpm_create(C.byref(cfg), C.byref(self._h)))
         self.algo, self.target_id = int(algo), int(target_id)
         self.n_cr = int(n_cr) if algo == L.ALGO_DREAM else 1

@@ -83,6 +83,10 @@ typedef struct bpm_config {
     double p_snooker;      /* DE-MC only: probability of a snooker update (0 = off) */
     int32_t outlier_every; /* DREAM burn-in: IQR outlier-chain reset every this many generations (0 = off) */
     int32_t keep_history;  /* 1: append every generation (chain.py:51-54); 0: keep current state only */
+    int32_t running_moments; /* 1: keep, per generation, the population sums sum_i x_ij and sum_i x_ij^2 (2 dim doubles): bpm_reduce_moments
+                              * then answers for any burn-in of WHOLE generations without a resident history -- param_est (demc.py:235-248)
+                              * of 10^5 generations of config 2 would otherwise need 660 GB.  Two small dispatches per generation. */
+    int32_t _pad2;
 } bpm_config_t;
 
 /* run_mcmc(**kwargs) (demc.py:73-75,161-162; dream.py:40-41). */
@@ -232,7 +236,8 @@ int bpm_reserve_history(bpm_handle_t h, int64_t total_rows);
 /* param_est (demc.py:235-248) without moving the history: for this rank's rows of the interleaved
  * super chain (row g*N + i = chain i at generation g) with row index >= n_burn, returns count,
  * sum_j (x - shift_j), sum_j (x - shift_j)^2 and shift_j (length dim each; shift is identical on every
- * rank).  mean_j = shift_j + S1/n, var_j = S2/n - (S1/n)^2 after summing S1, S2, n over ranks. */
+ * rank).  mean_j = shift_j + S1/n, var_j = S2/n - (S1/n)^2 after summing S1, S2, n over ranks.  A sampler created with
+ * running_moments and without a resident history answers from its per-generation sums: n_burn must then be a multiple of n_chains. */
 int bpm_reduce_moments(bpm_handle_t h, int64_t n_burn, double* sum, double* sumsq, double* shift, int64_t* count);
 int bpm_get_stats(bpm_handle_t h, bpm_stats_t* out);
 /* checkpoint what the reference forgets: p_cr, delta_m, n_cr_updates, t_abs */

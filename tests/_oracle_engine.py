@@ -9,7 +9,7 @@ from oracle import sampler_ref as R
 class OracleEngine(object):
     def __init__(self, algo, n_chains, dim, target_id, target_params, seed, device=0, rank=0, world_size=1,
                  nccl_uid=None, gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
-                 p_snooker=0.0, outlier_every=0, keep_history=True, ll_fn=None):
+                 p_snooker=0.0, outlier_every=0, keep_history=True, running_moments=False, ll_fn=None):
         self.n_chains, self.dim, self.rank, self.world_size = n_chains, dim, rank, world_size
         self.n_local = n_chains // world_size
         self.lo = rank * self.n_local

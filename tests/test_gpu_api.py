@@ -1009,3 +1009,62 @@ def test_sampler_sequence_in_one_process_keeps_histories_intact():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "coherent_memory_hazard.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "all four histories equal" in out.stdout, out.stdout[-2000:]
+
+
+def test_running_moments_equal_history_moments_without_a_history():
+    """param_est's mean / std (demc.py:242-246) for a burn-in of whole generations from per-generation population sums
+    (bpm_config_t.running_moments): a sampler that keeps NO history must return what the history-based reduction returns, to 1e-12,
+    on a 2000-generation run that passes through burn-in with CR adaptation and the outlier check (whose resets rewrite the last row)."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss, mixture_nd
+    for spec, N, kw in ((d100_gauss.Gauss_100D()._bpm_target_spec(), 256, dict(burnin_gen=100, n_cr_gen=5)),
+                        (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), 512, dict(burnin_gen=300, n_cr_gen=5, outlier_every=50))):
+        tid, tp, d = spec
+        X0 = np.random.RandomState(4).normal(size=(N, d)) + 1.0
+        G = 2000
+        res = {}
+        for label, keep, run in (("hist", True, False), ("sums", False, True), ("both", True, True)):
+            if label == "sums" and "outlier_every" in kw:
+                continue                      # (the outlier check itself needs the log-like history)
+            e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=17, keep_history=keep,
+                          running_moments=run, **kw)
+            e.set_state(X0)
+            e.begin_run()
+            e.step(700)
+            e.step(G - 700)
+            out = {}
+            for n_burn in (0, N * 1, N * 401, N * 1999, N * (G + 1)):
+                cnt, s1, s2, sh = e.reduce_moments(n_burn)
+                out[n_burn] = (cnt, sh + s1 / max(cnt, 1), np.sqrt(np.maximum(s2 / max(cnt, 1) - (s1 / max(cnt, 1)) ** 2, 0.0)))
+            if label == "sums":
+                with pytest.raises(L.BpmError, match="multiple of n_chains"):
+                    e.reduce_moments(N * 3 + 1)
+                assert e.history_rows() <= 1
+            res[label] = (out, e.get_state())
+            e.close()
+        for label in res:
+            assert np.array_equal(res[label][1], res["hist"][1])                  # the same run
+            for n_burn, (cnt, mean, std) in res[label][0].items():
+                c0, m0, s0 = res["hist"][0][n_burn]
+                assert cnt == c0
+                if cnt:
+                    np.testing.assert_allclose(mean, m0, rtol=1e-12, atol=1e-12)
+                    np.testing.assert_allclose(std, s0, rtol=1e-10, atol=1e-12)
+
+
+def test_sampler_class_without_history_still_estimates_parameters():
+    from bipymc_amd import DreamMpi
+    from bipymc_amd.utils import d100_gauss
+    t = d100_gauss.Gauss_100D(rho=0.5, dim=10)
+    a = DreamMpi(t.ln_like, np.zeros(10), n_chains=64, n_cr_gen=3, burnin_gen=10, seed=5)
+    b = DreamMpi(t.ln_like, np.zeros(10), n_chains=64, n_cr_gen=3, burnin_gen=10, seed=5, keep_history=False)
+    a.run_mcmc(64 * 300)
+    b.run_mcmc(64 * 300)
+    ma, sa = a.param_est_moments(64 * 100)
+    mb, sb = b.param_est_moments(64 * 100)
+    mean, std, _ = a.param_est(64 * 100)
+    np.testing.assert_allclose(mb, ma, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(sb, sa, rtol=1e-10)
+    np.testing.assert_allclose(mb, mean, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sb, std, rtol=1e-9)
