@@ -430,6 +430,7 @@ struct Work {
     uint32_t maskbits;
 };
 
+typedef double bpm_d2v __attribute__((ext_vector_type(2)));
 template <int LPC, int DPL>
 __device__ __forceinline__ void load_row(const double* row, int q, uint32_t ld, double* v) {
 #pragma unroll
@@ -467,6 +468,21 @@ __device__ __forceinline__ void store_row_wt(double* row, int q, uint32_t ld, co
     }
 }
 
+// The same through ONE 16-byte store per lane: `global_store_dwordx4 ... sc1` is what the compiler emits for an agent-scope store of
+// up to 8 bytes; HIP has no 16-byte atomic store, hence the instruction by hand (gfx942 / gfx950 cache-policy bits: sc0 sc1 nt).
+template <int LPC, int DPL>
+__device__ __forceinline__ void store_row_wt16(double* row, int q, uint32_t ld, const double* v) {
+#pragma unroll
+    for (int u = 0; u < DPL / 2; ++u) {
+        const uint32_t pi = (uint32_t)(q + u * LPC);
+        if (2 * pi < ld) {
+            bpm_d2v t = {v[2 * u], v[2 * u + 1]};
+            bpm_d2v* p = reinterpret_cast<bpm_d2v*>(row) + pi;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+        }
+    }
+}
+
 // Push exchange: a row into ANOTHER rank's replica (peer device memory over xGMI, or another process's buffer on the same GPU):
 // relaxed system-scope stores -- written through to the memory that owns the line, visible to the peer's next kernel once this
 // kernel's completion has been announced (push_sync_kernel) and that kernel's packet has acquired.
@@ -487,7 +503,6 @@ __device__ __forceinline__ void store_row_sys(double* row, int q, uint32_t ld, c
 // end-of-kernel release writes everything back -- with 3.3 MB of history per launch that flush sat on the critical
 // path between the two half generations: 14.4 vs 15.7 us/generation at cfg2, 72.0 vs 76.2 at N=65536.  (Agent- or
 // system-scope stores measured slower, 16.5; the accepted state rows gain nothing, they are few.)
-typedef double bpm_d2v __attribute__((ext_vector_type(2)));
 template <int LPC, int DPL>
 __device__ __forceinline__ void store_row_stream(double* row, int q, uint32_t ld, const double* v) {
 #pragma unroll
@@ -972,7 +987,10 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         store_row<LPC, DPL>(a.x_next + (uint32_t)(li * ld), q, ld, nv);
         if (accepted && q == 0) a.ll[li] = new_ll;
     } else if (accepted) {
-        if (a.wt) {
+        if (a.wt == 2u) {
+            store_row_wt16<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
+            if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (a.wt) {
             store_row_wt<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
             if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -1027,13 +1045,23 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                 mean[s] = mean[s] + d1 / cntp;
                 m2[s] = m2[s] + d1 * (nv[s] - mean[s]);
             }
-            store_row_stream<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
-            store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+            if (a.wt) {      // release-less packets: the next generation's kernels read these rows
+                store_row_wt16<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
+                store_row_wt16<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+            } else {
+                store_row_stream<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
+                store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+            }
         }
         if (q == 0) {
             const bool gated = a.adapt_on && a.cr_gate;
-            *delta_ptr(a.L, c) = gated ? wk.delta : 0.0;
-            *cridx_ptr(a.L, c) = gated ? (double)wk.cr_idx : -1.0;
+            if (a.wt) {
+                __hip_atomic_store(delta_ptr(a.L, c), gated ? wk.delta : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cridx_ptr(a.L, c), gated ? (double)wk.cr_idx : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *delta_ptr(a.L, c) = gated ? wk.delta : 0.0;
+                *cridx_ptr(a.L, c) = gated ? (double)wk.cr_idx : -1.0;
+            }
         }
     }
     if (a.trace_i32 && q == 0) {

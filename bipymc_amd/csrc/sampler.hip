@@ -43,6 +43,7 @@ using namespace bpm;
 //   planall      plan records whatever the number of chains
 //   nohot        the general kernel instantiation instead of the specialised ones
 //   groupqueues  every rank of a local group on an AQL queue of its own (the ranks' barrier kernels wait for each other across queues)
+//   wt8          rows written through with two 8-byte agent-scope atomic stores per lane (round 2's form) instead of one 16-byte sc1 store
 //   serial       the emulated ranks of a local group take turns on the GPU (tools/emulate_ranks.py)
 //   hosttiming   host nanoseconds spent preparing generations and inside launch calls, printed by bpm_destroy
 // Operational switches (documented in README.md): BPM_DIRECT_QUEUE=0, BPM_QUEUE_INFLIGHT, BPM_QUEUE_TIMEOUT_S, BPM_EXCHANGE, BPM_VERBOSE.
@@ -151,16 +152,14 @@ static thread_local bpm::DirectQueue* g_dq = nullptr;
 static thread_local int g_dq_sig = -1;            // the next update dispatch carries this timing signal (bpm_step_timed)
 static thread_local bool g_dq_error = false;      // a dispatch could not be made: run_generations reports it
 // Fences of an update-kernel packet.  A HIP stream puts agent-scope acquire + release around every kernel; the release (write-back of
-// every XCD's L2 at the end of the kernel) is 0.6 us of a 6 us launch period at cfg2.  In the steady state the update kernel instead
-// sends what the next kernel reads (accepted rows, ln-like, accept counters) through agent-scope stores (PhaseArgs::wt, kernels.h:
-// store_row_wt) and its packet carries the acquire only; history rows (non-temporal stores, read by nobody before the drain) are
-// written back by the fenced empty kernel DirectQueue::drain puts behind such packets.  Burn-in generations (Welford moments, CR
-// slots) and half generations that rewrite more than WT_MAX_BYTES of state keep acquire + release with plain stores.
-// (BPM_DQ_FENCE=full: always; =none only together with the BPM_COHERENT_STATE=1 experiment.  The packet after a table build or after
-// entering direct mode always acquires.)
-static constexpr uint64_t WT_MAX_BYTES = 4ull << 20;       // per generation, write-through stores / release fence, same box: 3.3 MB (cfg2)
-                                                           // 11.2 / 12.5 us, 1 MB (cfg5 / 8) 9.7 / 11.0, 0.5 MB (cfg3) 13.8 / 15.2;
-                                                           // 8.4 MB (cfg5) 59.2 / 58.8; 26 MB (N=65536 x d=100) 73.2 / 70.1
+// every XCD's L2 at the end of the kernel) is 0.6 us of a 6 us launch period at cfg2.  On the library's own queue the update kernel instead
+// sends what later kernels read -- accepted rows, ln-like, accept counters, during CR adaptation the Welford rows and the CR slots --
+// through write-through stores (PhaseArgs::wt, kernels.h: store_row_wt16) and its packet carries the acquire only; history rows
+// (non-temporal stores, read by nobody before the drain) are written back by the fenced empty kernel DirectQueue::drain puts behind
+// such packets.  Round 2 did this in the steady state up to 4 MiB per half generation only (two 8-byte atomic stores per lane cost
+// more than the release beyond that, and in burn-in); with one 16-byte store per lane it wins everywhere (profiles/r03_write_through_16B.txt).
+// bpm_set_launch_path(h, 1, 3): acquire + release on every packet with plain stores.  The packet after a table build or after entering
+// direct mode always acquires.
 static thread_local int g_dq_update_fence = bpm::DirectQueue::FENCED;
 static thread_local bool g_dq_call_last_gen = false;      // run_generations: this is the last generation of the bpm_step call ...
 static thread_local bool g_dq_release_this = false;       // ... whose last update dispatch carries the release: the drain that usually
@@ -1284,7 +1283,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
-        a.wt = g_wt_stores ? 1u : 0u;
+        { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;
@@ -1697,7 +1696,12 @@ static int run_generations(const Group& g, int64_t n_gens) {
             g_dq = direct ? s0->dq : nullptr;
             g_dq_error = false;
             // (half a generation rewrites at most N/2 + 1 rows)
-            const bool plain_stores = adapting || (!s0->coherent && (uint64_t)(s0->N / 2 + 1) * s0->ld * sizeof(double) > WT_MAX_BYTES);
+            // Release-less packets + write-through stores in every generation, burn-in included, at every size: with ONE 16-byte sc1 store
+            // per lane (store_row_wt16) the write-through form beats the end-of-kernel release everywhere it was measured -- round 2's two
+            // 8-byte atomic stores lost above 4 MiB per half generation and in burn-in, hence its size rule and the fenced burn-in
+            // (profiles/r03_write_through_16B.txt: cfg2 burn-in 23.1 -> 21.9 us, cfg5 57.6 -> 55.9, cfg5 burn-in 90 -> 81, N = 65536 x d = 100 70.0 -> 68.7).
+            // BPM_TEST_PATHS=wt8 selects the 8-byte form, bpm_set_launch_path(h, 1, 3) the fenced packets with plain stores.
+            const bool plain_stores = false;
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
             // push exchange: every update packet acquires and releases at SYSTEM scope (rows go to and come from other agents)
             if (push) g_dq_update_fence = bpm::DirectQueue::FENCED | (s0->push_agent_scope ? 0 : (int)bpm::DirectQueue::SYSTEM);
