@@ -169,6 +169,9 @@ struct PhaseArgs {
     // slots -- is stored at the same offset in each of them with system-scope stores; n_peers == 0: no push
     const unsigned long long* peer_tab;
     uint32_t n_peers;
+    uint32_t hist_by_pos;       // 1: the history row and its ln-like are appended at the update's POSITION in this generation's shuffle order
+                                // (work items of a wavefront write consecutive rows) instead of at the chain's index; the host remembers the
+                                // generation, and rows are put back into chain order when anything reads them (sampler.hip: normalize_history)
     uint32_t wt;                // 1: the dispatch packet of this launch carries NO release fence -- what a later kernel reads (accepted state
                                 // rows, ln-like cache, accept counters) leaves through agent-scope (write-through) stores (store_row_wt)
     uint64_t seed;
@@ -423,6 +426,7 @@ struct Work {
     double gamma;
     uint32_t acc_hi, acc_lo;   // words of the accept uniform
     uint32_t item;             // work-item number of this update (index of its accept byte when acc_by_item)
+    uint32_t pos_own;          // its position in this generation's shuffle order (mode 0)
     double ll_cur;             // cached ln_like of the current state, fetched early
     uint32_t acc_prev;         // this chain's accept counter, fetched early
     double w_mean[DPL], w_m2[DPL];   // burn-in only: Welford moments of this chain's own history, fetched early
@@ -561,7 +565,18 @@ __device__ __forceinline__ uint32_t partner_pos(const PhaseArgs& a, uint32_t c, 
 }
 
 __device__ __forceinline__ uint32_t pos_to_chain(const PhaseArgs& a, uint32_t pos) {
+#ifdef BPM_FAKE_NO_PARTNER_HOP      // timing experiment only (wrong results): what the position -> chain id lookup of a partner costs
+    return pos;                     // (profiles/r03_small_d_hops_and_position_order.txt)
+#else
     return a.perm_tab ? a.perm_tab[pos] : perm_fwd(pos, a.pk);
+#endif
+}
+__device__ __forceinline__ uint32_t own_pos_to_chain(const PhaseArgs& a, uint32_t pos) {
+#ifdef BPM_FAKE_NO_OWN_HOP          // timing experiment only (wrong results): the work item's own position -> chain id lookup
+    return pos;
+#else
+    return a.perm_tab ? a.perm_tab[pos] : perm_fwd(pos, a.pk);
+#endif
 }
 __device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c) {
     return a.inv_tab ? a.inv_tab[c] : perm_inv(c, a.pk);
@@ -1030,8 +1045,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
             }
         }
     }
-    if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(li * ld), q, ld, nv);
-    if (a.llhist_row && q == 0) a.llhist_row[li] = new_ll;
+    const uint32_t hi = a.hist_by_pos ? wk.pos_own : li;
+    if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(hi * ld), q, ld, nv);
+    if (a.llhist_row && q == 0) a.llhist_row[hi] = new_ll;
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
@@ -1094,7 +1110,7 @@ __device__ __forceinline__ void pin_args(const PhaseArgs& a) {
 __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, uint32_t& c) {
     bool active = w < a.n_items;
     if (a.mode == 0) {
-        c = pos_to_chain(a, a.upd_off + (active ? w : 0u));
+        c = own_pos_to_chain(a, a.upd_off + (active ? w : 0u));
     } else if (a.mode == 2) {
         c = a.lo + (active ? w : 0u);
     } else {
@@ -1198,6 +1214,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
     wk.item = w;
+    wk.pos_own = a.upd_off + (active ? w : 0u);
 #ifdef BPM_STAMPS
     bpm_stamp[1] = 0; BPM_STAMP(1);
     make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp);
@@ -1348,7 +1365,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
-    wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0; wk.item = w;
+    wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0; wk.item = w; wk.pos_own = 0u;
     // finish_update rewrites the CR slots: carry the values written by the propose kernel
     if (ALGO == ALGO_DREAM && active) {
         wk.delta = *delta_ptr(a.L, c);
@@ -1535,6 +1552,18 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
     const uint32_t g = (uint32_t)(e / N), k = (uint32_t)(e % N);
     tab[e] = perm_fwd(k, keys.k[g]);
     inv[e] = perm_inv(k, keys.k[g]);      // (walking the network backwards costs less than the scattered store inv[g N + c] = k did: 7.5 -> 4.9 us at cfg2)
+}
+
+// A history row appended by POSITION (PhaseArgs::hist_by_pos) back into chain order: dst row c = src row k with c = pi_t(k), the shuffle of
+// the generation that wrote it (recomputed from its key: the tables of that generation are long gone).  One thread per coordinate pair.
+__global__ void hist_unpermute_kernel(const PermKey key, uint32_t N, uint32_t ld, const double* src, const double* llsrc, double* dst, double* lldst) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t np = ld / 2u;
+    if (e >= (uint64_t)N * np) return;
+    const uint32_t k = (uint32_t)(e / np), p = (uint32_t)(e % np);
+    const uint32_t c = perm_fwd(k, key);
+    reinterpret_cast<double2*>(dst + (uint64_t)c * ld)[p] = reinterpret_cast<const double2*>(src + (uint64_t)k * ld)[p];
+    if (p == 0) lldst[c] = llsrc[k];
 }
 
 // Records of K consecutive generations in one launch, one thread per (generation, position in shuffle order):

@@ -327,6 +327,14 @@ struct bpm_sampler {
     double* hist = nullptr;
     double* llhist = nullptr;
     int64_t hist_cap = 0;      // rows allocated
+    // Position-ordered history append (single GPU, fewer than 64 lanes per chain): the update kernels write a generation's history row in
+    // that generation's shuffle order -- consecutive work items, consecutive rows: 1.0 us per generation at cfg3, 5.5 us at cfg5 against
+    // the scattered append by chain index (profiles/r03_small_d_hops_and_position_order.txt) -- and hist_tag[row] remembers how to read it:
+    // -1 chain order, else (generation << 1) | shuffle.  normalize_history puts rows back into chain order, in place, before anything
+    // reads them by chain (bpm_get_history, the moment rebuild, the outlier check, a partial first generation of bpm_reduce_moments).
+    bool hist_by_pos = false;
+    std::vector<int64_t> hist_tag;
+    double* hist_tmp = nullptr;    // one row (n_local * ld) + its ln-likes (n_local): staging of normalize_history
     int64_t hist_rows = 0;     // rows stored (0 when keep_history == 0 and nothing stored)
     int64_t rows_logical = 0;  // len(chain.chain) of the reference: 1 + generations since (re)initialisation
     // running population sums (cfg.running_moments): per history row g the 2 ld doubles [sum_i (x_ij - shift_j) | sum_i (x_ij - shift_j)^2]
@@ -586,6 +594,7 @@ static int ensure_history(bpm_sampler* s, int64_t rows) {
     s->hist = nh;
     s->llhist = nl;
     s->hist_cap = cap;
+    s->hist_tag.resize((size_t)cap, -1);
     s->dq_active = was_direct && g_dq != nullptr;      // (inside a direct-mode generation: the stream is idle again, go on)
     return 0;
 }
@@ -600,6 +609,30 @@ static int eval_local_ll(bpm_sampler* s) {
         default: return 0;  // host callback: caller supplies values via bpm_set_loglike
     }
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+// History rows [r0, r1) into chain order (see bpm_sampler::hist_by_pos).  On the sampler's stream: the caller has drained the library's
+// own queue (check_handle / StreamSection).
+static int normalize_history(bpm_sampler* s, int64_t r0, int64_t r1) {
+    if (!s->hist_by_pos) return 0;
+    r0 = std::max<int64_t>(r0, 0);
+    r1 = std::min<int64_t>(r1, std::min<int64_t>(s->hist_rows, (int64_t)s->hist_tag.size()));
+    const size_t row_d = (size_t)s->n_local * s->ld;
+    const uint64_t n = (uint64_t)s->n_local * (s->ld / 2u);
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t tag = s->hist_tag[(size_t)r];
+        if (tag < 0) continue;
+        const PermKey key = make_perm_key(s->cfg.seed, (uint64_t)(tag >> 1), s->N, (tag & 1) != 0);
+        double* row = s->hist + (uint64_t)r * row_d;
+        double* llrow = s->llhist + (uint64_t)r * s->n_local;
+        hipLaunchKernelGGL(hist_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, key, s->N, s->ld, (const double*)row,
+                           (const double*)llrow, s->hist_tmp, s->hist_tmp + row_d);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(row, s->hist_tmp, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        HIPCK(hipMemcpyAsync(llrow, s->hist_tmp + row_d, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        s->hist_tag[(size_t)r] = -1;
+    }
     return 0;
 }
 
@@ -656,6 +689,7 @@ static int reset_history(bpm_sampler* s) {
     const size_t row_d = (size_t)s->n_local * s->ld;
     HIPCK(hipMemcpyAsync(s->hist, s->G + (uint64_t)s->rank * s->L.blk, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIPCK(hipMemcpyAsync(s->llhist, s->ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (!s->hist_tag.empty()) s->hist_tag[0] = -1;
     s->hist_rows = 1;
     // Welford over the single row: mean = row, m2 = 0
     HIPCK(hipMemcpyAsync(s->w_mean, s->hist, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -719,7 +753,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p)
         if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -885,6 +919,10 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipMemcpyAsync(s->cr_state, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
         HIPCKD(hipStreamSynchronize(s->stream));
     }
+    // position-ordered history append: one wavefront per chain writes whole 128-byte lines whatever the row's place, nothing to gain there
+    s->hist_by_pos = s->world == 1 && s->shape.idx < 3 && cfg->keep_history != 0 && tid != BPM_TARGET_HOST_CALLBACK && cfg->algo != BPM_ALGO_DEMC_SYNC &&
+                     !test_path("histchain");
+    if (s->hist_by_pos) CKD(dev_alloc(&s->hist_tmp, (size_t)s->n_local * (s->ld + 1)));
     if (s->cfg.running_moments) {
         s->gs_nb = (uint32_t)std::max<uint32_t>(1u, std::min<uint32_t>(256u, (s->n_local + 63u) / 64u));
         CKD(dev_alloc(&s->gs_shift, (size_t)s->ld));
@@ -1206,6 +1244,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         const uint64_t n_elem = (uint64_t)s->n_local * s->ld;
         StreamSection sec(s);
         CK(sec.rc);
+        CK(normalize_history(s, 0, s->hist_rows));
         hipLaunchKernelGGL(welford_rebuild_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s->stream,
                            s->hist, n_elem, n_elem, (uint32_t)s->hist_rows, s->w_mean, s->w_m2);
         HIPCK(hipGetLastError());
@@ -1219,6 +1258,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         CK(ensure_history(s, s->hist_rows + 1));
         hist_row = s->hist + (uint64_t)s->hist_rows * s->n_local * s->ld;
         llhist_row = s->llhist + (uint64_t)s->hist_rows * s->n_local;
+        s->hist_tag[(size_t)s->hist_rows] = -1;      // (how the row about to be appended has to be read: decided in finish_generation)
     }
     for (int ph = 0; ph < 2; ++ph) {
         PhaseArgs& a = s->cur_args[ph];
@@ -1283,6 +1323,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
+        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr) ? 1u : 0u;
         { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
@@ -1350,7 +1391,11 @@ static int finish_generation(bpm_sampler* s) {
         s->w_rows += 1;
     }
     if (s->cfg.running_moments) CK(push_gen_sums(s, s->rows_logical));      // (the row this generation appended: index rows_logical)
-    if (s->cfg.keep_history) s->hist_rows += 1;
+    if (s->cfg.keep_history) {
+        if (s->cur_args[0].hist_by_pos || s->cur_args[1].hist_by_pos)      // appended by position: generation t_abs, its shuffle switch
+            s->hist_tag[(size_t)s->hist_rows] = (s->t_abs << 1) | (s->opts.shuffle != 0 ? 1 : 0);
+        s->hist_rows += 1;
+    }
     s->rows_logical += 1;
     s->k_gen += 1;      // demc.py:134
     s->t_abs += 1;
@@ -1448,6 +1493,7 @@ static int group_outlier_check(const Group& g) {
         bpm_sampler* s = g.h[r];
         s->outlier_due = false;
         if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
+        CK(normalize_history(s, 0, s->hist_rows));          // (omega and the repair of the last row go by chain)
         const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
         hipLaunchKernelGGL(outlier_omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->ll, s->n_local, r0, rows,
                            s->om + (size_t)s->rank * 2 * s->n_local);
@@ -2133,6 +2179,7 @@ extern "C" int bpm_set_history(bpm_handle_t s, int64_t rows, const double* hist_
         }
         s->hist_rows = rows;
         s->rows_logical = rows;
+        for (int64_t r = 0; r < rows && r < (int64_t)s->hist_tag.size(); ++r) s->hist_tag[(size_t)r] = -1;
         s->w_rows = 0;      // moments are rebuilt from the rows when adaptation next needs them
         if (s->cfg.running_moments) {      // population sums of every installed row
             CK(ensure_gen_sums(s, rows));
@@ -2179,6 +2226,7 @@ extern "C" int bpm_reduce_moments(bpm_handle_t s, int64_t n_burn, double* sum, d
     const int64_t g0 = n_burn / s->N;
     int64_t first = n_burn % s->N - (int64_t)s->lo;      // first local chain of generation g0 that counts
     first = std::max<int64_t>(0, std::min<int64_t>(first, s->n_local));
+    if (first != 0 && g0 < s->hist_rows) CK(normalize_history(s, g0, g0 + 1));      // a partial first generation is counted by chain index
     const uint64_t m_lo = (uint64_t)std::min<int64_t>(g0, s->hist_rows) * s->n_local + (g0 < s->hist_rows ? (uint64_t)first : 0);
     const uint64_t m_hi = (uint64_t)s->hist_rows * s->n_local;
     std::vector<double> h(3 * (size_t)s->ld, 0.0);
@@ -2354,6 +2402,7 @@ extern "C" int bpm_get_history(bpm_handle_t s, int64_t g_lo, int64_t g_hi, doubl
     if (g_lo < 0 || g_hi < g_lo || g_hi > s->hist_rows) return fail("bpm_get_history: generation range out of bounds");
     if (g_hi == g_lo) return 0;
     if (!out) return fail("bpm_get_history: null argument");
+    CK(normalize_history(s, g_lo, g_hi));
     const size_t rows = (size_t)(g_hi - g_lo) * s->n_local;
     if (rows * s->dim * sizeof(double) >= ((size_t)128 << 20)) {
         HIPCK(hipStreamSynchronize(s->stream));
@@ -2370,6 +2419,7 @@ extern "C" int bpm_get_loglike_history(bpm_handle_t s, int64_t g_lo, int64_t g_h
     CK(set_device(s));
     if (g_lo < 0 || g_hi < g_lo || g_hi > s->hist_rows) return fail("bpm_get_loglike_history: range out of bounds");
     if (g_hi == g_lo) return 0;
+    CK(normalize_history(s, g_lo, g_hi));
     HIPCK(hipMemcpyAsync(out, s->llhist + (uint64_t)g_lo * s->n_local, (size_t)(g_hi - g_lo) * s->n_local * sizeof(double),
                          hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));

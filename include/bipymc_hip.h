@@ -199,26 +199,25 @@ int bpm_push_export(bpm_handle_t h, void* blob);
 int bpm_push_connect(bpm_handle_t h, const void* blobs);
 int bpm_push_selftest(bpm_handle_t* handles, int32_t R, int32_t* ok);
 /* How the generation loop's kernels reach the GPU (no counterpart in the reference: its loop is the Python interpreter,
- * demc.py:79-140).  A single-GPU sampler with a device target dispatches its steady state through the library's own
- * user-mode AQL queue (packets written by the library, bipymc_amd/csrc/aql_queue.h) -- update kernels, table builds, during
- * burn-in the CR reduction kernels; exchanges and every other entry point use the HIP stream.  out[6] = {1 if the sampler has
- * such a queue, update-kernel dispatches of the calling thread through it, update-kernel launches of the calling thread through
- * the HIP stream, 1 if work may be in flight on the queue, 1 if the sampler's state lives in the hardware-coherent memory type
- * (experiment, see below), packet fences of the steady-state update kernels on the queue: 3 acquire + release, 1 acquire only
- * (the default: what the next kernel reads leaves through agent-scope stores), 0 none}.
+ * demc.py:79-140).  A sampler with a device target dispatches its generation loop through the library's own user-mode AQL queue
+ * (packets written by the library, bipymc_amd/csrc/aql_queue.h) -- update kernels, table builds, the CR reduction kernels of burn-in,
+ * with the push exchange also the cross-rank barrier kernels of a rank of a world; RCCL exchanges and every other entry point use the
+ * HIP stream.  out[6] = {1 if the sampler has such a queue, update-kernel dispatches of the calling thread through it, update-kernel
+ * launches of the calling thread through the HIP stream, 1 if work may be in flight on the queue, 0 (was: experimental memory type),
+ * packet fences of the update kernels on the queue: 3 acquire + release, 1 acquire only (the default: what later kernels read leaves
+ * through write-through stores)}.
  * BPM_DIRECT_QUEUE=0 in the environment disables the queue. */
 int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
 /* direct != 0: use the library's own queue where the sampler has one (the default); 0: HIP stream launches only.
- * fence: packet fences of the steady-state update kernels on that queue: -1 keep, 3 agent-scope acquire + release on every
- * packet with plain stores (what a HIP stream does), 1 acquire only with agent-scope stores of what the next kernel reads (the
- * default where the queue exists; burn-in and half generations that rewrite more than 4 MiB keep the release), 0 none; 0 is
- * refused unless the sampler was created in the experimental mode that keeps its state in hardware-coherent memory
- * (BPM_COHERENT_STATE=1 in the environment; not safe).  Results do not depend on the launch path (tested). */
+ * fence: packet fences of the update kernels on that queue: -1 keep, 3 agent-scope acquire + release on every packet with plain
+ * stores (what a HIP stream does), 1 acquire only with write-through stores of what later kernels read (the default where the queue
+ * exists); 0 is refused (fence-less packets belong to an experiment build only).  Results do not depend on the
+ * launch path (tested). */
 int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
-/* Test hook: the probe that decides whether packets may go without a release fence -- 48 dependent dispatches with
- * acquire-only packets hand every block of a 2 MB buffer from workgroup to workgroup (XCD to XCD); *wrong = elements that
- * missed an update, -1 if there is no queue.  coherent_alloc != 0: the memory type of the BPM_COHERENT_STATE=1 experiment; 0:
- * hipMalloc (must FAIL there: plain stores need the release). */
+/* Test hook: why packets may drop the release fence only together with write-through stores -- 48 dependent dispatches with
+ * acquire-only packets and PLAIN stores hand every block of a 2 MB buffer from workgroup to workgroup (XCD to XCD); *wrong = elements
+ * that missed an update (> 0 on hipMalloc memory: the probe must FAIL there), -1 if there is no queue.  coherent_alloc != 0 (the
+ * memory type of round 2's experiment) is an error in the product library. */
 int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc, int64_t* wrong);
 
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.

@@ -73,7 +73,9 @@ if __name__ == "__main__":
         for v in variants:
             env = dict(os.environ)
             env.pop("BPM_TEST_PATHS", None)
-            if v:
+            if v.startswith("lib="):           # an experiment build of the library instead of a test path
+                env["BPM_LIB_PATH"] = os.path.join(ROOT, v[4:])
+            elif v:
                 env["BPM_TEST_PATHS"] = v
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ",".join(names)], env=env, capture_output=True, text=True, timeout=900)
             if out.returncode != 0:
