@@ -1574,6 +1574,8 @@ __global__ void hist_unpermute_kernel(const PermKey key, uint32_t N, uint32_t ld
 struct PlanParams {
     uint64_t seed, t0;
     uint32_t n_gens, N, np, snooker;     // np pairs (<= 5); snooker: also the three snooker partners (DE-MC, pools of >= 3)
+    uint32_t own_lo, own_n;              // own_n > 0 (push exchange, owner-sorted records): only the records of chains [own_lo, own_lo + own_n)
+                                         // are built -- nobody replays another rank's updates, so a rank needs its own run only
 };
 constexpr int PLAN_THREADS = 256;
 __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(const PlanParams P, const uint32_t* tab, uint32_t* plan, const uint32_t* sidx) {
@@ -1592,6 +1594,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(const PlanParams P, 
     const bool first = pos < n_first;
     const uint32_t pool_off = first ? n_first : 0u, M = first ? P.N - n_first : n_first;
     const uint32_t c = tg[pos];
+    if (sidx && P.own_n && (c - P.own_lo) >= P.own_n) return;       // another rank's chain
     uint32_t r[PLAN_WORDS];
 #pragma unroll
     for (int i = 0; i < PLAN_WORDS; ++i) r[i] = 0u;

@@ -74,7 +74,9 @@ static int fail(const std::string& m) {
 // this class of host the core then drops to its base clock and the launch calls that follow take ~4.7 us instead of ~2.4 us
 // for the first few hundred microseconds -- longer than the 6 us the GPU needs per update kernel, so a short bpm_step call
 // issued right after a wait ran HOST-paced (profiles/r02_host_launch_pacing.txt).  A polling wait keeps the core clocked up.
-static int wait_stream(hipStream_t st, double spin_ms = 2000.0) {
+// (50 ms of polling cover the short calls this is for -- a 1000-generation step is 11 ms; longer waits park the thread instead of burning a
+// core per rank: ADVICE r02)
+static int wait_stream(hipStream_t st, double spin_ms = 50.0) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(st);
@@ -374,6 +376,7 @@ struct bpm_sampler {
                                         // `plan` then holds the records in THAT order (rank segment by rank segment inside each group)
         uint32_t* plan_count = nullptr; // device [win_K * 2 * world]: updates of every rank in every half generation
         uint32_t* count_h = nullptr;    // the same in pinned host memory, copied behind the build
+        bool own_only = false;          // its records cover this rank's chains only (built under the push exchange)
         int64_t W = -1;                 // window held (or being built)
         int shuffle = -1;
         hipEvent_t built = nullptr;     // recorded on the build stream behind the window's last kernel / copy
@@ -1164,7 +1167,7 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
         if (B.plan) {
             struct { PlanParams P; const uint32_t* tab; uint32_t* plan; const uint32_t* sidx; } qa{
                 PlanParams{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
-                           (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u},
+                           (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u, 0u, 0u},
                 B.perm, B.plan, B.sidx};
             const bpm::DqKernel* kq = g_dq->kernel(reinterpret_cast<const void*>(plan_kernel));
             if (!kq || g_dq->launch(*kq, (uint32_t)((n + 255) / 256), 1, 256, &qa, sizeof(qa), bpm::DirectQueue::FENCED) != 0) return fail("direct AQL queue: plan_kernel: " + g_dq->why());
@@ -1190,8 +1193,12 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
             HIPCK(hipGetLastError());
             HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * s->world * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
         }
+        // (push exchange: nobody replays another rank's updates -- only this rank's own run of the owner-sorted records is built;
+        // a window remembers it, and a change of the exchange mode rebuilds)
+        const bool own_only = B.sidx != nullptr && s->push_enabled && s->push_connected;
+        B.own_only = own_only;
         PlanParams pp{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
-                      (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u};
+                      (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u, own_only ? s->lo : 0u, own_only ? s->n_local : 0u};
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, pp, B.perm, B.plan, B.sidx);
         HIPCK(hipGetLastError());
     }
@@ -1212,7 +1219,8 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
     const int64_t W = t / K;
     const int b = (int)(W & 1);
     bpm_sampler::TabBuf& B = s->tb[b];
-    if (B.W != W || B.shuffle != shuffle) CK(build_window(s, b, W, shuffle));
+    const bool want_own = B.sidx != nullptr && s->push_enabled && s->push_connected;
+    if (B.W != W || B.shuffle != shuffle || (B.sidx && B.own_only && !want_own)) CK(build_window(s, b, W, shuffle));
     if (B.sidx) HIPCK(hipEventSynchronize(B.built));              // the window's launch sizes (count_h)
     s->cur = b;
     s->perm_tab = B.perm; s->inv_tab = B.inv; s->plan_tab = B.plan; s->plan_count_h = B.count_h;
@@ -1220,7 +1228,7 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
     s->tab_K = K;
     s->tab_shuffle = shuffle;
     bpm_sampler::TabBuf& Bn = s->tb[b ^ 1];
-    if (Bn.W != W + 1 || Bn.shuffle != shuffle) CK(build_window(s, b ^ 1, W + 1, shuffle));
+    if (Bn.W != W + 1 || Bn.shuffle != shuffle || (Bn.sidx && Bn.own_only && !want_own)) CK(build_window(s, b ^ 1, W + 1, shuffle));
     return 0;
 }
 
@@ -1750,8 +1758,10 @@ static int run_generations(const Group& g, int64_t n_gens) {
             const bool plain_stores = false;
             g_dq_update_fence = plain_stores ? (int)bpm::DirectQueue::FENCED : s0->dq_fence;
             // push exchange: every update packet acquires and releases at SYSTEM scope (rows go to and come from other agents)
-            if (push) g_dq_update_fence = bpm::DirectQueue::FENCED | (s0->push_agent_scope ? 0 : (int)bpm::DirectQueue::SYSTEM);
-            g_wt_stores = !push && !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
+            // push exchange: system scope -- every update packet acquires and releases at SYSTEM scope, plain stores into the own replica (rows
+            // go to and come from other agents); agent scope -- the single-GPU form: acquire only, write-through stores into the own replica
+            if (push && !s0->push_agent_scope) g_dq_update_fence = bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM;
+            g_wt_stores = !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
             g_dq_call_last_gen = direct && done == n_gens - 1;
             if (push && !push_entered) {
                 // entry barrier of the call: a peer's first update kernel may push into THIS replica only after this rank has finished
@@ -1875,6 +1885,7 @@ extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     if (mode == 3 && !s->push_connected) return fail("bpm_set_exchange: the push exchange needs bpm_push_connect first");
     if (mode != 3 && s->push_no_rccl) return fail("bpm_set_exchange: this sampler was created without an RCCL communicator: the push exchange is its only one");
     if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
+    if (s->push_enabled && mode != 3) s->cur = -1;      // (windows built with this rank's records only are rebuilt: ensure_perm_table)
     s->push_enabled = mode == 3;
     if (mode == 3) s->push_agent_scope = (cap & 1) != 0;
     s->sparse_enabled = mode == 1;
