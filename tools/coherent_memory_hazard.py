@@ -5,9 +5,10 @@ Warm-up: samplers of four shapes, each run through the library's own queue and t
 destroyed.  Then four repetitions (own queue, HIP stream, own queue, HIP stream) of a short run whose history grows through several
 buffers and whose row 1 is written twice (bpm_set_state in the middle of the run).  The four histories must be equal.
 
-With BPM_COHERENT_STATE=1 (state in the GPU's hardware-coherent memory type, the experimental mode of DESIGN.md section 5) they
-are not: 4-5 runs of 6 show the first repetition with ~20 % of row 1 still holding its FIRST version, now and then a repetition
-with every row different -- with acquire-only and with acquire + release packets alike.  Exit status 1 then."""
+With the state in the GPU's hardware-coherent memory type (round 2's experiment; since round 3 only in the experiment build
+`make -C bipymc_amd/csrc variant NAME=coherent DEFS=-DBPM_EXPERIMENT_COHERENT`, run with BPM_LIB_PATH=build_variants/libbipymc_coherent.so
+BPM_COHERENT_STATE=1) they are not: 4-5 runs of 6 show the first repetition with ~20 % of row 1 still holding its FIRST version, now and then
+a repetition with every row different -- with acquire-only and with acquire + release packets alike.  Exit status 1 then."""
 import os
 import sys
 
