@@ -44,6 +44,7 @@ using namespace bpm;
 //   nohot        the general kernel instantiation instead of the specialised ones
 //   groupqueues  every rank of a local group on an AQL queue of its own (the ranks' barrier kernels wait for each other across queues)
 //   wt8          rows written through with two 8-byte agent-scope atomic stores per lane (round 2's form) instead of one 16-byte sc1 store
+//   ctrlarena    the push exchange's control block inside the coarse-grained arena instead of a fine-grained allocation of its own
 //   serial       the emulated ranks of a local group take turns on the GPU (tools/emulate_ranks.py)
 //   hosttiming   host nanoseconds spent preparing generations and inside launch calls, printed by bpm_destroy
 // Operational switches (documented in README.md): BPM_DIRECT_QUEUE=0, BPM_QUEUE_INFLIGHT, BPM_QUEUE_TIMEOUT_S, BPM_EXCHANGE, BPM_VERBOSE.
@@ -405,6 +406,10 @@ struct bpm_sampler {
     void* arena = nullptr;
     size_t arena_bytes = 0, off_om = 0, off_ctrl = 0;
     PushCtrl* ctrl = nullptr;
+    bool ctrl_fine = false;                 // the control block is a FINE-GRAINED allocation of its own (what a flag polled inside a kernel while
+                                            // another agent writes it should live in; inside the coarse-grained arena otherwise)
+    void* peer_ctrl_base[MAX_SEG] = {};     // the peers' fine-grained control blocks as this process addresses them
+    bool peer_ctrl_opened[MAX_SEG] = {};
     bool push_connected = false, push_enabled = false, push_no_rccl = false;
     bool push_agent_scope = false;          // update packets fence at agent scope instead of system scope (bpm_set_exchange(h, 3, 1))
     void* peer_base[MAX_SEG] = {};          // every rank's arena as THIS process addresses it (own entry: arena)
@@ -753,8 +758,11 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     const bool free_buffers = bpm_debug_destroy_plan(queue_failed ? 1 : 0, quiet ? 1 : 0) == 1;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
-    for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p)
+    for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p) {
         if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
+        if (s->peer_ctrl_opened[p] && s->peer_ctrl_base[p]) (void)hipIpcCloseMemHandle(s->peer_ctrl_base[p]);
+    }
+    if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
     void* ptrs[] = {s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
@@ -897,6 +905,20 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         s->G = reinterpret_cast<double*>(s->arena);
         if (want_om) s->om = reinterpret_cast<double*>(reinterpret_cast<char*>(s->arena) + s->off_om);
         s->ctrl = reinterpret_cast<PushCtrl*>(reinterpret_cast<char*>(s->arena) + s->off_ctrl);
+        {   // The flags are polled INSIDE a kernel while other agents write them: the memory model promises coherence across agents for
+            // fine-grained memory only (coarse-grained: at kernel boundaries).  So the control block gets a fine-grained allocation of its own
+            // when the runtime gives one that can be exported; else it stays in the arena (ranks sharing one GPU do not need more).
+            void* fg = nullptr;
+            hipIpcMemHandle_t probe;
+            if (!test_path("ctrlarena") && hipExtMallocWithFlags(&fg, up(sizeof(PushCtrl)), hipDeviceMallocFinegrained) == hipSuccess && fg &&
+                hipMemset(fg, 0, up(sizeof(PushCtrl))) == hipSuccess && hipIpcGetMemHandle(&probe, fg) == hipSuccess) {
+                s->ctrl = reinterpret_cast<PushCtrl*>(fg);
+                s->ctrl_fine = true;
+            } else {
+                (void)hipGetLastError();
+                if (fg) (void)hipFree(fg);
+            }
+        }
         CKD(dev_alloc(&s->tab_peerG, (size_t)MAX_PEERS));
         CKD(dev_alloc(&s->tab_all, (size_t)3 * MAX_SEG));
         HIPCKD(hipMemsetAsync(s->tab_peerG, 0, MAX_PEERS * sizeof(unsigned long long), s->stream));
@@ -1905,7 +1927,7 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     out[3] = s->n_sparse_replays;
     out[4] = s->n_replay_gens;
     out[5] = s->n_push_gens;
-    out[6] = s->push_connected ? 1 : 0;
+    out[6] = s->push_connected ? (s->ctrl_fine ? 2 : 1) : 0;
     out[7] = (int64_t)s->push_seq | (s->push_agent_scope ? (1ll << 62) : 0);
     return 0;
 }
@@ -1919,6 +1941,8 @@ struct PushBlob {
     int32_t rank, world, device, has_ipc;
     uint64_t arena_addr, arena_bytes, off_om, off_ctrl, n_chains, dim;
     hipIpcMemHandle_t handle;
+    uint64_t ctrl_addr;            // != 0: the control block is an allocation of its own (fine-grained), exported by ctrl_handle
+    hipIpcMemHandle_t ctrl_handle;
 };
 static_assert(sizeof(PushBlob) <= BPM_PUSH_BLOB_BYTES, "blob size");
 static constexpr uint64_t PUSH_MAGIC = 0x4850555350504D42ull;      // "BPMPUSPH"
@@ -1935,6 +1959,10 @@ extern "C" int bpm_push_export(bpm_handle_t s, void* blob) {
     b.n_chains = s->N; b.dim = s->dim;
     if (hipIpcGetMemHandle(&b.handle, s->arena) == hipSuccess) b.has_ipc = 1;
     else { (void)hipGetLastError(); b.has_ipc = 0; }      // (ranks of ONE process need no handle; another process will be told)
+    if (s->ctrl_fine) {
+        b.ctrl_addr = (uint64_t)(uintptr_t)s->ctrl;
+        if (hipIpcGetMemHandle(&b.ctrl_handle, s->ctrl) != hipSuccess) { (void)hipGetLastError(); b.has_ipc = 0; }
+    }
     std::memset(blob, 0, BPM_PUSH_BLOB_BYTES);
     std::memcpy(blob, &b, sizeof(b));
     return 0;
@@ -1974,7 +2002,20 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
         }
         s->peer_base[p] = base;
         const unsigned long long a = (unsigned long long)(uintptr_t)base;
-        all[p] = a; all[MAX_SEG + p] = a + s->off_ctrl; all[2 * MAX_SEG + p] = a + s->off_om;
+        unsigned long long ctrl_a = a + s->off_ctrl;
+        if (b.ctrl_addr != 0) {                              // the peer keeps its control block in a fine-grained allocation of its own
+            void* cb = nullptr;
+            if (p == s->rank) cb = s->ctrl;
+            else if (b.pid == (int64_t)getpid()) cb = reinterpret_cast<void*>((uintptr_t)b.ctrl_addr);
+            else {
+                const hipError_t e = hipIpcOpenMemHandle(&cb, b.ctrl_handle, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) { (void)hipGetLastError(); return fail(std::string("bpm_push_connect: hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s control block failed: " + hipGetErrorString(e)); }
+                s->peer_ctrl_opened[p] = true;
+            }
+            s->peer_ctrl_base[p] = cb;
+            ctrl_a = (unsigned long long)(uintptr_t)cb;
+        }
+        all[p] = a; all[MAX_SEG + p] = ctrl_a; all[2 * MAX_SEG + p] = a + s->off_om;
         if (p != s->rank) others[n_others++] = a;
     }
     for (uint32_t i = n_others; i < (uint32_t)MAX_PEERS; ++i) others[i] = others[0];

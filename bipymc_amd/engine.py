@@ -191,7 +191,7 @@ class HipEngine(object):
         out = (C.c_int64 * 8)()
         L.check(self.lib.bpm_get_exchange_stats(self._h, out))
         return dict(mode=["dense", "rows", "replay", "push"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
-                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), barriers=int(out[7]) & ((1 << 62) - 1),
+                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), push_flags_fine_grained=int(out[6]) == 2, barriers=int(out[7]) & ((1 << 62) - 1),
                     push_fence_scope="agent" if int(out[7]) >> 62 & 1 else "system")
 
     # ---- push exchange (world_size > 1): map the ranks' buffers into each other ------------------------------------------

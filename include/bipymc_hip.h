@@ -174,7 +174,8 @@ int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
  * count seen.  mode 0: the dense all-gather of whole blocks.  The same values on every rank. */
 int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
 /* out[8] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
- *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected,
+ *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected (2: with the
+ *           control block in fine-grained memory of its own),
  *           barriers so far | bit 62 when the push exchange fences at agent scope} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 /* mode 3, "push" (the default once connected): where the reference's ranks meet in MPI_Allgather twice per generation
