@@ -517,7 +517,8 @@ def main(argv=None):
     k_avg_ms = ev_ms / max(n_launch, 1)
     units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
     achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-    pair_ms, pair_n = eng.step_profiled(32)                       # cross-check: an event pair around every launch
+    # cross-check at N = 1: an event pair around every launch (bpm_step_profiled exchanges with the dense all-gather: not part of an N > 1 run)
+    pair_ms, pair_n = eng.step_profiled(32) if world == 1 and not use_dist else (0.0, 1)
     fence()
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # HBM bytes per launch from rocprofv3 --pmc (offline)
@@ -599,7 +600,7 @@ def main(argv=None):
                          "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, %d> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation%s)" % ((5, " of the sharded launch mode") if world > 1 else (1, "")),
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
-                         "launches_timed": n_launch, "avg_launch_us_event_pairs": pair_ms / pair_n * 1e3,
+                         "launches_timed": n_launch, "avg_launch_us_event_pairs": (pair_ms / pair_n * 1e3) if pair_ms > 0 else None,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs},
             "posterior": extra,
         }

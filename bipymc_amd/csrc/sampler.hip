@@ -2168,6 +2168,8 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     if (s->cfg.target_id == BPM_TARGET_HOST_CALLBACK) return fail("bpm_step_profiled: device targets only");
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) return fail("bpm_step_profiled: not available for the synchronous DE-MC mode");
     if (n_gens <= 0 || n_gens > 4096) return fail("bpm_step_profiled: 1 <= n_gens <= 4096");
+    // (this entry point exchanges with the dense RCCL all-gather; a world without a communicator has no exchange here)
+    if (s->world > 1 && !s->comm) return fail("bpm_step_profiled: not available for a rank of a world without an RCCL communicator (push exchange only): use bpm_step_timed");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
     CK(ensure_gen_sums(s, s->rows_logical + n_gens));
     std::vector<hipEvent_t> ev((size_t)n_gens * 4);
