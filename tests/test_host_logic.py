@@ -314,3 +314,74 @@ def test_default_device_enters_its_collective_before_it_raises(monkeypatch):
     s.comm = Comm(1, [("box", 0, 2, None)])
     with pytest.raises(RuntimeError, match="same GPU"):
         D.DeMcMpi._default_device(s)
+
+
+def test_exchange_is_chosen_collectively(monkeypatch):
+    """DeMcMpi._connect_exchange (world > 1): the push exchange is used only when EVERY rank exported, mapped its peers and passed the
+    self-test; one failing rank sends all ranks to the RCCL replay exchange (exchange="auto") or raises on all of them (exchange="push").
+    The reference has no counterpart: its ranks meet in comm.Allgather (demc.py:93-94,116-117)."""
+    import warnings
+    import bipymc_amd.demc as D
+
+    class Eng(object):
+        def __init__(self, fail_at=None):
+            self.fail_at, self.calls, self.mode = fail_at, [], None
+
+        def push_export(self):
+            self.calls.append("export")
+            if self.fail_at == "export":
+                raise RuntimeError("no arena")
+            return b"x" * 256
+
+        def push_connect(self, blobs):
+            self.calls.append("connect")
+            assert len(blobs) == 2
+            if self.fail_at == "connect":
+                raise RuntimeError("hipIpcOpenMemHandle failed")
+
+        def push_selftest(self):
+            self.calls.append("selftest")
+            return self.fail_at != "selftest"
+
+        def set_exchange(self, mode, cap=0):
+            self.mode = mode
+
+    class Comm(object):
+        """this process is rank 0 of 2; `other` scripts what rank 1 contributes to each collective, in order"""
+        rank, size = 0, 2
+
+        def __init__(self, other):
+            self.other = list(other)
+
+        def allgather(self, obj):
+            return [obj, self.other.pop(0)]
+
+        def Barrier(self):
+            pass
+
+    def run(eng, other, exchange="auto"):
+        s = object.__new__(D.DeMcMpi)
+        s._engine, s.comm, s.exchange, s._target_id = eng, Comm(other), exchange, 1      # (a device target)
+        s._connect_exchange()
+        return s
+
+    good = [(b"y" * 256, None), (True, None), True]
+    s = run(Eng(), good)
+    assert s.exchange_used == "push" and s._engine.mode == "push" and s._engine.calls == ["export", "connect", "selftest"]
+    # the OTHER rank could not map this one: nobody runs the self-test, everybody takes the fallback
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = run(Eng(), [(b"y" * 256, None), (False, "connect: hipIpcOpenMemHandle failed")])
+    assert s.exchange_used == "replay" and s._engine.mode == "replay" and "selftest" not in s._engine.calls
+    assert any("rank 1: connect" in str(x.message) for x in w)
+    # this rank's self-test fails, the other's passes: fallback too
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        s = run(Eng(fail_at="selftest"), good)
+    assert s.exchange_used == "replay"
+    # exchange="push" (no RCCL to fall back to): an error on every rank
+    with pytest.raises(RuntimeError, match="push exchange could not be connected"):
+        run(Eng(fail_at="export"), [(None, "export: no arena"), (False, None)], exchange="push")
+    # an RCCL exchange asked for by name: no mapping at all
+    s = run(Eng(), [], exchange="dense")
+    assert s.exchange_used == "dense" and s._engine.calls == []
