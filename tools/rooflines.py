@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""Per-configuration `roofline` objects from the committed rocprofv3 summaries (profiles/r02_*): the same fields bench.py prints for
+"""Per-configuration `roofline` objects from the committed rocprofv3 summaries (profiles/<tag>_*): the same fields bench.py prints for
 config 2, for the kernels of configs 3 and 5 and the burn-in variants.  achieved = algorithmic bytes per launch (SURVEY 8(d):
 bytes per chain-update x updates per launch) / average kernel duration of the kernel trace; traffic = memory-side bytes per launch
-from the --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, or TCC_EA0 read requests x 128 B + write requests).
+from the --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, both in KB).
 
-    python tools/rooflines.py > profiles/r02_rooflines.json
+    python tools/rooflines.py r03 > profiles/r03_rooflines.json
 """
 import csv
 import json
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def kernel_avg_us(csv_name, needle):
@@ -24,37 +26,42 @@ def kernel_avg_us(csv_name, needle):
     raise KeyError((csv_name, needle))
 
 
-def pmc(txt_name, counter, section=None):
+def pmc(txt_name, counter):
     t = open(os.path.join(P, txt_name)).read()
-    if section:
-        t = t.split("== " + section)[1].split("== ")[0]
     m = re.search(counter + r" per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t)
     return float(m.group(1))
 
 
-def entry(config, kernel, csv_name, needle, bytes_per_unit, units, traffic, note):
+def traffic(txt_name):
+    try:
+        return (2 * pmc(txt_name, "FETCH_SIZE") + pmc(txt_name, "WRITE_SIZE")) * 1024.0
+    except (OSError, AttributeError):
+        return None
+
+
+def entry(config, kernel, csv_name, needle, bytes_per_unit, units, tr, note):
     us, calls = kernel_avg_us(csv_name, needle)
     ach = units * bytes_per_unit / (us * 1e-6) / 1e9
     return {"config": config, "kernel": kernel, "bound": "hbm", "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
             "avg_launch_us": us, "launches": calls, "achieved": ach, "peak": PEAK, "unit": "GB/s", "frac": ach / PEAK,
-            "traffic": traffic, "traffic_frac_of_peak": (traffic / (us * 1e-6) / 1e9 / PEAK) if traffic else None,
+            "traffic": tr, "traffic_over_algorithmic": (tr / (units * bytes_per_unit)) if tr else None,
+            "traffic_frac_of_peak": (tr / (us * 1e-6) / 1e9 / PEAK) if tr else None,
             "source": "profiles/" + csv_name, "note": note}
 
 
-out = []
-out.append(entry("cfg2 DREAM d=100 N=8192 steady", "phase_fused_kernel<1,1,64,2,3,1>", "r02_kernel_stats_bench_driver.csv", "64, 2, 3, 1>", 7216, 4096,
-                 (2 * pmc("r02_pmc_bench_driver.txt", "FETCH_SIZE") + pmc("r02_pmc_bench_driver.txt", "WRITE_SIZE")) * 1024,
-                 "kernel-trace duration; bench.py reports the back-to-back launch period (6.0-6.2 us -> 0.60)"))
-out.append(entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", "r02_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
-                 "Welford moments r/w add 32 d bytes per update; + cr_partial_kernel 2.9 us + cr_final_kernel 3.0 us per generation"))
-out.append(entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", "r02_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
-                 pmc("r02_pmc_tcc_cfg5_cfg3_cfg2.txt", "TCC_EA0_RDREQ_sum", "cfg3") * 128 + 6320 * 64 + (83616 - 6320) * 32,
-                 "latency bound: launch floor + three dependent Infinity-Cache round trips (r02_hop_floor_micro.txt); a 16-byte row is an eighth of a 128-byte line"))
-out.append(entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1,2,4,2,3,2>", "r02_kernel_stats_cfg5.csv", "<1, 2, 4, 2, 3, 2>", 592, 131072,
-                 pmc("r02_pmc_tcc_cfg5_cfg3_cfg2.txt", "TCC_EA0_RDREQ_sum", "cfg5") * 128 + 155370 * 64 + (545024 - 155370) * 32,
-                 "bandwidth bound on 128-byte line traffic: a 64-byte row is half a line, 7 of 8 rows per update are random"))
-out.append(entry("cfg5 one GPU's share N=32768 steady", "phase_fused_kernel<1,2,4,2,3,2>", "r02_kernel_stats_cfg5_local.csv", "<1, 2, 4, 2, 3, 2>", 592, 16384, None,
-                 "latency bound (1024 wavefronts)"))
-out.append(entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", "r02_kernel_stats_cfg5_burnin_outlier.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
-                 "+ cr_partial_kernel (ticket form) 11 us per generation, outlier check 0.44 ms per 50 generations"))
+T = TAG
+out = [
+    entry("cfg2 DREAM d=100 N=8192 steady", "phase_fused_kernel<1,1,64,2,3,1>", T + "_kernel_stats_bench_driver.csv", "64, 2, 3, 1>", 7216, 4096,
+          traffic(T + "_pmc_bench_driver.txt"), "kernel-trace duration of the driver's invocation; bench.py reports the back-to-back launch period"),
+    entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", T + "_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
+          "Welford moments r/w add 32 d bytes per update; + cr_partial_kernel + cr_final_kernel per generation"),
+    entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", T + "_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
+          traffic(T + "_pmc_cfg3.txt"), "latency bound: launch floor + dependent Infinity-Cache round trips; a 16-byte row is an eighth of a 128-byte line"),
+    entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5.csv", "<1, 2, 4, 2, 3, 2>", 592, 131072,
+          traffic(T + "_pmc_cfg5.txt"), "bandwidth bound on 128-byte line traffic: a 64-byte row is half a line, 7 of 8 rows per update are random"),
+    entry("cfg5 one GPU's share N=32768 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5_local.csv", "<1, 2, 4, 2, 3, 2>", 592, 16384, None,
+          "latency bound (1024 wavefronts)"),
+    entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", T + "_kernel_stats_cfg5_burnin.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
+          "+ cr_partial_kernel (ticket form) per generation, outlier check every 50 generations"),
+]
 print(json.dumps(out, indent=1))
