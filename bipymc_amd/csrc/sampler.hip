@@ -1353,7 +1353,11 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
-        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr) ? 1u : 0u;
+        // (while the outlier check is due every few generations -- DREAM burn-in with outlier_every > 0 -- rows are appended by chain: the check
+        // reads the ln-like history by chain and repairs the last row, and de-permuting every row it has not seen yet cost more than the
+        // coalesced append gains: cfg5 burn-in with the check 104 us per generation instead of 82)
+        const bool outlier_phase = dream && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen;
+        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr && !outlier_phase) ? 1u : 0u;
         { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
