@@ -733,7 +733,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     uint32_t snk_id[3] = {0u, 0u, 0u};
     if (SNK_DIRECT && snk_possible && planned) {
         snk_id[0] = rec[5 + 2 * P]; snk_id[1] = rec[6 + 2 * P]; snk_id[2] = rec[7 + 2 * P];
-    } else if (SNK_DIRECT && snk_possible) {               // three distinct snooker partners, one Philox block
+    } else if (SNK_DIRECT && snk_possible && (u_sel < a.p_snooker || a.trace_i32 != nullptr)) {
+        // three distinct snooker partners, one Philox block -- only for the lanes whose update IS a snooker update (one in ten at the
+        // BASELINE setting): the three table lookups per lane are scattered 4-byte loads (the trace records them for every chain)
         const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
         uint32_t iz, i1, i2;
         distinct_three(ws.x, ws.y, ws.z, a.M, iz, i1, i2);
