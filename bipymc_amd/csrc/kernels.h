@@ -1506,6 +1506,9 @@ __global__ __launch_bounds__(WAVE) void push_sync_kernel(PushCtrl* mine, const u
         __hip_atomic_store(&pc->flag[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (do_wait) {
+        // (a wait of this rank has already run into its limit: the replicas are inconsistent and the host will be told; do not sit out the
+        // limit again at every later barrier)
+        if (__hip_atomic_load(&mine->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) return;
         const unsigned long long t0 = wall_clock64();
         // relaxed polls (an acquire load is a load + an invalidate of the caches, in a loop, under the other ranks' running kernels: measured
         // 10 us per hand-over at 2 ranks, 118 us at 8 on one GPU); the acquire is the next packet's fence

@@ -126,3 +126,41 @@ if rank == 0:
     assert str(b["used"]) == "push"
     assert np.array_equal(a["chain"], b["chain"]) and np.array_equal(a["p_cr"], b["p_cr"]) and int(a["acc"]) == int(b["acc"])
     np.testing.assert_allclose(a["mm"], b["mm"], rtol=1e-12, atol=1e-14)
+
+
+def test_a_rank_that_waits_for_a_missing_peer_gives_up_and_says_so():
+    """Every cross-rank wait inside push_sync_kernel is bounded (BPM_PUSH_TIMEOUT_S): a rank whose peer never arrives must come back with an
+    error at the next bpm_synchronize, not hang (the reference's ranks WOULD hang in comm.Allgather, demc.py:93-94).  Two ranks of a local
+    group with queues of their own, only rank 0 is ever stepped; bound 2 s.  In a child process (BPM_TEST_PATHS is read at library load)."""
+    code = r'''
+import os, sys, time, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+from bipymc_amd.utils import d100_gauss
+tid, tp, d = d100_gauss.Gauss_100D(dim=6)._bpm_target_spec()
+uid = b"BPMLOCAL" + bytes(120)
+ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid, burnin_gen=0)
+         for r in range(2)]
+blobs = [e.push_export() for e in ranks]
+for e in ranks:
+    e.push_connect(blobs)
+    e.set_state(np.random.RandomState(0).normal(size=(64, d)))
+    e.begin_run()
+t0 = time.time()
+ranks[0].step(3)                       # rank 1 never steps: rank 0's entry barrier waits for it
+try:
+    ranks[0].synchronize()
+    print("NOERROR")
+except L.BpmError as err:
+    print("ERROR after %.1f s: %s" % (time.time() - t0, err))
+'''
+    env = dict(os.environ)
+    env["BPM_TEST_PATHS"] = "groupqueues"
+    env["BPM_PUSH_TIMEOUT_S"] = "2"
+    env["BPM_QUEUE_TIMEOUT_S"] = "60"
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(HERE, ".."), env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith(("ERROR", "NOERROR"))][0]
+    assert line.startswith("ERROR after") and "waited longer than the limit for rank 1" in line, line
+    assert float(line.split()[2]) < 60.0
