@@ -85,3 +85,35 @@ def test_cfg5_share_on_the_shipped_path_equals_the_oracle():
     X0 = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
     _run_both(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, mp, 3, X0, 10,
               dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1), hist_rows=(2, 10))
+
+
+@pytest.mark.parametrize("algo,N,d,shuffle,flip", [("demc", 77, 2, True, 0.5), ("demc", 10, 1, True, 0.3), ("demc", 129, 3, False, 1.0),
+                                                    ("dream", 101, 8, True, 0.5), ("dream", 64, 5, False, 0.0), ("dream", 33, 17, True, 0.7),
+                                                    ("dream", 12, 32, True, 0.5)])
+def test_histories_appended_in_shuffle_order_come_back_in_chain_order(algo, N, d, shuffle, flip):
+    """Fewer than 64 lanes per chain: the update kernels append a generation's history row (and its ln-likes) in that generation's shuffle
+    order and bpm_get_history de-permutes it (sampler.hip: normalize_history).  Whole histories against the oracle's (chain.py:51-54:
+    one row per generation, chain i at column block i) for odd and even populations, padded rows (odd d), shuffle off, every flip -- read
+    in two pieces and out of order, then the run goes on and the rest is read."""
+    from bipymc_amd.engine import HipEngine
+    A = R.ALGO_DEMC if algo == "demc" else R.ALGO_DREAM
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0)) if d > 1 else R.gauss_equicorr_params(0.0, np.ones(1))
+    kw = dict(p_snooker=0.2) if algo == "demc" else dict(del_pairs=2, n_cr=3, burnin_gen=5, n_cr_gen=2)
+    eng = HipEngine(algo=A, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=9, **kw)
+    ora = R.OracleSampler(A, N, d, R.TARGET_GAUSS_EQUICORR, params, 9, **kw)
+    X0 = np.random.RandomState(2).normal(size=(N, d))
+    eng.set_state(X0)
+    ora.set_state(X0)
+    eng.begin_run(flip=flip, shuffle=shuffle)
+    eng.step(9)
+    tail = eng.get_history(6, 10)                         # rows 6..9 first ...
+    head = eng.get_history(0, 6)                          # ... then the older ones
+    eng.step(4)
+    rest = eng.get_history(10, 14)
+    llh = eng.get_loglike_history(0, 14)
+    ora.run(13, flip=flip, shuffle=shuffle)
+    H = np.concatenate([head, tail, rest], axis=0)
+    np.testing.assert_allclose(H, np.stack(ora.history, axis=0), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(llh, np.stack(ora.ll_history, axis=0), rtol=RTOL, atol=1e-9)
+    assert eng.stats()["local_n_accepted"] == ora.local_n_accepted
+    eng.close()
