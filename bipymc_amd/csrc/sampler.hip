@@ -1,11 +1,14 @@
 // Host side of libbipymc_hip.so: the sampler object behind the C ABI of
 // include/bipymc_hip.h.  It owns the device state (replicated chain-state matrix,
-// log-like cache, history, Welford moments, CR statistics), runs the generation
-// loop of bipymc/demc.py:63-151 as back-to-back kernel launches on one HIP stream
-// and, for world_size > 1, replaces the two MPI_Allgathers per generation
-// (demc.py:93-94,116-117) with in-place RCCL all-gathers on the same stream: of one
-// accept byte per chain followed by a replay of the accepted proposals (default), of
-// packed accepted rows, or of whole rank blocks (burn-in, synchronous mode).
+// log-like cache, history, Welford moments, CR statistics) and runs the generation
+// loop of bipymc/demc.py:63-151 as back-to-back dispatches on a user-mode AQL queue of
+// the library's own (aql_queue.h) or on one HIP stream.  For world_size > 1 the two
+// MPI_Allgathers per generation (demc.py:93-94,116-117) are replaced by the PUSH
+// exchange -- the owner of a chain stores an accepted row into every other rank's
+// replica from inside the update kernel (IPC-mapped buffers), a one-wavefront kernel
+// orders the ranks -- or, as the fallback, by in-place RCCL all-gathers on the stream:
+// of one accept byte per chain followed by a replay of the accepted proposals, of
+// packed accepted rows, or of whole rank blocks.
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <unistd.h>
