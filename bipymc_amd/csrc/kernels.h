@@ -1710,6 +1710,53 @@ __global__ __launch_bounds__(PLAN_LOCAL_THREADS) void plan_slot_kernel(const uin
     }
 }
 
+// The same for ONE rank's chains only (push exchange: a rank launches its own updates and nobody replays anybody's): the slot of a position
+// owned by this rank = half offset + number of earlier positions of the half that this rank owns too.  Two launches over (chunk of
+// SLOT_CHUNK positions, half, generation) -- thousands of workgroups where plan_slot_kernel has two per generation (82 us per window
+// at 8 x 8192 chains): count per chunk, then every chunk adds the counts of the chunks before it.  Positions of other ranks get no slot
+// (plan_kernel skips them); count[(g * 2 + half) * n_rank + me] = this rank's updates, the other ranks' entries stay zero.
+constexpr int SLOT_CHUNK = 1024;
+__global__ __launch_bounds__(SLOT_CHUNK) void plan_slot_own_kernel(const uint32_t* tab, uint32_t N, uint32_t own_lo, uint32_t own_n, uint32_t n_rank,
+                                                                   uint32_t me, uint32_t n_chunks, uint32_t* chunk_count, uint32_t* sidx, uint32_t* count,
+                                                                   uint32_t assign) {
+    __shared__ uint32_t s_wave[SLOT_CHUNK / WAVE];
+    __shared__ uint32_t s_before;
+    const uint32_t chunk = blockIdx.x, grp = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+    const uint32_t lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const uint32_t n_first = (N + 1u) / 2u;
+    const uint32_t off = grp ? n_first : 0u, n = grp ? N - n_first : n_first;
+    const uint32_t i = chunk * SLOT_CHUNK + tid;
+    const bool mine = i < n && (tab[(uint64_t)g * N + off + i] - own_lo) < own_n;
+    const unsigned long long b = __ballot(mine);
+    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
+    uint32_t* cc = chunk_count + ((uint64_t)g * 2u + grp) * n_chunks;
+    __syncthreads();
+    if (!assign) {
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int k = 0; k < SLOT_CHUNK / WAVE; ++k) tot += s_wave[k];
+            cc[chunk] = tot;
+        }
+        return;
+    }
+    if (tid == 0) {                                     // chunks before this one, in order (at most a few hundred values)
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < chunk; ++k) acc += cc[k];
+        s_before = acc;
+        if (chunk == n_chunks - 1u) {                   // the half's total: this rank's launch size
+            uint32_t tot = acc;
+            for (int k = 0; k < SLOT_CHUNK / WAVE; ++k) tot += s_wave[k];
+            count[((uint64_t)g * 2u + grp) * n_rank + me] = tot;
+        }
+    }
+    __syncthreads();
+    if (mine) {
+        uint32_t wave_off = 0;
+        for (uint32_t k = 0; k < wv; ++k) wave_off += s_wave[k];
+        sidx[(uint64_t)g * N + off + i] = off + s_before + wave_off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // DREAM outlier-chain reset (Vrugt et al. 2009; NOT in the reference -- extension), entirely on the device:
 //   outlier_omega_kernel   omega_i = mean ln_like of chain i over the last half of its history, this rank's chains

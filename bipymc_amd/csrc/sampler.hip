@@ -378,6 +378,7 @@ struct bpm_sampler {
         uint32_t* plan = nullptr;       // [win_K * N * PLAN_WORDS] update records (plan_kernel) or nullptr
         uint32_t* sidx = nullptr;       // world > 1: [win_K * N] slot of every position in the owner-sorted order of its generation (plan_slot_kernel);
                                         // `plan` then holds the records in THAT order (rank segment by rank segment inside each group)
+        uint32_t* chunk_count = nullptr; // push exchange: per-chunk counts of this rank's positions (plan_slot_own_kernel)
         uint32_t* plan_count = nullptr; // device [win_K * 2 * world]: updates of every rank in every half generation
         uint32_t* count_h = nullptr;    // the same in pinned host memory, copied behind the build
         bool own_only = false;          // its records cover this rank's chains only (built under the push exchange)
@@ -767,7 +768,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     }
     if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -1212,16 +1213,25 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
     HIPCK(hipGetLastError());
     if (B.plan) {
-        if (B.sidx) {              // world > 1: every position's slot in the owner-sorted order, every rank's counts (they size the launches)
-            hipLaunchKernelGGL(plan_slot_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, bs, B.perm, s->N, s->n_local, s->world,
-                               B.sidx, B.plan_count);
-            HIPCK(hipGetLastError());
-            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * s->world * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
-        }
         // (push exchange: nobody replays another rank's updates -- only this rank's own run of the owner-sorted records is built;
         // a window remembers it, and a change of the exchange mode rebuilds)
         const bool own_only = B.sidx != nullptr && s->push_enabled && s->push_connected;
         B.own_only = own_only;
+        if (B.sidx) {              // world > 1: every position's slot in the owner-sorted order, every rank's counts (they size the launches)
+            if (own_only) {        // this rank's positions only: the other ranks' counts stay zero, its own run starts at the half's offset
+                const uint32_t n_chunks = ((s->N + 1u) / 2u + SLOT_CHUNK - 1u) / SLOT_CHUNK;
+                if (!B.chunk_count) CK(dev_alloc(&B.chunk_count, (size_t)s->win_K * 2 * n_chunks));
+                HIPCK(hipMemsetAsync(B.plan_count, 0, (size_t)K * 2 * s->world * sizeof(uint32_t), bs));
+                for (uint32_t assign = 0; assign < 2; ++assign)
+                    hipLaunchKernelGGL(plan_slot_own_kernel, dim3(n_chunks, 2, (unsigned)K), dim3(SLOT_CHUNK), 0, bs, B.perm, s->N, s->lo, s->n_local, s->world,
+                                       s->rank, n_chunks, B.chunk_count, B.sidx, B.plan_count, assign);
+            } else {
+                hipLaunchKernelGGL(plan_slot_kernel, dim3(2, (unsigned)K), dim3(PLAN_LOCAL_THREADS), 0, bs, B.perm, s->N, s->n_local, s->world,
+                                   B.sidx, B.plan_count);
+            }
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(B.count_h, B.plan_count, (size_t)K * 2 * s->world * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+        }
         PlanParams pp{s->cfg.seed, (uint64_t)t0, (uint32_t)K, s->N, s->cfg.algo == BPM_ALGO_DREAM ? (uint32_t)s->cfg.del_pairs : 1u,
                       (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.p_snooker > 0.0) ? 1u : 0u, own_only ? s->lo : 0u, own_only ? s->n_local : 0u};
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, pp, B.perm, B.plan, B.sidx);
