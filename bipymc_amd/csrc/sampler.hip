@@ -1994,6 +1994,18 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
     HIPCK(hipStreamSynchronize(s->stream));
     std::vector<unsigned long long> all(3 * MAX_SEG, 0ull), others(MAX_PEERS, 0ull);
     uint32_t n_others = 0;
+    // (a failure half way leaves nothing mapped: a later attempt starts from scratch)
+    struct Undo {
+        bpm_sampler* s; bool armed = true;
+        ~Undo() {
+            if (!armed) return;
+            for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p) {
+                if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
+                if (s->peer_ctrl_opened[p] && s->peer_ctrl_base[p]) (void)hipIpcCloseMemHandle(s->peer_ctrl_base[p]);
+                s->peer_opened[p] = s->peer_ctrl_opened[p] = false; s->peer_base[p] = s->peer_ctrl_base[p] = nullptr;
+            }
+        }
+    } undo{s};
     for (uint32_t p = 0; p < s->world; ++p) {
         PushBlob b;
         std::memcpy(&b, static_cast<const char*>(blobs) + (size_t)p * BPM_PUSH_BLOB_BYTES, sizeof(b));
@@ -2038,6 +2050,7 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
     for (uint32_t i = n_others; i < (uint32_t)MAX_PEERS; ++i) others[i] = others[0];
     HIPCK(hipMemcpy(s->tab_all, all.data(), all.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(s->tab_peerG, others.data(), others.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    undo.armed = false;
     s->push_connected = true;
     s->push_enabled = true;               // connected: the default exchange from here on (bpm_set_exchange chooses another)
     return 0;
