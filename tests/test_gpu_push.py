@@ -164,3 +164,36 @@ except L.BpmError as err:
     line = [ln for ln in out.stdout.splitlines() if ln.startswith(("ERROR", "NOERROR"))][0]
     assert line.startswith("ERROR after") and "waited longer than the limit for rank 1" in line, line
     assert float(line.split()[2]) < 60.0
+
+
+def test_connect_refuses_wrong_blobs_and_can_be_repeated():
+    """bpm_push_connect checks what it is given (rank order, world, sampler shape) and leaves nothing mapped when it fails: the caller's
+    communicator delivered the blobs (the reference's counterpart is mpi_comm, demc.py:15), so a mix-up must be an error, not a wrong run."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D(dim=6)._bpm_target_spec()
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=32, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid) for r in range(2)]
+    other = HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=1, world_size=2, nccl_uid=uid)
+    blobs = [e.push_export() for e in ranks]
+    with pytest.raises(L.BpmError, match="not the export of rank"):
+        ranks[0].push_connect(blobs[::-1])                               # rank order mixed up
+    with pytest.raises(L.BpmError, match="another sampler shape"):
+        ranks[0].push_connect([blobs[0], other.push_export()])           # a rank of another world
+    with pytest.raises(L.BpmError, match="needs bpm_push_connect first"):
+        ranks[0].set_exchange("push")
+    single = HipEngine(algo=L.ALGO_DREAM, n_chains=32, dim=d, target_id=tid, target_params=tp, seed=1)
+    with pytest.raises(L.BpmError, match="no push exchange"):
+        single.push_export()
+    for e in ranks:
+        e.push_connect(blobs)                                            # and now for real
+    with pytest.raises(L.BpmError, match="already connected"):
+        ranks[0].push_connect(blobs)
+    arr = (C.c_void_p * 2)(*[e._h for e in ranks])
+    ok = C.c_int32(0)
+    L.check(ranks[0].lib.bpm_push_selftest(arr, 2, C.byref(ok)))
+    assert ok.value == 1 and ranks[0].exchange_stats()["push_flags_fine_grained"]
+    for e in ranks + [other, single]:
+        e.close()
