@@ -117,3 +117,12 @@ def test_histories_appended_in_shuffle_order_come_back_in_chain_order(algo, N, d
     np.testing.assert_allclose(llh, np.stack(ora.ll_history, axis=0), rtol=RTOL, atol=1e-9)
     assert eng.stats()["local_n_accepted"] == ora.local_n_accepted
     eng.close()
+
+
+@pytest.mark.parametrize("N,d,pairs", [(96, 130, 3), (40, 300, 2), (64, 64, 3), (50, 33, 1)])
+def test_wide_rows_on_the_shipped_path_equal_the_oracle(N, d, pairs):
+    """One wavefront per chain with 2, 4 or 8 coordinates per lane (d = 33 ... 300) on the shipped path -- own queue, acquire-only packets,
+    16-byte write-through stores of 2 / 4 chunks per lane, plan records -- against the oracle (dream.py:32-140), burn-in and steady state."""
+    params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) + 1.0))
+    X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, X0, 9, dict(del_pairs=pairs, n_cr=3, burnin_gen=4, n_cr_gen=2), hist_rows=(4, 9))
