@@ -337,30 +337,63 @@ def connect_exchange(eng, dist, rank, world, want):
     return dict(mode="replay", why="push exchange not available (%s)" % why)
 
 
-def validate_push_fence_scope(eng, dist, X0, gens=150):
-    """The push exchange's update packets may fence at agent scope instead of system scope (6 us less per half generation); whether
-    that suffices between the GPUs of THIS node is checked before anything is timed: the same `gens` generations (CR adaptation on, so
-    the per-update statistics travel too) from the same start under both settings must leave every rank with the same replica, bit for
-    bit -- and the replicas of all ranks must agree with each other.  -> the setting the timed run uses."""
+def validate_exchange(eng, dist, X0, make_single, candidates, gens=150):
+    """Which exchange the timed run uses is decided by a RUN, not by what connected: `gens` generations with CR adaptation (so the per-update
+    statistics travel too) from the same start, once on a single-rank sampler holding the whole population on this rank's own GPU (what
+    the reference computes on one MPI rank, demc.py:63-151) and then under each candidate in order -- push with agent-scope fences (cheapest),
+    push with system-scope fences (what the HSA memory model asks for between agents), accept bytes + replay through RCCL, the dense all-gather
+    (the reference's own exchange, demc.py:93-94).  The first candidate that leaves EVERY rank's replica bit-identical to the single-rank run
+    wins; a candidate that raises (a cross-rank wait that ran into its limit) is recorded and skipped.  -> dict(mode=..., validation=[...])."""
     import hashlib
-    shas = {}
-    for scope in ("system", "agent"):
-        eng.set_exchange(mode="push" if scope == "system" else "push-agent")
-        eng.set_state(X0)
-        eng.set_adapt_state(t_abs=0)
-        eng.begin_run()
-        dist.barrier()
-        eng.step(gens)
-        eng.synchronize()
-        mine = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]
-        box = [None] * dist.get_world_size()
-        dist.all_gather_object(box, mine)
-        shas[scope] = box
-    agent_ok = len(set(shas["system"])) == 1 and shas["agent"] == shas["system"]
-    eng.set_exchange(mode="push-agent" if agent_ok else "push")
-    eng.set_adapt_state(t_abs=0)
-    return dict(fence_scope="agent" if agent_ok else "system", fence_scope_validation=dict(
-        generations=gens, replicas_identical_system=len(set(shas["system"])) == 1, agent_equals_system=shas["agent"] == shas["system"]))
+
+    def sha(x):
+        return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()[:16]
+    world = dist.get_world_size()
+    single = make_single()
+    single.set_state(X0)
+    single.begin_run()
+    single.step(gens)
+    single.synchronize()
+    want = sha(single.get_state())
+    single.close()
+    log = []
+    push_dead = False
+    for cand in candidates:
+        if push_dead and cand.startswith("push"):
+            log.append(dict(exchange=cand, ok=False, why="skipped: a push wait timed out under an earlier candidate"))
+            continue
+        mine, err = None, None
+        try:
+            eng.set_exchange(mode=cand)
+            eng.set_state(X0)
+            eng.set_adapt_state(t_abs=0)
+            eng.begin_run()
+            dist.barrier()
+            eng.step(gens)
+            eng.synchronize()
+            mine = sha(eng.get_state())
+        except Exception as e:                                         # noqa: BLE001 -- decided collectively below
+            err = "%s: %s" % (type(e).__name__, e)
+        box = [None] * world
+        dist.all_gather_object(box, (mine, err))
+        ok = all(b[0] == want for b in box)
+        entry = dict(exchange=cand, ok=ok, generations=gens, ranks_equal_to_single_rank_run=sum(1 for b in box if b[0] == want))
+        errs = ["rank %d: %s" % (i, b[1]) for i, b in enumerate(box) if b[1]]
+        if errs:
+            entry["errors"] = errs[:4]
+            if cand.startswith("push"):
+                push_dead = True
+                try:                                                    # (clears the time-out mark so that bpm_synchronize works again)
+                    eng.set_exchange(mode="dense")
+                except Exception:                                      # noqa: BLE001
+                    pass
+        log.append(entry)
+        if ok:
+            eng.set_exchange(mode=cand)
+            eng.set_adapt_state(t_abs=0)
+            return dict(mode="push" if cand.startswith("push") else cand, fence_scope={"push-agent": "agent", "push": "system"}.get(cand),
+                        validation=log)
+    raise SystemExit("bench.py: no exchange reproduced the single-rank run on every rank: " + json.dumps(log))
 
 
 def main(argv=None):
@@ -455,8 +488,17 @@ def main(argv=None):
     X0 = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((n_chains, 1))
                                           + np.sqrt(0.5) * rs.standard_normal((n_chains, DIM)))
     total_gens = BURNIN_GEN + max(args.warmup + args.steps + 32, POSTERIOR_MIN_GENS) + 64
-    if exchange_info is not None and exchange_info["mode"] == "push" and args.exchange in (None, "push"):
-        exchange_info.update(validate_push_fence_scope(eng, dist, X0))
+    if world > 1:
+        # candidates in order of cost; --exchange restricts the list (and then failing is fatal).  Ranks sharing one GPU have no RCCL.
+        if args.exchange in ("replay", "rows", "dense"):
+            cands = [args.exchange]
+        else:
+            cands = (["push-agent", "push"] if exchange_info["mode"] == "push" else []) + ([] if args.share_gpu or args.exchange == "push" else ["replay", "dense"])
+
+        def make_single():
+            return HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42, device=local_rank,
+                             del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
+        exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands))
     eng.set_state(X0)
     eng.reserve_history(1 + total_gens)
 

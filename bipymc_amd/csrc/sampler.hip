@@ -415,6 +415,7 @@ struct bpm_sampler {
     void* peer_ctrl_base[MAX_SEG] = {};     // the peers' fine-grained control blocks as this process addresses them
     bool peer_ctrl_opened[MAX_SEG] = {};
     bool push_connected = false, push_enabled = false, push_no_rccl = false;
+    bool push_failed = false;      // a cross-rank wait ran into its limit: push cannot be re-enabled (bpm_set_exchange)
     bool push_agent_scope = false;          // update packets fence at agent scope instead of system scope (bpm_set_exchange(h, 3, 1))
     void* peer_base[MAX_SEG] = {};          // every rank's arena as THIS process addresses it (own entry: arena)
     bool peer_opened[MAX_SEG] = {};         // mapped with hipIpcOpenMemHandle (to be closed)
@@ -1524,6 +1525,7 @@ static int push_check_error(bpm_sampler* s) {
     if (!s->push_connected) return 0;
     unsigned long long e = 0;
     HIPCK(hipMemcpy(&e, &s->ctrl->err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0) s->push_failed = true;
     if (e != 0) return fail("push exchange: rank " + std::to_string(s->rank) + " waited longer than the limit for rank " + std::to_string((long long)e - 1) +
                             " (a rank that died, or ranks that entered bpm_step more than BPM_PUSH_TIMEOUT_S apart); the replicas are no longer consistent");
     return 0;
@@ -1922,9 +1924,14 @@ extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     CK(check_handle(s));
     if (mode < 0 || mode > 3) return fail("bpm_set_exchange: mode must be 0 (dense), 1 (rows), 2 (replay) or 3 (push)");
     if (mode == 3 && !s->push_connected) return fail("bpm_set_exchange: the push exchange needs bpm_push_connect first");
+    if (mode == 3 && s->push_failed) return fail("bpm_set_exchange: a wait of the push exchange ran into its limit earlier (the ranks' barrier counters no longer agree): this sampler can only go on with an RCCL exchange");
     if (mode != 3 && s->push_no_rccl) return fail("bpm_set_exchange: this sampler was created without an RCCL communicator: the push exchange is its only one");
     if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
     if (s->push_enabled && mode != 3) s->cur = -1;      // (windows built with this rank's records only are rebuilt: ensure_perm_table)
+    if (s->push_failed && mode != 3) {                  // leaving a push exchange that timed out: the next bpm_synchronize must not report it again
+        CK(set_device(s));
+        HIPCK(hipMemset(&s->ctrl->err, 0, sizeof(unsigned long long)));
+    }
     s->push_enabled = mode == 3;
     if (mode == 3) s->push_agent_scope = (cap & 1) != 0;
     s->sparse_enabled = mode == 1;

@@ -94,3 +94,74 @@ def test_visible_gpu_count_probe_runs_in_a_child_and_reports_zero_here():
     assert n >= 0, "the probe child could not load bipymc_amd/libbipymc_hip.so"
     if not os.path.exists("/dev/kfd"):
         assert n == 0
+
+
+# ---- bench.py: which exchange an N > 1 run uses is decided by a run against a single-rank sampler (validate_exchange) ----------------
+class _StubDist(object):
+    def get_world_size(self):
+        return 1
+
+    def barrier(self):
+        pass
+
+    def all_gather_object(self, box, v):
+        box[0] = v
+
+
+class _StubEngine(object):
+    """final state = a function of the exchange mode: `good` modes reproduce the single-rank state, `bad` ones do not, `boom` ones raise"""
+    def __init__(self, good=(), boom=()):
+        self.good, self.boom, self.mode, self.modes_set = set(good), set(boom), None, []
+
+    def set_exchange(self, mode):
+        self.mode = mode
+        self.modes_set.append(mode)
+
+    def set_state(self, X):
+        self.X = X
+
+    def set_adapt_state(self, **kw):
+        pass
+
+    def begin_run(self):
+        pass
+
+    def step(self, n):
+        if self.mode in self.boom:
+            raise RuntimeError("push exchange: rank 0 waited longer than the limit for rank 1")
+
+    def synchronize(self):
+        pass
+
+    def get_state(self):
+        import numpy as np
+        return self.X + (0.0 if self.mode is None or self.mode in self.good else 1.0)
+
+    def close(self):
+        pass
+
+
+def test_exchange_is_chosen_by_reproducing_the_single_rank_run():
+    import numpy as np
+    import pytest
+    X0 = np.arange(12.0).reshape(3, 4)
+    cands = ["push-agent", "push", "replay", "dense"]
+    # the cheapest candidate that reproduces the single-rank run wins
+    e = _StubEngine(good=cands)
+    got = bench.validate_exchange(e, _StubDist(), X0, lambda: _StubEngine(), cands, gens=3)
+    assert got["mode"] == "push" and got["fence_scope"] == "agent" and [v["ok"] for v in got["validation"]] == [True]
+    # agent-scope fences give other bits: system scope
+    e = _StubEngine(good=["push", "replay", "dense"])
+    got = bench.validate_exchange(e, _StubDist(), X0, lambda: _StubEngine(), cands, gens=3)
+    assert got["mode"] == "push" and got["fence_scope"] == "system" and [v["ok"] for v in got["validation"]] == [False, True]
+    assert e.mode == "push"
+    # a push wait that times out: the other push candidate is skipped, the time-out mark is cleared (set_exchange away from push), RCCL replay is taken
+    e = _StubEngine(good=["replay", "dense"], boom=["push-agent"])
+    got = bench.validate_exchange(e, _StubDist(), X0, lambda: _StubEngine(), cands, gens=3)
+    assert got["mode"] == "replay" and got["fence_scope"] is None
+    assert [v["exchange"] for v in got["validation"]] == cands[:3] and "errors" in got["validation"][0] and "skipped" in got["validation"][1]["why"]
+    assert e.modes_set == ["push-agent", "dense", "replay", "replay"]
+    # nothing reproduces it: no number is printed
+    with pytest.raises(SystemExit) as ei:
+        bench.validate_exchange(_StubEngine(good=[]), _StubDist(), X0, lambda: _StubEngine(), cands, gens=3)
+    assert "no exchange reproduced" in str(ei.value)

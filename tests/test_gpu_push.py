@@ -154,6 +154,15 @@ try:
     print("NOERROR")
 except L.BpmError as err:
     print("ERROR after %.1f s: %s" % (time.time() - t0, err))
+# a sampler whose push exchange timed out can leave it for another exchange (bench.py: validate_exchange), never re-enter it
+try:
+    ranks[0].set_exchange(mode="push")
+    print("PUSH-AGAIN accepted")
+except L.BpmError as err:
+    print("PUSH-AGAIN refused: %s" % err)
+ranks[0].set_exchange(mode="dense")
+ranks[0].synchronize()
+print("LEFT-PUSH synchronize ok")
 '''
     env = dict(os.environ)
     env["BPM_TEST_PATHS"] = "groupqueues"
@@ -164,6 +173,7 @@ except L.BpmError as err:
     line = [ln for ln in out.stdout.splitlines() if ln.startswith(("ERROR", "NOERROR"))][0]
     assert line.startswith("ERROR after") and "waited longer than the limit for rank 1" in line, line
     assert float(line.split()[2]) < 60.0
+    assert "PUSH-AGAIN refused" in out.stdout and "ran into its limit earlier" in out.stdout and "LEFT-PUSH synchronize ok" in out.stdout, out.stdout[-1500:]
 
 
 def test_connect_refuses_wrong_blobs_and_can_be_repeated():
