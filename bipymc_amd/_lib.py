@@ -59,6 +59,7 @@ SIGNATURES = {
     "bpm_destroy": (C.c_int, [_H]),
     "bpm_debug_destroy_plan": (C.c_int, [C.c_int32, C.c_int32]),
     "bpm_debug_fail_queue": (C.c_int, [_H, C.c_int32]),
+    "bpm_debug_queue_pad": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
     "bpm_init_chains": (C.c_int, [_H, _dp, _dp]),
     "bpm_set_state": (C.c_int, [_H, _dp]),
     "bpm_get_state": (C.c_int, [_H, _dp]),

@@ -193,7 +193,6 @@ class DirectQueue {
         struct InDrain { bool& f; bool old; InDrain(bool& x) : f(x), old(x) { f = true; } ~InDrain() { f = old; } } guard(in_drain_);
         since_drain_ = 0;
         if (!next_slot()) return -1;
-        flush();
         if (unreleased_) {
             // packets without a release fence were dispatched: an (empty) kernel with acquire + release first, so that the caches end up as
             // after the last kernel of a HIP stream (history rows of non-temporal stores may still wait in an L2)
@@ -201,9 +200,12 @@ class DirectQueue {
             uint64_t zero = 0;
             if (launch(fence_kernel_, 64, 1, 64, &zero, sizeof(zero), FENCED) != 0) return -1;
             unreleased_ = false;
-            flush();
             if (!next_slot()) return -1;
         }
+        // next_slot() may have put an epoch marker in front of this slot: publish it BEFORE the barrier packet, whose header is written
+        // directly -- a doorbell over an unpublished (INVALID) marker stops the packet processor for good (once in 256 drains of this kind:
+        // tests/test_gpu_api.py::test_drains_at_every_position_of_the_queues_epochs)
+        flush();
         auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
         std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
         hsa_signal_store_relaxed(done_, 1);
@@ -247,6 +249,26 @@ class DirectQueue {
         return false;
     }
     bool dead() const { return dead_; }
+    // test hook (bpm_debug_queue_pad): no-op barrier packets until the next packet would take position `pos` of its epoch of 256 (pos < 255);
+    // -> the write index.  Lets a test put a drain's packets at a chosen place of the ring.
+    int64_t test_pad_to(uint32_t pos) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
+        if (failed_ || pos >= EPOCH - 1) return -1;
+        for (;;) {
+            if (!next_slot()) return -1;
+            if (widx_ % EPOCH == pos) break;
+            auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
+            std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
+            pending_header_[n_unpublished_] = (uint32_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+            pending_packet_[n_unpublished_] = reinterpret_cast<uint32_t*>(b);
+            ++n_unpublished_;
+            ++widx_;
+            busy_ = true;
+            if (n_unpublished_ >= MAX_UNPUBLISHED - 1 || (widx_ & (q_->size - 1)) == 0) flush();
+        }
+        flush();
+        return (int64_t)widx_;
+    }
     // test hook (bpm_debug_fail_queue): behave as if a drain had timed out; refuse != 0: and as if the queue could not be inactivated
     void test_mark_failed(bool refuse) { std::lock_guard<std::recursive_mutex> lk(mu_); failed_ = true; why_ = "failure injected by the test hook"; test_refuse_quiesce_ = refuse; }
     const std::string& why() const { return why_; }

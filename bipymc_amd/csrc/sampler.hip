@@ -215,7 +215,7 @@ static void launch_hot(const PhaseArgs& a, hipStream_t s) {
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 #ifdef BPM_PRELOAD
-    {   // frequent cases take a specialised instantiation (kernels.h: HOT): steady state, DREAM's burn-in, a rank of a world
+    if constexpr (DPL <= 8) {   // frequent cases take a specialised instantiation (kernels.h: HOT): steady state, DREAM's burn-in, a rank of a world (d <= 512)
         constexpr bool CAN_PLAN = (LPC == WAVE && DPL == 2);               // the shape that can read plan records
         const bool wp = CAN_PLAN && a.rec_tab != nullptr;
         constexpr bool DREAM_ = ALGO == ALGO_DREAM;
@@ -270,23 +270,25 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
     else if (np <= 64) sh = {64, 2, 3};   // (two / four chains per wavefront, 32x4 and 16x8, measured no faster: DESIGN.md)
     else if (np <= 128) sh = {64, 4, 4};
     else if (np <= 256) sh = {64, 8, 5};
+    else if (np <= 512) sh = {64, 16, 6};     // d <= 1024, 2048: the same kernels with 8 / 16 coordinate pairs per lane (general instantiation only)
+    else if (np <= 1024) sh = {64, 32, 7};
     else return false;
     return true;
 }
 #define SHAPE_TABLE(FN, ...)                                                                     \
     {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
-     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>}
+     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>, FN<__VA_ARGS__ 64, 16>, FN<__VA_ARGS__ 64, 32>}
 #define COMMA ,
 // update-kernel variants: [DE-MC (1 pair) | DREAM del_pairs = 3 (compile-time) | DREAM any del_pairs][shape]
-static PhaseLaunch g_fused_gauss[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
+static PhaseLaunch g_fused_gauss[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
                                           SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
-static PhaseLaunch g_fused_mixture[3][6] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
+static PhaseLaunch g_fused_mixture[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
                                             SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
 static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
                                         launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
-static PhaseLaunch g_propose[2][6] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+static PhaseLaunch g_propose[2][8] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
 template <int ALGO, int NP, int LPC, int DPL>
 static void launch_replay(const PhaseArgs& a, hipStream_t s) {
     // (a workgroup per 64 positions that compacts the remote accepted chains in LDS and rebuilds only those -- 8192 wavefronts
@@ -302,17 +304,15 @@ static void launch_replay_sorted(const PhaseArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((phase_replay_sorted_kernel<ALGO, DPL, NP>), dim3((max_cnt + REPLAY_WG / WAVE - 1) / (REPLAY_WG / WAVE), a.n_seg), dim3(REPLAY_WG),
                        0, s, a);
 }
-// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][dims per lane 2 / 4 / 8]: owner-sorted records exist for one wavefront per chain only
-static PhaseLaunch g_replay_sorted[3][3] = {
-    {launch_replay_sorted<ALGO_DEMC, 1, 2>, launch_replay_sorted<ALGO_DEMC, 1, 4>, launch_replay_sorted<ALGO_DEMC, 1, 8>},
-    {launch_replay_sorted<ALGO_DREAM, 3, 2>, launch_replay_sorted<ALGO_DREAM, 3, 4>, launch_replay_sorted<ALGO_DREAM, 3, 8>},
-    {launch_replay_sorted<ALGO_DREAM, 0, 2>, launch_replay_sorted<ALGO_DREAM, 0, 4>, launch_replay_sorted<ALGO_DREAM, 0, 8>}};
+// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][dims per lane 2 / 4 / 8 / 16 / 32]: owner-sorted records exist for one wavefront per chain only
+#define RS_ROW(A, P) {launch_replay_sorted<A, P, 2>, launch_replay_sorted<A, P, 4>, launch_replay_sorted<A, P, 8>, launch_replay_sorted<A, P, 16>, launch_replay_sorted<A, P, 32>}
+static PhaseLaunch g_replay_sorted[3][5] = {RS_ROW(ALGO_DEMC, 1), RS_ROW(ALGO_DREAM, 3), RS_ROW(ALGO_DREAM, 0)};
 // [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][shape]: the same pair-count variants as the update kernels (no target: no ln-like)
-static PhaseLaunch g_replay[3][6] = {SHAPE_TABLE(launch_replay, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 3 COMMA),
+static PhaseLaunch g_replay[3][8] = {SHAPE_TABLE(launch_replay, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 3 COMMA),
                                      SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 0 COMMA)};
-static PhaseLaunch g_commit[2][6] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
-static EvalLaunch g_eval_gauss[6] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
-static EvalLaunch g_eval_mixture[6] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
+static PhaseLaunch g_commit[2][8] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
+static EvalLaunch g_eval_gauss[8] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
+static EvalLaunch g_eval_mixture[8] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
 
 // ---- the sampler ------------------------------------------------------------------------
 struct bpm_sampler {
@@ -451,6 +451,8 @@ struct bpm_sampler {
     bool dq_private = false;          // a queue of this sampler's own (rank of a local group under BPM_TEST_PATHS=groupqueues)
     bool dq_active = false;
     bool dq_enabled = true;           // bpm_set_launch_path
+    bool shape_needs_scratch = false; // 1024 < d <= 2048 (16 coordinate pairs per lane): the update kernels spill to scratch memory, which the HIP
+                                      // runtime provisions for ITS queues -- these samplers launch on the stream
     bool coherent = false;            // state buffers live in cached-coherent device memory (dev_alloc_state)
     int dq_fence = bpm::DirectQueue::FENCED;   // fences of the update-kernel packets (run_generations)
     bool timed_direct = false;        // the last bpm_step_timed was timed by the queue's dispatch time stamps
@@ -803,6 +805,18 @@ extern "C" int bpm_debug_fail_queue(bpm_handle_t s, int32_t refuse_quiesce) {
     return 0;
 }
 
+// Test hook: no-op packets on the handle's queue until its next packet takes position `pos` (0 ... 254) of an epoch of 256 packets; *widx = the
+// queue's write index afterwards.  (tests/test_gpu_api.py::test_drains_at_every_position_of_the_queues_epochs)
+extern "C" int bpm_debug_queue_pad(bpm_handle_t s, int32_t pos, int64_t* widx) {
+    if (!s) return fail("null handle");
+    if (!s->dq) return fail("bpm_debug_queue_pad: this sampler has no queue of its own");
+    if (pos < 0 || pos > 254) return fail("bpm_debug_queue_pad: pos must be 0 ... 254");
+    const int64_t w = s->dq->test_pad_to((uint32_t)pos);
+    if (w < 0) return fail("bpm_debug_queue_pad: " + s->dq->why());
+    if (widx) *widx = w;
+    return 0;
+}
+
 extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (!cfg || !out) return fail("bpm_create: null argument");
     *out = nullptr;
@@ -833,7 +847,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->rank = (uint32_t)cfg->rank;
     s->n_local = s->N / s->world;
     s->lo = s->rank * s->n_local;
-    if (!pick_shape(s->ld, s->shape)) { delete s; return fail("bpm_create: dim > 512 not supported"); }
+    if (!pick_shape(s->ld, s->shape)) { delete s; return fail("bpm_create: dim > 2048 not supported"); }
+    s->shape_needs_scratch = s->shape.dpl > 16;
     if ((uint64_t)s->N * (s->ld + 2) >= (1ull << 31)) { delete s; return fail("bpm_create: n_chains * (dim + 2) must stay below 2^31 (32-bit device offsets)"); }
     const int tid = cfg->target_id;
     const int np = cfg->n_target_params;
@@ -1773,10 +1788,10 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
             bool group_direct = push && g.R > 1 && !g_host_timing && !local_serial(g);
             for (int r = 0; r < g.R && group_direct; ++r)
-                group_direct = g.h[r]->dq_private && g.h[r]->dq_enabled && !g.h[r]->dq->failed() && !g.h[r]->trace_i32 && !g.h[r]->stamps;
+                group_direct = g.h[r]->dq_private && g.h[r]->dq_enabled && !g.h[r]->dq->failed() && !g.h[r]->trace_i32 && !g.h[r]->stamps && !g.h[r]->shape_needs_scratch;
             const bool direct = group_direct ||
                                 (s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && (!s0->local_group || s0->dq_private) &&
-                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed());
+                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed() && !s0->shape_needs_scratch);
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (direct && !s->dq_active) {

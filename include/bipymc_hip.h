@@ -64,7 +64,7 @@ typedef struct bpm_config {
     int32_t abi_version; /* BPM_ABI_VERSION */
     int32_t algo;        /* BPM_ALGO_* */
     int32_t n_chains;    /* global number of chains, >= 4 (samplers.py:249), divisible by world_size */
-    int32_t dim;         /* len(theta_0) or kwargs["dim"] (demc.py:20-23) */
+    int32_t dim;         /* len(theta_0) or kwargs["dim"] (demc.py:20-23); 1 ... 2048 (the reference has no limit) */
     int32_t target_id;   /* BPM_TARGET_* */
     int32_t n_target_params;
     const double* target_params; /* copied */
@@ -248,6 +248,9 @@ int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_
  * queue (the device's queue is unusable for the rest of the process afterwards: child processes only) */
 int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);
 int bpm_debug_fail_queue(bpm_handle_t h, int32_t refuse_quiesce);
+/* test hook: no-op packets on the handle's own AQL queue until its next packet takes position `pos` (0 ... 254) of an epoch of 256 packets;
+ * *widx = the queue's write index afterwards (a test then puts a drain's packets at a chosen place of the ring) */
+int bpm_debug_queue_pad(bpm_handle_t h, int32_t pos, int64_t* widx);
 /* test hooks (no sampler state involved) */
 int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* test hook: the order statistics, first argmax and cut (Q1 - 2 IQR) the outlier check would select from `omega` (n_chains values) */
 int bpm_debug_outlier_select(bpm_handle_t h, const double* omega, double out[6]);

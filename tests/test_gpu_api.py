@@ -1070,3 +1070,51 @@ def test_sampler_class_without_history_still_estimates_parameters():
     np.testing.assert_allclose(sb, sa, rtol=1e-10)
     np.testing.assert_allclose(mb, mean, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(sb, std, rtol=1e-9)
+
+
+def test_drains_at_every_position_of_the_queues_epochs():
+    """The library's own AQL queue closes every epoch of 256 packets with a marker packet of its own, and a drain behind release-less packets of
+    a SMALL population (fewer than 64 workgroups: the last update kernel's release is not a full write-back) dispatches an empty fence kernel before its
+    barrier packet.  When that kernel took position 254 of an epoch IN THE RING'S FIRST LAP the marker behind it stayed unpublished while the
+    barrier packet's doorbell was rung: the packet processor stopped in front of an INVALID header and the drain ran into its time limit (found
+    when a longer test file shifted the suite's packet count onto that position).  Here: in a fresh process the queue is padded so that the drain's
+    packets sit just in front of the marker in every epoch of the first two laps (fence kernel at 254 in the first), then drains at random positions.
+    In a child process: the time limit is read once per process, and the first lap exists once."""
+    import subprocess
+    code = r'''
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+from bipymc_amd.utils import d100_gauss
+tid, tp, d = d100_gauss.Gauss_100D(dim=8)._bpm_target_spec()
+e = HipEngine(algo=L.ALGO_DREAM, n_chains=20, dim=d, target_id=tid, target_params=tp, seed=3, burnin_gen=0, keep_history=False)
+e.set_state(np.random.RandomState(0).normal(size=(20, d)))
+e.begin_run()
+ls0 = e.launch_stats()
+assert ls0["has_queue"], ls0
+e.step(1)
+e.synchronize()                                   # (the first table build is behind us)
+w = C.c_int64(0)
+n = 1
+for epoch, start in enumerate((252, 251, 252, 250, 252, 253, 254, 252)):   # 2 update packets, then the drain's fence kernel + barrier packet: fence at start + 2
+    L.check(e.lib.bpm_debug_queue_pad(e._h, start, C.byref(w)))
+    assert w.value == 256 * epoch + start, (w.value, epoch, start)           # epochs 0 ... 3 are the ring's first lap
+    e.step(1)
+    e.synchronize()
+    n += 1
+    print("drain behind position", start, "ok", flush=True)
+rs = np.random.RandomState(1)
+for i in range(400):
+    k = int(rs.randint(1, 4))
+    e.step(k)
+    e.synchronize()
+    n += k
+ls = e.launch_stats()
+assert ls["direct"] - ls0["direct"] == 2 * n and ls["stream"] == ls0["stream"], (ls0, ls)
+print("DRAINS-OK", n)
+'''
+    env = dict(os.environ, BPM_QUEUE_TIMEOUT_S="15")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "DRAINS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]

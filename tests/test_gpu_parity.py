@@ -83,7 +83,7 @@ def test_targets_against_reference_known_answers(golden_dir):
                                [e["ln_like"] for e in g["Banana_2D"]], rtol=1e-12)
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 16, 33, 100, 128, 130, 256, 300, 512])
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 16, 33, 100, 128, 130, 256, 300, 512, 513, 1000, 1024, 1025, 1999, 2048])
 def test_gauss_target_every_kernel_shape(d):
     """every (lanes-per-chain, dims-per-lane) instantiation, odd dims (padded rows) included"""
     params = _gauss_params(d, rho=0.3)
@@ -92,7 +92,7 @@ def test_gauss_target_every_kernel_shape(d):
     np.testing.assert_allclose(eng.eval_loglike(X), R.ll_gauss_equicorr(X, params), rtol=1e-13)
 
 
-@pytest.mark.parametrize("d", [2, 4, 8, 32, 100])
+@pytest.mark.parametrize("d", [2, 4, 8, 32, 100, 600, 1026, 2048])
 def test_mixture_target_shapes(d):
     eng = _engine(algo=R.ALGO_DREAM, n_chains=8, dim=d, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1)
     rs = np.random.RandomState(d)
@@ -366,9 +366,10 @@ def test_outlier_chain_reset_matches_oracle():
 
 
 @pytest.mark.parametrize("N,d,P_,n_cr", [(4, 1, 1, 1), (5, 3, 1, 2), (4, 100, 1, 3), (7, 2, 3, 8), (23, 9, 10, 3),
-                                         (6, 512, 2, 3), (11, 511, 3, 3), (64, 114, 3, 3), (64, 116, 3, 3), (16, 128, 3, 5)])
+                                         (6, 512, 2, 3), (11, 511, 3, 3), (64, 114, 3, 3), (64, 116, 3, 3), (16, 128, 3, 5),
+                                         (7, 513, 3, 3), (6, 1024, 2, 3), (9, 1025, 3, 3), (5, 1500, 1, 2), (8, 2048, 3, 3)])
 def test_dream_edge_shapes(N, d, P_, n_cr):
-    """smallest populations (pool of two), odd N (unequal pools), dim 1, padded odd dims, the largest dim,
+    """smallest populations (pool of two), odd N (unequal pools), dim 1, padded odd dims, the largest dims (8 and 16 coordinate pairs per lane: d up to 2048),
     del_pairs up to 10, n_cr 1..8, and the dims around the merged-Philox lane budget (114 / 116)."""
     if 2 * P_ > 0 and (N // 2) < 2:
         pytest.skip("pool too small")
@@ -381,7 +382,7 @@ def test_dream_edge_shapes(N, d, P_, n_cr):
     np.testing.assert_allclose(eng.stats()["p_cr"], ora.cr.p_cr, rtol=1e-6)
 
 
-@pytest.mark.parametrize("N,d", [(4, 1), (5, 2), (6, 3), (9, 100), (8, 300)])
+@pytest.mark.parametrize("N,d", [(4, 1), (5, 2), (6, 3), (9, 100), (8, 300), (7, 777), (6, 2047)])
 def test_demc_edge_shapes(N, d):
     eng, ora = _pair(R.ALGO_DEMC, N, d, R.TARGET_GAUSS_EQUICORR, _gauss_params(d), 98, p_snooker=0.5)
     X = np.random.RandomState(2).normal(size=(N, d))

@@ -119,10 +119,41 @@ def test_histories_appended_in_shuffle_order_come_back_in_chain_order(algo, N, d
     eng.close()
 
 
-@pytest.mark.parametrize("N,d,pairs", [(96, 130, 3), (40, 300, 2), (64, 64, 3), (50, 33, 1)])
+@pytest.mark.parametrize("N,d,pairs", [(96, 130, 3), (40, 300, 2), (64, 64, 3), (50, 33, 1), (48, 640, 3), (40, 1024, 2)])
 def test_wide_rows_on_the_shipped_path_equal_the_oracle(N, d, pairs):
-    """One wavefront per chain with 2, 4 or 8 coordinates per lane (d = 33 ... 300) on the shipped path -- own queue, acquire-only packets,
-    16-byte write-through stores of 2 / 4 chunks per lane, plan records -- against the oracle (dream.py:32-140), burn-in and steady state."""
+    """One wavefront per chain with 2, 4, 8 or 16 coordinates per lane (d = 33 ... 1024) on the shipped path -- own queue, acquire-only packets,
+    16-byte write-through stores of 2 ... 8 chunks per lane, plan records -- against the oracle (dream.py:32-140), burn-in and steady state."""
     params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) + 1.0))
     X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
     _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, X0, 9, dict(del_pairs=pairs, n_cr=3, burnin_gen=4, n_cr_gen=2), hist_rows=(4, 9))
+
+
+def test_widest_rows_run_on_the_stream_and_equal_the_oracle():
+    """1024 < d <= 2048: 16 coordinate pairs per lane -- the update kernels spill to scratch memory, which the HIP runtime provisions for its own
+    queues only, so these samplers launch on the HIP stream (launch_stats says so); results against the oracle as everywhere.  Beyond 2048: refused."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    N, d = 24, 1800
+    params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) + 1.0))
+    kw = dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2)
+    eng = HipEngine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=5, **kw)
+    ora = R.OracleSampler(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, **kw)
+    X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    eng.set_state(X0)
+    ora.set_state(X0)
+    ls0 = eng.launch_stats()
+    eng.begin_run()
+    eng.step(9)
+    eng.synchronize()
+    ora.run(9)
+    ls = eng.launch_stats()
+    assert ls["stream"] - ls0["stream"] == 18 and ls["direct"] == ls0["direct"], (ls0, ls)
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+    np.testing.assert_allclose(eng.get_state(), ora.X, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(eng.get_history(), np.stack(ora.history, axis=0), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+    eng.close()
+    with pytest.raises(L.BpmError, match="dim > 2048 not supported"):
+        HipEngine(algo=R.ALGO_DREAM, n_chains=N, dim=2050, target_id=R.TARGET_GAUSS_EQUICORR,
+                  target_params=R.gauss_equicorr_params(0.3, np.ones(2050)), seed=5, **kw)
