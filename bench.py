@@ -337,7 +337,7 @@ def connect_exchange(eng, dist, rank, world, want):
     return dict(mode="replay", why="push exchange not available (%s)" % why)
 
 
-def validate_exchange(eng, dist, X0, make_single, candidates, gens=150):
+def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000):
     """Which exchange the timed run uses is decided by a RUN, not by what connected: `gens` generations with CR adaptation (so the per-update
     statistics travel too) from the same start, once on a single-rank sampler holding the whole population on this rank's own GPU (what
     the reference computes on one MPI rank, demc.py:63-151) and then under each candidate in order -- push with agent-scope fences (cheapest),
@@ -392,6 +392,7 @@ def validate_exchange(eng, dist, X0, make_single, candidates, gens=150):
             eng.set_exchange(mode=cand)
             eng.set_adapt_state(t_abs=0)
             return dict(mode="push" if cand.startswith("push") else cand, fence_scope={"push-agent": "agent", "push": "system"}.get(cand),
+                        candidate=cand, candidates_left=[c for c in candidates[candidates.index(cand) + 1:] if not (push_dead and c.startswith("push"))],
                         validation=log)
     raise SystemExit("bench.py: no exchange reproduced the single-rank run on every rank: " + json.dumps(log))
 
@@ -498,9 +499,8 @@ def main(argv=None):
         def make_single():
             return HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42, device=local_rank,
                              del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
-        exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands))
-    eng.set_state(X0)
-    eng.reserve_history(1 + total_gens)
+        eng.reserve_history(1 + total_gens)
+        exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands, gens=min(1000, total_gens)))
 
     def fence():
         eng.synchronize()
@@ -508,108 +508,131 @@ def main(argv=None):
         if dist is not None:
             dist.barrier()
 
-    eng.begin_run()
-    # ---- pre-heat: the same steady-state kernels on a scratch sampler without history, for a fixed wall time
-    preheat = dict(seconds=0.0, generations=0)
-    if args.preheat > 0:
-        heat = HipEngine(algo=L.ALGO_DREAM, n_chains=CHAINS_PER_GPU, dim=DIM, target_id=tid, target_params=tparams, seed=7,
-                         device=local_rank, del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
-        heat.set_state(X0[:CHAINS_PER_GPU])
-        heat.begin_run()
+    # The measurement below runs once.  At N > 1 it runs again under the next (more conservative) exchange candidate if the ranks' replicas
+    # are not bit-identical at its end: a run whose replicas diverged is not a measurement (validate_exchange has passed 1000 generations by then,
+    # so this is the net under a rare ordering fault of the cheaper fences); with no candidate left the bench fails without a line.
+    attempts = []
+    while True:
+        eng.set_state(X0)
+        eng.reserve_history(1 + total_gens)
+        eng.begin_run()
+        # ---- pre-heat: the same steady-state kernels on a scratch sampler without history, for a fixed wall time
+        preheat = dict(seconds=0.0, generations=0)
+        if args.preheat > 0:
+            heat = HipEngine(algo=L.ALGO_DREAM, n_chains=CHAINS_PER_GPU, dim=DIM, target_id=tid, target_params=tparams, seed=7,
+                             device=local_rank, del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
+            heat.set_state(X0[:CHAINS_PER_GPU])
+            heat.begin_run()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < args.preheat:
+                heat.step(500)
+                heat.synchronize()
+                preheat["generations"] += 500
+            preheat["seconds"] = time.perf_counter() - t0
+            heat.close()
+        # ---- burn-in with CR adaptation: timed separately, never part of `value`
+        fence()
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < args.preheat:
-            heat.step(500)
-            heat.synchronize()
-            preheat["generations"] += 500
-        preheat["seconds"] = time.perf_counter() - t0
-        heat.close()
-    # ---- burn-in with CR adaptation: timed separately, never part of `value`
-    fence()
-    t0 = time.perf_counter()
-    eng.step(BURNIN_GEN)
-    fence()
-    burn_s = time.perf_counter() - t0
-    # ---- warm-up: W generations, the last of them through the same timed entry point as the timed region (the first
-    # event-bound dispatch of a process sets up profiling signals: 10-30 us of host time, once)
-    if args.warmup > 1:
-        eng.step(args.warmup - 1)
-    if args.warmup > 0:
-        eng.step_timed(1)          # (reads the events too: every host-side path of the timed call has run once)
-    fence()
-    # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two time stamps
-    # bound to the first and the last update-kernel dispatch of the same K generations (bpm_step_timed; it returns with the
-    # sampler's queue / stream drained).
-    t0 = time.perf_counter()
-    eng.step_timed(args.steps, read=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    ev_ms, ev_launches = eng.last_step_time()
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    value = n_chains * args.steps / el
-
-    # ---- dominant kernel (phase_fused_kernel): 2 launches per generation, back to back on one queue; at
-    # N = 1 nothing else runs in the region, so event time / launches is its average launch duration
-    # (inter-launch gaps included; rocprofv3 --kernel-trace gives the gap-free figure, profiles/).
-    n_launch = ev_launches
-    k_avg_ms = ev_ms / max(n_launch, 1)
-    units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
-    achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-    # cross-check at N = 1: an event pair around every launch (bpm_step_profiled exchanges with the dense all-gather: not part of an N > 1 run)
-    pair_ms, pair_n = eng.step_profiled(32) if world == 1 and not use_dist else (0.0, 1)
-    fence()
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # HBM bytes per launch from rocprofv3 --pmc (offline)
-    if os.path.exists(tfile) and world == 1 and CHAINS_PER_GPU == 8192:
-        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-
-    extra = {"evaluated": False}
-    if not args.no_moments:
-        # parity gate reported with the number: posterior moments of the post-burn-in rows vs the
-        # analytic ones (mean 0, var_i = i+1), from the on-device reduction over this rank's rows.  A short timed
-        # region (the driver's 20 generations) is extended by untimed generations: 52 correlated generations say nothing.
-        post = args.warmup + args.steps + 32
-        if post < POSTERIOR_MIN_GENS:
-            eng.step(POSTERIOR_MIN_GENS - post)
-            fence()
-            post = POSTERIOR_MIN_GENS
-        n_burn = (1 + BURNIN_GEN) * n_chains
-        cnt, s1, s2, sh = eng.reduce_moments(n_burn)
+        eng.step(BURNIN_GEN)
+        fence()
+        burn_s = time.perf_counter() - t0
+        # ---- warm-up: W generations, the last of them through the same timed entry point as the timed region (the first
+        # event-bound dispatch of a process sets up profiling signals: 10-30 us of host time, once)
+        if args.warmup > 1:
+            eng.step(args.warmup - 1)
+        if args.warmup > 0:
+            eng.step_timed(1)          # (reads the events too: every host-side path of the timed call has run once)
+        fence()
+        # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two time stamps
+        # bound to the first and the last update-kernel dispatch of the same K generations (bpm_step_timed; it returns with the
+        # sampler's queue / stream drained).
+        t0 = time.perf_counter()
+        eng.step_timed(args.steps, read=False)
+        torch.cuda.synchronize()
         if dist is not None:
-            pack = torch.tensor(np.concatenate([[cnt], s1, s2]), dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(pack)
-            pack = pack.cpu().numpy()
-            cnt, s1, s2 = pack[0], pack[1:1 + DIM], pack[1 + DIM:]
-        mean = sh + s1 / cnt
-        var = s2 / cnt - (s1 / cnt) ** 2
-        sig2 = np.arange(DIM) + 1.0
-        st = eng.stats()
-        acc = st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
-        vr = float(np.mean(var / sig2))
-        mm = float(np.max(np.abs(mean) / np.sqrt(sig2)))
-        extra = dict(evaluated=True, generations=int(post), rows=int(cnt),
-                     # the gate: pooled variance ratio within 1 % of the analytic value, every mean within 0.05 sigma
-                     # (tests/test_gpu_api.py::test_posterior_moments_at_baseline_sizes is the asserted form)
-                     var_ratio_mean=vr, max_abs_mean_over_sigma=mm, gate_pass=bool(abs(vr - 1.0) < 0.01 and mm < 0.05),
-                     var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)),
-                     acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
+            dist.barrier()
+        el = time.perf_counter() - t0
+        ev_ms, ev_launches = eng.last_step_time()
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        value = n_chains * args.steps / el
 
-    import hashlib
-    state_sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]   # (A/B of launch paths: same bits)
-    lstat = eng.launch_stats()
-    xstat = eng.exchange_stats() if use_dist else None
-    # N > 1: what every rank saw -- its update / exchange kernel periods and the size of the world its exchange runs in
-    per_rank = None
-    if dist is not None:
-        mine = dict(rank=rank, device=local_rank, avg_launch_us=k_avg_ms * 1e3, launches_timed=int(n_launch),
-                    exchange=xstat, update_dispatches=dict(direct_aql_queue=lstat["direct"], hip_stream=lstat["stream"]),
-                    final_state_sha256_16=state_sha)
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        # ---- dominant kernel (phase_fused_kernel): 2 launches per generation, back to back on one queue; at
+        # N = 1 nothing else runs in the region, so event time / launches is its average launch duration
+        # (inter-launch gaps included; rocprofv3 --kernel-trace gives the gap-free figure, profiles/).
+        n_launch = ev_launches
+        k_avg_ms = ev_ms / max(n_launch, 1)
+        units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
+        achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        # cross-check at N = 1: an event pair around every launch (bpm_step_profiled exchanges with the dense all-gather: not part of an N > 1 run)
+        pair_ms, pair_n = eng.step_profiled(32) if world == 1 and not use_dist else (0.0, 1)
+        fence()
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # HBM bytes per launch from rocprofv3 --pmc (offline)
+        if os.path.exists(tfile) and world == 1 and CHAINS_PER_GPU == 8192:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+
+        extra = {"evaluated": False}
+        if not args.no_moments:
+            # parity gate reported with the number: posterior moments of the post-burn-in rows vs the
+            # analytic ones (mean 0, var_i = i+1), from the on-device reduction over this rank's rows.  A short timed
+            # region (the driver's 20 generations) is extended by untimed generations: 52 correlated generations say nothing.
+            post = args.warmup + args.steps + 32
+            if post < POSTERIOR_MIN_GENS:
+                eng.step(POSTERIOR_MIN_GENS - post)
+                fence()
+                post = POSTERIOR_MIN_GENS
+            n_burn = (1 + BURNIN_GEN) * n_chains
+            cnt, s1, s2, sh = eng.reduce_moments(n_burn)
+            if dist is not None:
+                pack = torch.tensor(np.concatenate([[cnt], s1, s2]), dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(pack)
+                pack = pack.cpu().numpy()
+                cnt, s1, s2 = pack[0], pack[1:1 + DIM], pack[1 + DIM:]
+            mean = sh + s1 / cnt
+            var = s2 / cnt - (s1 / cnt) ** 2
+            sig2 = np.arange(DIM) + 1.0
+            st = eng.stats()
+            acc = st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
+            vr = float(np.mean(var / sig2))
+            mm = float(np.max(np.abs(mean) / np.sqrt(sig2)))
+            extra = dict(evaluated=True, generations=int(post), rows=int(cnt),
+                         # the gate: pooled variance ratio within 1 % of the analytic value, every mean within 0.05 sigma
+                         # (tests/test_gpu_api.py::test_posterior_moments_at_baseline_sizes is the asserted form)
+                         var_ratio_mean=vr, max_abs_mean_over_sigma=mm, gate_pass=bool(abs(vr - 1.0) < 0.01 and mm < 0.05),
+                         var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)),
+                         acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
+
+        import hashlib
+        state_sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]   # (A/B of launch paths: same bits)
+        if os.environ.get("BENCH_TEST_FIRST_ATTEMPT_DIVERGES") and not attempts and rank == world - 1:
+            state_sha = "0" * 16          # rehearsal hook: exercises the second measurement under the next exchange candidate
+        lstat = eng.launch_stats()
+        xstat = eng.exchange_stats() if use_dist else None
+        # N > 1: what every rank saw -- its update / exchange kernel periods and the size of the world its exchange runs in
+        per_rank = None
+        if dist is not None:
+            mine = dict(rank=rank, device=local_rank, avg_launch_us=k_avg_ms * 1e3, launches_timed=int(n_launch),
+                        exchange=xstat, update_dispatches=dict(direct_aql_queue=lstat["direct"], hip_stream=lstat["stream"]),
+                        final_state_sha256_16=state_sha)
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        if per_rank is None or len(set(p_["final_state_sha256_16"] for p_ in per_rank)) == 1:
+            break
+        attempts.append(dict(exchange=exchange_info.get("candidate"), replicas_identical=False))
+        left = exchange_info.get("candidates_left") or []
+        if not left:
+            if rank == 0:
+                sys.stderr.write("bench.py: the ranks' replicas differ at the end of the run and no further exchange candidate is left: " + json.dumps(attempts) + "\n")
+            return 3
+        if rank == 0:
+            sys.stderr.write("bench.py: the ranks' replicas differ under exchange %r: measuring again under %r\n" % (exchange_info.get("candidate"), left[0]))
+        eng.set_exchange(mode=left[0])
+        eng.set_adapt_state(t_abs=0)
+        exchange_info.update(mode="push" if left[0].startswith("push") else left[0], candidate=left[0], candidates_left=left[1:],
+                             fence_scope={"push-agent": "agent", "push": "system"}.get(left[0]))
     eng.close()
     if rank == 0:
         copy_gbs = measured_copy_bandwidth(torch, local_rank)
@@ -649,6 +672,7 @@ def main(argv=None):
         if per_rank is not None:
             out["ranks"] = per_rank
             out["config"]["replicas_identical"] = len(set(p["final_state_sha256_16"] for p in per_rank)) == 1
+            out["config"]["exchange"]["attempts_discarded"] = attempts
         if world == 1 and not use_dist and not args.no_other_configs and CHAINS_PER_GPU == 8192:
             out["configs"] = other_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
