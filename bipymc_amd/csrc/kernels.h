@@ -1091,6 +1091,11 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
         tf[0] = alpha; tf[1] = ll_prop; tf[2] = wk.delta; tf[3] = wk.gamma;
     }
+    // push exchange: a wavefront ends only when its stores into the peers' replicas have been acknowledged at system scope (gfx942 / gfx950 count
+    // stores in vmcnt: the #error at the top of this file).  The packet of this kernel may carry no release fence (agent-scope mode), and the flag
+    // that announces this half generation to the peers is stored by the NEXT packet of the queue: with this wait "kernel complete" implies "pushes
+    // performed" by the ISA's own rules rather than by the order in which a fabric happens to deliver posted writes.
+    if (a.n_peers) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // The kernel argument block is read with scalar loads.  Left alone, the compiler loads each field right before its
