@@ -1535,6 +1535,7 @@ __global__ void push_copy_kernel(const double* src, const unsigned long long* ta
     const double v = src[i];
     for (uint32_t p = 0; p < world; ++p)
         if (p != me) __hip_atomic_store(reinterpret_cast<double*>(tab[p]) + off + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (as in finish_update: pushes acknowledged before the wavefront ends)
 }
 
 // Connection self-test of the push exchange: every rank writes (seed + me) into probe[me] of every other rank's control block.
