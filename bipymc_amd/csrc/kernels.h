@@ -1095,6 +1095,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     // stores in vmcnt: the #error at the top of this file).  The packet of this kernel may carry no release fence (agent-scope mode), and the flag
     // that announces this half generation to the peers is stored by the NEXT packet of the queue: with this wait "kernel complete" implies "pushes
     // performed" by the ISA's own rules rather than by the order in which a fabric happens to deliver posted writes.
+    // (The GCN / CDNA ISA manuals describe S_ENDPGM as implying S_WAITCNT 0, which would make this redundant -- and the same wait behind the
+    // single-GPU write-through stores measured free at every size but one: profiles/r03_wave_end_store_wait.txt.  Written out where another GPU
+    // depends on it.)
     if (a.n_peers) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
