@@ -32,8 +32,16 @@ def test_push_exchange_local_group_equals_single_rank(case, R):
     assert nd == 0 and ns > 0
 
 
+@pytest.mark.parametrize("case,R", [("dream_gauss700", 2), ("dream_gauss700", 4), ("dream_gauss1300", 2)])
+def test_push_exchange_with_wide_rows(case, R):
+    """d = 700 / 1300 (16 / 32 coordinates per lane, the general update kernel; the widest shape spills to scratch memory) over the push exchange."""
+    from _push_worker import local_group_check
+    nd, ns = local_group_check(case, R)
+    assert nd == 0 and ns > 0
+
+
 @pytest.mark.parametrize("case,R", [("dream_gauss100", 2), ("dream_gauss100_long", 4), ("dream_mix8_outlier", 4), ("dream_gauss100", 8),
-                                    ("demc_banana_snooker", 8)])
+                                    ("demc_banana_snooker", 8), ("dream_gauss700", 2)])
 def test_push_exchange_local_group_with_a_queue_per_rank(case, R):
     """The same with every rank on an AQL queue of its own (BPM_TEST_PATHS=groupqueues, read at library load: a child process): the
     ranks' one-wavefront barrier kernels announce and WAIT FOR EACH OTHER across queues inside one process -- what the ranks of a
@@ -71,7 +79,7 @@ def _run_processes(case, R, tmp_path):
 
 
 @pytest.mark.parametrize("case,R", [("dream_gauss100", 2), ("dream_gauss100", 4), ("dream_gauss100_long", 2), ("dream_mix8_outlier", 4), ("demc_banana_snooker", 2),
-                                    ("cfg4_shape", 4)])
+                                    ("cfg4_shape", 4), ("dream_gauss700", 2)])
 def test_push_exchange_between_processes_sharing_the_gpu(case, R, tmp_path):
     """R processes, one GPU, buffers mapped with hipIpcOpenMemHandle, every rank's kernels on its own AQL queue."""
     ref = _single(case, world=R)
