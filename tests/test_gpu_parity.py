@@ -452,6 +452,9 @@ def test_gpu_reproduces_committed_engine_fixture(golden_dir):
     (R.ALGO_DREAM, 100, 64, dict(burnin_gen=5, n_cr_gen=1)),
     (R.ALGO_DEMC, 2, 24, dict(p_snooker=0.3)),
     (R.ALGO_DEMC, 3, 10, dict()),
+    (R.ALGO_DREAM, 600, 12, dict(burnin_gen=5, n_cr_gen=1)),         # 16 coordinates per lane
+    (R.ALGO_DREAM, 1201, 10, dict(burnin_gen=4, n_cr_gen=1)),        # 32 coordinates per lane, odd d
+    (R.ALGO_DEMC, 2000, 8, dict(p_snooker=0.3)),
 ])
 def test_propose_commit_path_against_oracle(algo, d, N, kw):
     """The propose / commit kernels (arbitrary Python ln_like_fn: samplers.py:36-43) compared with OracleSampler(ll_fn=...)
@@ -471,6 +474,7 @@ def test_propose_commit_path_against_oracle(algo, d, N, kw):
     ora.set_state(X0)
     eng.begin_run()
     n_gens = 9
+    prev = X0
     for g in range(n_gens):
         ora.trace = []
         for ph in range(2):
@@ -482,7 +486,9 @@ def test_propose_commit_path_against_oracle(algo, d, N, kw):
         acc_o = np.zeros(N, dtype=bool)
         for phn in ("phase0", "phase1"):
             acc_o[tr[phn]["ids"]] = tr[phn]["accepted"]
-        changed = np.any(eng.get_state() != (ora.history[-2] if g else X0), axis=1)
+        now = eng.get_state()
+        changed = np.any(now != prev, axis=1)        # (against the ENGINE's previous state: a snooker proposal of a wide row differs from the
+        prev = now                                   #  oracle's in the last bits -- another summation order of its dot products)
         # a chain moved iff the oracle accepted it (proposals differ from the current state with probability 1)
         assert np.array_equal(changed, acc_o), g
         np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-11, atol=1e-13)
