@@ -332,12 +332,14 @@ def connect_exchange(eng, dist, rank, world, want):
     why = "; ".join("rank %d: %s" % (i, o[1]) for i, o in enumerate(seen) if o[1]) or "self-test failed on some rank"
     if want == "push":
         raise SystemExit("bench.py: --exchange push but the push exchange is not available: " + why)
+    if want == "push-or-nothing":                                      # (a world without an RCCL communicator: the caller creates another one)
+        return dict(mode=None, why=why)
     if eng.exchange_stats()["push_connected"]:
         eng.set_exchange(mode="replay")
     return dict(mode="replay", why="push exchange not available (%s)" % why)
 
 
-def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000):
+def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000, fatal=True):
     """Which exchange the timed run uses is decided by a RUN, not by what connected: `gens` generations with CR adaptation (so the per-update
     statistics travel too) from the same start, once on a single-rank sampler holding the whole population on this rank's own GPU (what
     the reference computes on one MPI rank, demc.py:63-151) and then under each candidate in order -- push with agent-scope fences (cheapest),
@@ -394,6 +396,8 @@ def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000):
             return dict(mode="push" if cand.startswith("push") else cand, fence_scope={"push-agent": "agent", "push": "system"}.get(cand),
                         candidate=cand, candidates_left=[c for c in candidates[candidates.index(cand) + 1:] if not (push_dead and c.startswith("push"))],
                         validation=log)
+    if not fatal:
+        return dict(mode=None, validation=log)
     raise SystemExit("bench.py: no exchange reproduced the single-rank run on every rank: " + json.dumps(log))
 
 
@@ -466,21 +470,20 @@ def main(argv=None):
     n_chains = CHAINS_PER_GPU * world
     target = Gauss_100D(rho=0.5, dim=DIM)
     tid, tparams, _ = target._bpm_target_spec()
-    uid = None
-    if use_dist:
-        box = [(HipEngine.push_uid() if args.share_gpu else HipEngine.unique_id()) if rank == 0 else None]
+
+    def make_engine(uid):
+        return HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42,
+                         device=local_rank, rank=rank, world_size=world, nccl_uid=uid,
+                         del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
+
+    def make_single():
+        return HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42, device=local_rank,
+                         del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
+
+    def rccl_uid():
+        box = [HipEngine.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-    eng = HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42,
-                    device=local_rank, rank=rank, world_size=world, nccl_uid=uid,
-                    del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
-    # ---- N > 1: how the ranks exchange state where the reference calls comm.Allgather (demc.py:93-94,116-117).  Default: the push
-    # exchange (owners store accepted rows straight into the peers' replicas through IPC-mapped buffers; include/bipymc_hip.h), chosen
-    # COLLECTIVELY -- only when every rank could map every peer and the connection self-test passed everywhere; otherwise accept bytes
-    # through RCCL + replay.  --exchange forces one.
-    exchange_info = None
-    if use_dist:
-        exchange_info = connect_exchange(eng, dist, rank, world, args.exchange)
+        return box[0]
     # Synthetic start: exact draws of the target (x_i = sigma_i (sqrt(rho) g + sqrt(1-rho) e_i)), so the
     # timed region is the stationary regime and the moment gate below tests invariance.  (From the
     # reference's default start -- theta_0 = 0 + 1e-3 jitter, SURVEY 8(d) -- or an independent over-dispersed one the
@@ -489,18 +492,47 @@ def main(argv=None):
     X0 = np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((n_chains, 1))
                                           + np.sqrt(0.5) * rs.standard_normal((n_chains, DIM)))
     total_gens = BURNIN_GEN + max(args.warmup + args.steps + 32, POSTERIOR_MIN_GENS) + 64
-    if world > 1:
-        # candidates in order of cost; --exchange restricts the list (and then failing is fatal).  Ranks sharing one GPU have no RCCL.
-        if args.exchange in ("replay", "rows", "dense"):
-            cands = [args.exchange]
-        else:
-            cands = (["push-agent", "push"] if exchange_info["mode"] == "push" else []) + ([] if args.share_gpu or args.exchange == "push" else ["replay", "dense"])
-
-        def make_single():
-            return HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42, device=local_rank,
-                             del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False)
-        eng.reserve_history(1 + total_gens)
-        exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands, gens=min(1000, total_gens)))
+    # ---- N > 1: how the ranks exchange state where the reference calls comm.Allgather (demc.py:93-94,116-117).  First a world WITHOUT an RCCL
+    # communicator of the library's own: the push exchange (owners store accepted rows straight into the peers' replicas through IPC-mapped
+    # buffers; include/bipymc_hip.h) needs none, and nothing of RCCL can then stand between the run and its number.  It is taken only when every
+    # rank mapped every peer, the connection self-test passed everywhere AND 1000 generations reproduce a single-rank run bit for bit
+    # (validate_exchange).  Otherwise the sampler is created again with a communicator and the RCCL exchanges are tried the same way.
+    # --exchange restricts the candidates (and then failing is fatal).  Ranks sharing one GPU (--share-gpu) have no RCCL at all.
+    exchange_info = None
+    eng = None
+    if not use_dist:
+        eng = make_engine(None)
+    elif world == 1:                                   # BPM_FORCE_DIST=1: the one-rank rehearsal of the RCCL path
+        eng = make_engine(rccl_uid())
+        exchange_info = connect_exchange(eng, dist, rank, world, args.exchange)
+    else:
+        tried = []
+        if args.exchange in (None, "push"):
+            eng = make_engine(HipEngine.push_uid())
+            exchange_info = connect_exchange(eng, dist, rank, world, "push-or-nothing")
+            if exchange_info["mode"] == "push":
+                eng.reserve_history(1 + total_gens)
+                got = validate_exchange(eng, dist, X0, make_single, ["push-agent", "push"], gens=min(1000, total_gens), fatal=False)
+                tried += got["validation"]
+                if got.get("mode"):
+                    exchange_info.update(got)
+                else:
+                    exchange_info = dict(mode=None, why="no push candidate reproduced the single-rank run")
+            if exchange_info["mode"] != "push":
+                tried.append(dict(exchange="push", ok=False, why=exchange_info.get("why")))
+                dist.barrier()                         # (nobody unmaps while a peer may still be inside its last call)
+                eng.close()
+                eng = None
+                if args.exchange == "push" or args.share_gpu:
+                    raise SystemExit("bench.py: the push exchange is not available: " + json.dumps(tried))
+        if eng is None:
+            eng = make_engine(rccl_uid())
+            eng.reserve_history(1 + total_gens)
+            cands = [args.exchange] if args.exchange in ("replay", "rows", "dense") else ["replay", "dense"]
+            eng.set_exchange(mode=cands[0])
+            exchange_info = dict(why="--exchange" if args.exchange in cands else "push exchange not available or not validated")
+            exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands, gens=min(1000, total_gens)))
+            exchange_info["validation"] = tried + exchange_info["validation"]
 
     def fence():
         eng.synchronize()
