@@ -436,6 +436,7 @@ def main(argv=None):
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before anything initialises HSA: dmabuf IPC, what hipIpcGetMemHandle and RCCL need on this pool)
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
     ndev = torch.cuda.device_count()
     if ndev <= 0:
