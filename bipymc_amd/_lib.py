@@ -6,6 +6,10 @@ the engine fails loudly.
 import ctypes as C
 import os
 
+# dmabuf IPC (hipIpcGetMemHandle of the push exchange, RCCL): takes effect only if nothing has started HSA yet -- import this package (or
+# set the variable) before torch in a multi-process run; harmless in a single process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPM_LIB_PATH") or os.path.join(_HERE, "libbipymc_hip.so")   # override: experiment builds (tools/)
 
