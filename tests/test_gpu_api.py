@@ -290,10 +290,21 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
+@pytest.mark.parametrize("exchange", ["replay", "rows", "dense"])
+@pytest.mark.parametrize("case", ["dream_gauss900", "dream_gauss1100"])
+def test_multi_rank_equals_single_rank_with_wide_rows(case, exchange):
+    """d = 900 / 1100: 16 / 32 coordinates per lane (the latter spills to scratch memory) through the RCCL exchanges' kernels, two emulated ranks."""
+    _multi_rank_case(case, 2, exchange)
+
+
 @pytest.mark.parametrize("exchange", ["replay", "rows", "rows_overflow", "dense"])
-@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8", "demc_banana_snooker", "dream_gauss7_pairs2", "dream_gauss900", "dream_gauss1100"])
+@pytest.mark.parametrize("case", ["dream_gauss100", "dream_mix8", "demc_banana_snooker", "dream_gauss7_pairs2"])
 @pytest.mark.parametrize("R", [2, 4])
 def test_multi_rank_equals_single_rank_on_device(case, R, exchange):
+    _multi_rank_case(case, R, exchange)
+
+
+def _multi_rank_case(case, R, exchange):
     """The world_size > 1 device path (rank blocks of the exchange buffer, per-rank history / ln_like /
     Welford / accept counters, local-chain launch mode, CR statistics travelling in the gathered block)
     emulated with R handles on ONE GPU (bpm_local_group_step; the RCCL all-gather replaced by device
@@ -312,8 +323,6 @@ def test_multi_rank_equals_single_rank_on_device(case, R, exchange):
     elif case == "demc_banana_snooker":
         spec, algo, N, kw = banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 40, dict(p_snooker=0.3)
     elif case in ("dream_gauss900", "dream_gauss1100"):       # 16 / 32 coordinates per lane (the latter spills to scratch)
-        if R == 4 or exchange == "rows_overflow":
-            pytest.skip("one world size and one capacity are enough for the wide shapes")
         spec, algo, N, kw = d100_gauss.Gauss_100D(dim=int(case[11:]))._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=6, n_cr_gen=2)
     else:
         spec, algo, N, kw = d100_gauss.Gauss_100D(dim=7)._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=20, n_cr_gen=2, del_pairs=2)
