@@ -471,6 +471,7 @@ struct bpm_sampler {
     // per-generation cache (host-callback path keeps it between propose and commit)
     PhaseArgs cur_args[2];
     bool gen_adapt_on = false;
+    bool gen_cr_reduce = false;       // this generation's (delta, cr) slots are reduced (adaptation on AND the gate of dream.py:123 open)
 };
 
 
@@ -1297,6 +1298,10 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     if (flip) { std::swap(a_off, b_off); std::swap(a_n, b_n); }
     const bool adapt_on = dream && (s->cfg.burnin_gen > s->k_gen);          // dream.py:92
     s->gen_adapt_on = adapt_on;
+    // the CR statistics of a generation are reduced only when some update could contribute: while the chains' histories are not longer than
+    // n_cr_gen (dream.py:123) every slot says "no update" and the reduction would leave p_cr, delta_m and n_cr_updates as they are -- two
+    // dependent dispatches (6 us at cfg2) for nothing, in the first n_cr_gen generations of every fresh run
+    s->gen_cr_reduce = adapt_on && s->rows_logical > s->cfg.n_cr_gen;
     if (adapt_on && s->w_rows != s->rows_logical) {
         if (!s->cfg.keep_history || s->hist_rows != s->rows_logical)
             return fail("CR adaptation needs the chain history (keep_history=1) to rebuild its moments");
@@ -1420,7 +1425,8 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
 }
 
 static int finish_generation(bpm_sampler* s) {
-    if (s->gen_adapt_on) {
+    if (s->gen_adapt_on && !s->gen_cr_reduce) s->w_rows += 1;       // (the update kernels advanced the Welford moments all the same)
+    if (s->gen_cr_reduce) {
         // this generation's (delta, cr) slots -> partial sums -> totals, p_cr (kernels.h: "CR reduction in two dispatches"; beyond
         // 65536 chains ONE dispatch whose last workgroup folds)
         const uint32_t span = cr_part_span(s->N), nb = (s->N + span - 1) / span;
@@ -1746,7 +1752,7 @@ static int group_generation(const Group& g, int64_t n_ahead, int xmode, PhaseLau
     for (int r = 0; r < g.R; ++r) { bind_rank_queue(g.h[r]); CK(finish_generation(g.h[r])); }
     // push exchange during CR adaptation: the next generation's updates write their (delta, cr) slots into every replica; no rank may
     // get there while another rank's reduction kernels still read this generation's slots
-    if (xmode == 3 && g.h[0]->gen_adapt_on) CK(push_barrier(g));
+    if (xmode == 3 && g.h[0]->gen_cr_reduce) CK(push_barrier(g));
     if (g.h[0]->outlier_due) {
         // everything of the check, its cross-rank barriers included, runs on the HIP streams: queues drained before, streams after
         std::vector<StreamSection> secs;
