@@ -1038,7 +1038,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     if (a.n_peers) {
         // push exchange: the owner writes what changed into every other rank's replica (same offsets: the replicas have one layout)
         const uint32_t row_off = (uint32_t)(row_ptr(a.L, c) - a.L.G);
-        const bool slots = ALGO == ALGO_DREAM && a.adapt_on && q == 0;       // CR statistics of EVERY update travel during burn-in (dream.py:92)
+        // CR statistics of EVERY update travel during burn-in (dream.py:92) -- once the gate of dream.py:123 is open: before that nobody reduces
+        // them (sampler.hip: gen_cr_reduce), and the first generation behind the gate rewrites every chain's slots in every replica
+        const bool slots = ALGO == ALGO_DREAM && a.adapt_on && a.cr_gate && q == 0;
         const uint32_t d_off = (uint32_t)(delta_ptr(a.L, c) - a.L.G), c_off = (uint32_t)(cridx_ptr(a.L, c) - a.L.G);
         const bool gated = a.adapt_on && a.cr_gate;
 #pragma unroll 1
