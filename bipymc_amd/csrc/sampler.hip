@@ -361,6 +361,10 @@ struct bpm_sampler {
     uint32_t* acc_count = nullptr;           // device: accepted updates per local chain, this run
     int64_t gens_this_run_local = 0;
     double* prop_buf = nullptr;
+    // host-callback path: pinned staging of what bpm_propose reads back and bpm_commit sends (work-item order)
+    int32_t* h_ids = nullptr;
+    double* h_props = nullptr;
+    double* h_aux = nullptr;
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
     int32_t* trace_i32 = nullptr;
@@ -778,6 +782,9 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (free_buffers)
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+    if (s->h_ids) (void)hipHostFree(s->h_ids);
+    if (s->h_props) (void)hipHostFree(s->h_props);
+    if (s->h_aux) (void)hipHostFree(s->h_aux);
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -1024,6 +1031,9 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         CKD(dev_alloc(&s->prop_buf, row_d));
         CKD(dev_alloc(&s->aux_buf, 2 * (size_t)s->n_local));
         CKD(dev_alloc(&s->ids_buf, s->n_local));
+        HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_ids), s->n_local * sizeof(int32_t), hipHostMallocDefault));
+        HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_props), row_d * sizeof(double), hipHostMallocDefault));
+        HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_aux), 2 * (size_t)s->n_local * sizeof(double), hipHostMallocDefault));
     }
     if (s->world > 1 && !cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
     // Test mode: a uid starting with "BPMLOCAL" makes the ranks of a world handles of ONE process on one GPU;
@@ -2385,16 +2395,18 @@ extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, i
     HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
     if (a.n_items > 0) g_propose[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
-    std::vector<int32_t> ids(s->n_local);
-    std::vector<double> props((size_t)s->n_local * s->ld);
-    HIPCK(hipMemcpyAsync(ids.data(), s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipMemcpyAsync(props.data(), s->prop_buf, props.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    // ids, proposals and the (log_corr, .) pairs come back into pinned buffers in one go; bpm_commit fills in the ln-likes and sends the pairs back
+    const int32_t* ids = s->h_ids;
+    const double* props = s->h_props;
+    HIPCK(hipMemcpyAsync(s->h_ids, s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(s->h_props, s->prop_buf, (size_t)a.n_items * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(s->h_aux, s->aux_buf, 2 * (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     // compact the active work items (work-item order is kept; commit uses the same order)
     int32_t n = 0;
     for (uint32_t w = 0; w < a.n_items; ++w) {
         if (ids[w] < 0) continue;
-        std::memcpy(out_prop + (size_t)n * s->dim, props.data() + (size_t)w * s->ld, s->dim * sizeof(double));
+        std::memcpy(out_prop + (size_t)n * s->dim, props + (size_t)w * s->ld, s->dim * sizeof(double));
         out_ids[n++] = ids[w];
     }
     *n_out = n;
@@ -2407,19 +2419,16 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
     CK(set_device(s));
     if (!s->proposed) return fail("bpm_commit: nothing proposed");
     const PhaseArgs& a = s->cur_args[s->phase];
-    // scatter the values back to work-item order
-    std::vector<int32_t> ids(s->n_local);
-    HIPCK(hipMemcpyAsync(ids.data(), s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-    std::vector<double> aux(2 * (size_t)s->n_local);
-    HIPCK(hipMemcpyAsync(aux.data(), s->aux_buf, aux.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipStreamSynchronize(s->stream));
+    // scatter the values back to work-item order (ids and the pairs are still in the pinned buffers bpm_propose filled)
+    const int32_t* ids = s->h_ids;
+    double* aux = s->h_aux;
     size_t n = 0;
     for (uint32_t w = 0; w < a.n_items; ++w) {
         if (ids[w] < 0) continue;
         if (!ll_prop) return fail("bpm_commit: null ll_prop");
         aux[2 * (size_t)w + 1] = ll_prop[n++];
     }
-    HIPCK(hipMemcpyAsync(s->aux_buf, aux.data(), aux.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipMemcpyAsync(s->aux_buf, aux, 2 * (size_t)s->n_local * sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (a.n_items > 0) g_commit[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) {       // one propose/commit per generation: apply the banked updates
