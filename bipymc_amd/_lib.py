@@ -6,12 +6,12 @@ the engine fails loudly.
 import ctypes as C
 import os
 
-# dmabuf IPC (hipIpcGetMemHandle of the push exchange, RCCL): takes effect only if nothing has started HSA yet -- import this package (or
-# set the variable) before torch in a multi-process run; harmless in a single process
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPM_LIB_PATH") or os.path.join(_HERE, "libbipymc_hip.so")   # override: experiment builds (tools/)
+# the same sources built with -DBPM_TEST_HOOKS (include/bipymc_hip_test.h): bpm_debug_* / bpm_selftest_philox and the BPM_TEST_PATHS switches.
+# Only tests and tools load it (load_test(), or BPM_LIB_PATH=<this> for a whole child process); the product library has none of it.
+TEST_LIB_PATH = os.path.join(os.path.dirname(_HERE), "build_variants", "libbipymc_test.so")
 
 ABI_VERSION = 2
 ALGO_DEMC, ALGO_DREAM, ALGO_DEMC_SYNC = 0, 1, 2
@@ -61,9 +61,6 @@ SIGNATURES = {
     "bpm_get_unique_id": (C.c_int, [C.c_char_p]),
     "bpm_create": (C.c_int, [_P(BpmConfig), _P(_H)]),
     "bpm_destroy": (C.c_int, [_H]),
-    "bpm_debug_destroy_plan": (C.c_int, [C.c_int32, C.c_int32]),
-    "bpm_debug_fail_queue": (C.c_int, [_H, C.c_int32]),
-    "bpm_debug_queue_pad": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
     "bpm_init_chains": (C.c_int, [_H, _dp, _dp]),
     "bpm_set_state": (C.c_int, [_H, _dp]),
     "bpm_get_state": (C.c_int, [_H, _dp]),
@@ -83,7 +80,6 @@ SIGNATURES = {
     "bpm_push_selftest": (C.c_int, [_P(_H), C.c_int32, _P(C.c_int32)]),
     "bpm_get_launch_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_set_launch_path": (C.c_int, [_H, C.c_int32, C.c_int32]),
-    "bpm_debug_coherence_probe": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_int64)]),
     "bpm_set_history": (C.c_int, [_H, C.c_int64, _dp, _dp]),
     "bpm_reduce_moments": (C.c_int, [_H, C.c_int64, _dp, _dp, _dp, _P(C.c_int64)]),
     "bpm_propose": (C.c_int, [_H, _dp, _ip, _ip]),
@@ -94,15 +90,24 @@ SIGNATURES = {
     "bpm_get_stats": (C.c_int, [_H, _P(BpmStats)]),
     "bpm_set_adapt_state": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64]),
     "bpm_eval_loglike": (C.c_int, [_H, _dp, C.c_int32, _dp]),
-    "bpm_selftest_philox": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, _u32p, _u32p]),
-    "bpm_debug_perm": (C.c_int, [_H, C.c_int64, C.c_int32, C.c_double, _ip, _ip, _ip]),
-    "bpm_debug_outlier_select": (C.c_int, [_H, _dp, _dp]),
-    "bpm_debug_time_kernels": (C.c_int, [_H, C.c_int32, _P(C.c_float), _P(C.c_float)]),
     "bpm_set_trace": (C.c_int, [_H, C.c_int32]),
     "bpm_get_trace": (C.c_int, [_H, _ip, _dp, _u8p]),
 }
 
+# include/bipymc_hip_test.h: exported by the test variant only
+TEST_SIGNATURES = {
+    "bpm_debug_destroy_plan": (C.c_int, [C.c_int32, C.c_int32]),
+    "bpm_debug_fail_queue": (C.c_int, [_H, C.c_int32]),
+    "bpm_debug_queue_pad": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
+    "bpm_debug_coherence_probe": (C.c_int, [C.c_int32, C.c_int32, _P(C.c_int64)]),
+    "bpm_selftest_philox": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, _u32p, _u32p]),
+    "bpm_debug_perm": (C.c_int, [_H, C.c_int64, C.c_int32, C.c_double, _ip, _ip, _ip]),
+    "bpm_debug_outlier_select": (C.c_int, [_H, _dp, _dp]),
+    "bpm_debug_time_kernels": (C.c_int, [_H, C.c_int32, _P(C.c_float), _P(C.c_float)]),
+}
+
 _lib = None
+_test_lib = None
 
 
 class BpmError(RuntimeError):
@@ -118,15 +123,48 @@ def load():
         raise ImportError(
             "bipymc_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C bipymc_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    _lib = _bind(LIB_PATH, hooks=None)
+    return _lib
+
+
+def _bind(path, hooks):
+    """hooks: True = the test surface must be there, None = bind it when it is (BPM_LIB_PATH may name a test / experiment build)"""
+    lib = C.CDLL(path)       # RTLD_LOCAL: the product and the test variant define the same symbols and may live in one process
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in TEST_SIGNATURES.items():
+        if not hooks and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
     if lib.bpm_abi_version() != ABI_VERSION:
-        raise ImportError("bipymc_amd: libbipymc_hip.so ABI %d != binding ABI %d" % (lib.bpm_abi_version(), ABI_VERSION))
-    _lib = lib
+        raise ImportError("bipymc_amd: %s ABI %d != binding ABI %d" % (os.path.basename(path), lib.bpm_abi_version(), ABI_VERSION))
     return lib
+
+
+def load_test():
+    """The test variant (build_variants/libbipymc_test.so): every entry point of the product plus include/bipymc_hip_test.h.  Tests / tools only."""
+    global _test_lib
+    if _test_lib is None:
+        if os.path.abspath(LIB_PATH) == os.path.abspath(TEST_LIB_PATH):
+            _test_lib = load()
+        else:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise ImportError("bipymc_amd: %s not found (make -C bipymc_amd/csrc builds it beside the product library)" % TEST_LIB_PATH)
+            _test_lib = _bind(TEST_LIB_PATH, hooks=True)
+    return _test_lib
+
+
+def want_dmabuf_ipc():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: what hipIpcGetMemHandle of the push exchange and RCCL need on hosts whose driver supports
+    only that mode), as a default, for the MULTI-RANK paths only -- DeMcMpi with a communicator of more than one rank, bench.py's rank
+    processes.  Not at import: it changes IPC behaviour for every HSA user of the process, single-GPU users included.  It takes effect only
+    if nothing has initialised HSA yet (set it in the launcher's environment to be sure); where it did not, bpm_push_connect's error message
+    names the variable."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def device_count():
@@ -135,7 +173,8 @@ def device_count():
     return int(n.value)
 
 
-def check(rc):
+def check(rc, lib=None):
+    """lib: the library the failing call was made on (its bpm_last_error holds the message); default the product library"""
     if rc != 0:
-        msg = load().bpm_last_error()
+        msg = (lib or load()).bpm_last_error()
         raise BpmError(msg.decode("utf-8", "replace") if msg else "libbipymc_hip error %d" % rc)

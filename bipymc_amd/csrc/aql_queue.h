@@ -202,10 +202,11 @@ class DirectQueue {
             unreleased_ = false;
             if (!next_slot()) return -1;
         }
-        // next_slot() may have put an epoch marker in front of this slot: publish it BEFORE the barrier packet, whose header is written
-        // directly -- a doorbell over an unpublished (INVALID) marker stops the packet processor for good (once in 256 drains of this kind:
-        // tests/test_gpu_api.py::test_drains_at_every_position_of_the_queues_epochs)
-        flush();
+        // The barrier packet takes the same road as every other packet: its header joins the pending list behind whatever next_slot() left
+        // there (an epoch marker), and flush() publishes the list IN ORDER, write index and doorbell last.  Round 3 wrote this one header
+        // directly and once rang the doorbell over an unpublished marker -- the packet processor then waits at an INVALID header for good
+        // (1 in 256 drains of that kind; tests/test_gpu_api.py::test_drains_at_every_position_of_the_queues_epochs).  No packet header is
+        // written outside publish order anywhere in this file now.
         auto* b = reinterpret_cast<hsa_barrier_and_packet_t*>(q_->base_address) + (widx_ & (q_->size - 1));
         std::memset(reinterpret_cast<char*>(b) + 4, 0, sizeof(*b) - 4);
         hsa_signal_store_relaxed(done_, 1);
@@ -213,10 +214,12 @@ class DirectQueue {
         const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                         (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                         (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-        __atomic_store_n(reinterpret_cast<uint32_t*>(b), (uint32_t)hdr, __ATOMIC_RELEASE);
+        if (n_unpublished_ >= MAX_UNPUBLISHED) flush();
+        pending_header_[n_unpublished_] = (uint32_t)hdr;
+        pending_packet_[n_unpublished_] = reinterpret_cast<uint32_t*>(b);
+        ++n_unpublished_;
         ++widx_;
-        hsa_queue_store_write_index_screlease(q_, widx_);
-        hsa_signal_store_screlease(q_->doorbell_signal, (hsa_signal_value_t)(widx_ - 1));
+        flush();
         const auto t0 = std::chrono::steady_clock::now();
         while (hsa_signal_load_scacquire(done_) > 0) {                       // polling: a parked thread wakes up on a slow clock
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
@@ -249,6 +252,7 @@ class DirectQueue {
         return false;
     }
     bool dead() const { return dead_; }
+#ifdef BPM_TEST_HOOKS
     // test hook (bpm_debug_queue_pad): no-op barrier packets until the next packet would take position `pos` of its epoch of 256 (pos < 255);
     // -> the write index.  Lets a test put a drain's packets at a chosen place of the ring.
     int64_t test_pad_to(uint32_t pos) {
@@ -271,6 +275,7 @@ class DirectQueue {
     }
     // test hook (bpm_debug_fail_queue): behave as if a drain had timed out; refuse != 0: and as if the queue could not be inactivated
     void test_mark_failed(bool refuse) { std::lock_guard<std::recursive_mutex> lk(mu_); failed_ = true; why_ = "failure injected by the test hook"; test_refuse_quiesce_ = refuse; }
+#endif
     const std::string& why() const { return why_; }
 
     // end-of-kernel time stamps (ns, one clock) of the dispatches that carried timing signal 0 and 1; call after drain()

@@ -114,10 +114,17 @@ constexpr int MAX_PEERS = MAX_SEG - 1;   // other ranks an owner pushes its acce
 //   flag[p]   last barrier sequence number rank p has ANNOUNCED to this rank (written by p's push_sync_kernel, read by this rank's)
 //   err       set by this rank's push_sync_kernel when a wait ran into its time limit: 1 + the rank it was waiting for
 //   probe[p]  connection self-test pattern written by rank p
+//   arena_bad[f]  connection self-test of the arena (bpm_push_selftest): words of the probe rows the peers stored into THIS rank's
+//             arena that did not arrive, under packet fences of form f (0 system scope, 1 agent scope); written by this rank only
+// A flag >= PUSH_CLOSING says "rank p is destroying its sampler" (bpm_destroy's hand-over): a rank that still waits for p learns it at once
+// (err = PUSH_ERR_CLOSED + p) instead of running into the time limit.
+constexpr unsigned long long PUSH_CLOSING = 1ull << 62;
+constexpr unsigned long long PUSH_ERR_CLOSED = 0x100ull;
 struct PushCtrl {
     unsigned long long flag[MAX_SEG];
     unsigned long long err;
-    unsigned long long pad[7];
+    unsigned long long arena_bad[2];
+    unsigned long long pad[5];
     unsigned long long probe[MAX_SEG];
 };
 struct PhaseArgs {
@@ -565,14 +572,14 @@ __device__ __forceinline__ uint32_t partner_pos(const PhaseArgs& a, uint32_t c, 
 }
 
 __device__ __forceinline__ uint32_t pos_to_chain(const PhaseArgs& a, uint32_t pos) {
-#ifdef BPM_FAKE_NO_PARTNER_HOP      // timing experiment only (wrong results): what the position -> chain id lookup of a partner costs
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_PARTNER_HOP)      // timing experiment only (wrong results): what the position -> chain id lookup of a partner costs
     return pos;                     // (profiles/r03_small_d_hops_and_position_order.txt)
 #else
     return a.perm_tab ? a.perm_tab[pos] : perm_fwd(pos, a.pk);
 #endif
 }
 __device__ __forceinline__ uint32_t own_pos_to_chain(const PhaseArgs& a, uint32_t pos) {
-#ifdef BPM_FAKE_NO_OWN_HOP          // timing experiment only (wrong results): the work item's own position -> chain id lookup
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_OWN_HOP)          // timing experiment only (wrong results): the work item's own position -> chain id lookup
     return pos;
 #else
     return a.perm_tab ? a.perm_tab[pos] : perm_fwd(pos, a.pk);
@@ -602,6 +609,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     wk.ll_cur = 0.0;
     wk.acc_prev = 0u;
     if (!a.replay) {
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)      // timing experiment only (wrong results): what the chain-indexed ln-like cache and accept counter cost
+        if (LPC < WAVE) wk.ll_cur = wk.x[0] * 1e-300; else
+#endif
         wk.ll_cur = a.ll[c - a.lo];
         // the accept counter: one wavefront per chain reads it here (a scalar load, early) and stores + 1 on accept; with several chains per
         // wavefront the read is a scattered 4-byte load per update -- there an accepted update bumps it with a device-scope atomic add without
@@ -961,7 +971,8 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #pragma unroll 1
             for (uint32_t i = regs ? 2u * P : 0u; i < MAX_PARTNERS; ++i) {
                 int32_t v = -1;
-                if (i < npart) v = regs ? (int32_t)snk_id[i - 2u * P < 3u ? i - 2u * P : 0u] : (int32_t)part.lds[i];
+                const uint32_t ks = i - 2u * P;      // (a select chain, not snk_id[ks]: a dynamically indexed array would live in scratch memory)
+                if (i < npart) v = regs ? (int32_t)(ks == 1u ? snk_id[1] : (ks == 2u ? snk_id[2] : snk_id[0])) : (int32_t)part.lds[i];
                 tr[5 + i] = v;
             }
         }
@@ -992,6 +1003,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     // every chain owns one counter, the host sums them (demc.py:143-150)
     if (q == 0) {
         if (accepted) {
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)
+            if (LPC < WAVE) {} else
+#endif
             if (LPC < WAVE) __hip_atomic_fetch_add(&a.acc_count[li], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (a.wt) __hip_atomic_store(&a.acc_count[li], wk.acc_prev + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else a.acc_count[li] = wk.acc_prev + 1u;
@@ -1010,6 +1024,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     } else if (accepted) {
         if (a.wt == 2u) {
             store_row_wt16<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)
+            if (LPC < WAVE) {} else
+#endif
             if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (a.wt) {
             store_row_wt<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
@@ -1522,7 +1539,13 @@ __global__ __launch_bounds__(WAVE) void push_sync_kernel(PushCtrl* mine, const u
         const unsigned long long t0 = wall_clock64();
         // relaxed polls (an acquire load is a load + an invalidate of the caches, in a loop, under the other ranks' running kernels: measured
         // 10 us per hand-over at 2 ranks, 118 us at 8 on one GPU); the acquire is the next packet's fence
-        while (__hip_atomic_load(&mine->flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(&mine->flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v >= PUSH_CLOSING) {      // the peer is destroying its sampler (push_close_kernel): it will never announce `seq`
+                __hip_atomic_store(&mine->err, PUSH_ERR_CLOSED + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            if (v >= seq) break;
             if (wall_clock64() - t0 > timeout_ticks) {
                 __hip_atomic_store(&mine->err, 1ull + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
@@ -1530,6 +1553,81 @@ __global__ __launch_bounds__(WAVE) void push_sync_kernel(PushCtrl* mine, const u
             __builtin_amdgcn_s_sleep(8);
         }
     }
+}
+
+// Push exchange, teardown (bpm_destroy of a connected rank of a world of processes): lane p announces PUSH_CLOSING in rank p's control block --
+// from then on p's barrier kernels do not wait for this rank, they report "closed" -- and, do_wait, polls this rank's own block until p has
+// announced the same or `timeout_ticks` have passed (no error then: the caller frees anyway; what a peer still has mapped stays alive through
+// its mapping).  Ranks that end a run together therefore unmap each other's buffers only after ALL of them have left their last kernels.
+__global__ __launch_bounds__(WAVE) void push_close_kernel(PushCtrl* mine, const unsigned long long* ctrl_tab, uint32_t world, uint32_t me, uint32_t do_wait,
+                                                          unsigned long long timeout_ticks) {
+    const uint32_t p = threadIdx.x;
+    if (p >= world || p == me) return;
+    PushCtrl* pc = reinterpret_cast<PushCtrl*>(ctrl_tab[p]);
+    __hip_atomic_store(&pc->flag[me], PUSH_CLOSING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!do_wait) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&mine->flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < PUSH_CLOSING) {
+        if (wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// Connection self-test of the ARENA (bpm_push_selftest): what an owner's update kernel does to a peer -- stores into ITS OWN rank block of the
+// peer's replica (rows, the (delta, cr) slots at the block's end) and into its block of the peer's outlier buffer -- rehearsed on the first
+// and the last row of that block, the block's last two slots and the two ends of the om block, from the same queue and under the same packet
+// fences as the real thing.  Block (region, rank b) of 64 lanes; three launches with a cross-rank barrier between them:
+//   mode 0  save: what THIS rank's arena holds in the probe regions of every other rank's block (the self-test leaves the state as it found it)
+//   mode 1  write: this rank's pattern into its own block's regions of every PEER's arena (system-scope stores, acknowledged before the wave ends)
+//   mode 2  verify + restore: this rank's arena must hold rank b's pattern in block b's regions; mismatching words are counted in bad[0]
+// A mapping that points somewhere else (a wrong handle) or stores that are not visible behind the hand-over therefore end as *ok = 0 and the
+// RCCL exchanges, not as a divergence -- or a fault -- in the first generation.
+struct ProbeGeo {
+    uint64_t blk;          // doubles per rank block of G
+    uint32_t n_local, ld;
+    uint32_t om_n;         // doubles per rank block of the om buffer (2 n_local), 0: none
+    uint32_t world, me;
+    uint32_t save_stride;  // doubles per rank in the save buffer (2 ld + 8)
+};
+constexpr int PROBE_REGIONS = 5;
+__device__ __forceinline__ void probe_region(const ProbeGeo& g, uint32_t b, int r, bool& in_om, uint64_t& off, uint32_t& len, uint32_t& save_off) {
+    in_om = r >= 3;
+    if (r == 0) { off = (uint64_t)b * g.blk; len = g.ld; save_off = 0; }
+    else if (r == 1) { off = (uint64_t)b * g.blk + (uint64_t)(g.n_local - 1u) * g.ld; len = g.ld; save_off = g.ld; }
+    else if (r == 2) { off = (uint64_t)b * g.blk + g.blk - 2u; len = 2; save_off = 2u * g.ld; }
+    else if (r == 3) { off = (uint64_t)b * g.om_n; len = g.om_n ? 2u : 0u; save_off = 2u * g.ld + 2u; }
+    else { off = (uint64_t)b * g.om_n + (g.om_n ? g.om_n - 2u : 0u); len = g.om_n ? 2u : 0u; save_off = 2u * g.ld + 4u; }
+}
+__device__ __forceinline__ double probe_pattern(unsigned long long seed, uint32_t from, int r, uint32_t j) {
+    return (double)(((seed & 0xFFFFull) << 32) + ((unsigned long long)from << 24) + ((unsigned long long)r << 20) + j) + 0.5;
+}
+__global__ __launch_bounds__(WAVE) void push_arena_probe_kernel(const unsigned long long* tab_all, ProbeGeo g, int mode, unsigned long long seed, double* save,
+                                                                unsigned long long* bad) {
+    const int r = (int)blockIdx.x;
+    const uint32_t b = blockIdx.y, lane = threadIdx.x;
+    if (b == g.me || b >= g.world) return;
+    bool in_om; uint64_t off; uint32_t len, so;
+    // mode 1: block (r, p) writes MY block's region r into peer p's arena; modes 0 / 2: block (r, b) looks at block b's region r of MY arena
+    probe_region(g, mode == 1 ? g.me : b, r, in_om, off, len, so);
+    if (len == 0) return;
+    const uint32_t where = mode == 1 ? b : g.me;
+    double* base = reinterpret_cast<double*>(tab_all[(in_om ? 2u * MAX_SEG : 0u) + where]) + off;
+    double* sv = save + (uint64_t)b * g.save_stride + so;
+    uint32_t n_bad = 0;
+    for (uint32_t j = lane; j < len; j += WAVE) {
+        if (mode == 0) {
+            // (agent-scope store / load of the saved words: the packets of the agent-scope form carry no release fence)
+            __hip_atomic_store(sv + j, __hip_atomic_load(base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (mode == 1) {
+            __hip_atomic_store(base + j, probe_pattern(seed, g.me, r, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            const double v = __hip_atomic_load(base + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v != probe_pattern(seed, b, r, j)) ++n_bad;
+            __hip_atomic_store(base + j, __hip_atomic_load(sv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (mode == 2 && n_bad) __hip_atomic_fetch_add(bad, (unsigned long long)n_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (as in finish_update: stores into the peers acknowledged before the wavefront ends)
 }
 
 // Push exchange for the rare dense blocks (outlier check: the (omega | ln-like) block of this rank's chains): n doubles from `src` to
@@ -1640,7 +1738,11 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(const PlanParams P, 
     }
     // where the record goes: by position, or (world > 1) to its slot in the owner-sorted order of its generation
     if (sidx) {
-        const uint64_t oe = (uint64_t)g * P.N + sidx[e];
+        // (a slot beyond the generation means "never assigned" -- the table is initialised to 0xFFFFFFFF: a window built without its slot pass
+        // must not scatter records through memory, which is what the faults of round 3's first push runs were: DESIGN.md section 6)
+        const uint32_t slot = sidx[e];
+        if (slot >= P.N) return;
+        const uint64_t oe = (uint64_t)g * P.N + slot;
         uint4* out = reinterpret_cast<uint4*>(plan + oe * PLAN_WORDS);
 #pragma unroll
         for (int i = 0; i < PLAN_WORDS / 4; ++i) out[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);

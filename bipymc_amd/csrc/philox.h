@@ -69,7 +69,7 @@ BPM_HD u32x4 philox_block(uint64_t seed, uint64_t subseq, uint64_t blk) {
 }
 
 BPM_HD u32x4 chain_block(uint64_t seed, uint64_t chain_id, uint64_t t, uint32_t slot) {
-#if defined(BPM_FAKE_DRAWS) && defined(__HIP_DEVICE_COMPILE__)     // ablation builds only (tools/): what do the draws cost?
+#if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_DRAWS) && defined(__HIP_DEVICE_COMPILE__)     // ablation builds only (tools/): what do the draws cost?
     uint32_t x = (uint32_t)chain_id * 0x9e3779b9u + (uint32_t)t * 0x85ebca6bu + slot * 0xc2b2ae35u + (uint32_t)seed;
     x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
     return u32x4{x, x * 0x297a2d39u, x ^ 0x5bd1e995u, x + 0x7f4a7c15u};

@@ -32,7 +32,9 @@
 
 #include "../../include/bipymc_hip.h"
 #include "kernels.h"
+#ifdef BPM_TEST_HOOKS
 #include "rocrand_check.h"
+#endif
 #include "aql_queue.h"
 
 using namespace bpm;
@@ -51,10 +53,17 @@ using namespace bpm;
 //   serial       the emulated ranks of a local group take turns on the GPU (tools/emulate_ranks.py)
 //   hosttiming   host nanoseconds spent preparing generations and inside launch calls, printed by bpm_destroy
 // Operational switches (documented in README.md): BPM_DIRECT_QUEUE=0, BPM_QUEUE_INFLIGHT, BPM_QUEUE_TIMEOUT_S, BPM_EXCHANGE, BPM_VERBOSE.
+// The PRODUCT library does not read it: BPM_TEST_PATHS, the bpm_debug_* / bpm_selftest_* entry points and the BPM_FAKE_* timing builds exist
+// only in build_variants/libbipymc_test.so (-DBPM_TEST_HOOKS, declared in include/bipymc_hip_test.h); the GPU tests that need them load
+// that variant, the parity tests run against the product library.
+#ifdef BPM_TEST_HOOKS
 static bool test_path(const char* name) {
     static const std::string all = [] { const char* e = getenv("BPM_TEST_PATHS"); return std::string(",") + (e ? e : "") + ","; }();
     return all.find(std::string(",") + name + ",") != std::string::npos;
 }
+#else
+static constexpr bool test_path(const char*) { return false; }
+#endif
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
@@ -421,6 +430,8 @@ struct bpm_sampler {
     bool push_connected = false, push_enabled = false, push_no_rccl = false;
     bool push_failed = false;      // a cross-rank wait ran into its limit: push cannot be re-enabled (bpm_set_exchange)
     bool push_agent_scope = false;          // update packets fence at agent scope instead of system scope (bpm_set_exchange(h, 3, 1))
+    bool probe_sys_ok = false, probe_agent_ok = false, probe_direct = false;   // bpm_push_selftest: the arena probe under system- / agent-scope packet
+                                                                               // fences, and whether it ran on the library's own queue
     void* peer_base[MAX_SEG] = {};          // every rank's arena as THIS process addresses it (own entry: arena)
     bool peer_opened[MAX_SEG] = {};         // mapped with hipIpcOpenMemHandle (to be closed)
     unsigned long long* tab_peerG = nullptr;    // device [MAX_PEERS]: G of the other ranks (PhaseArgs::peer_tab)
@@ -557,6 +568,7 @@ static int dev_alloc_state(T** p, size_t n, bool coherent) {
 // coherent that way), so the property itself is tested once per device: 48 dependent dispatches with acquire-only packets hand
 // every block of a 2 MB buffer from workgroup to workgroup; ordinary memory fails this in every element (tools/micro/aql_direct.cpp).
 // -> number of wrong elements (0 = every launch saw its predecessor's writes), -1 = the probe could not run
+#if defined(BPM_TEST_HOOKS) || defined(BPM_EXPERIMENT_COHERENT)
 static long long coherence_probe(bpm::DirectQueue* dq, bool coherent_alloc) {
     constexpr uint32_t NB = 4096, L = 48;
     double* x = nullptr;
@@ -580,6 +592,7 @@ static long long coherence_probe(bpm::DirectQueue* dq, bool coherent_alloc) {
     if (x) (void)hipFree(x);
     return wrong;
 }
+#endif
 #ifdef BPM_EXPERIMENT_COHERENT
 static bool state_memory_is_coherent(bpm::DirectQueue* dq, int device) {
     static std::mutex mu;
@@ -732,7 +745,9 @@ static long long g_ns_prepare = 0, g_ns_launch = 0, g_n_launch = 0;
 static std::vector<long long> g_launch_log;       // (start, end) of every launch call of the current bpm_step_timed
 static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-extern "C" int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);
+// The decision bpm_destroy takes about the sampler's device buffers, as a pure function: 1 = free them, 0 = leak them.  Buffers are freed unless
+// the queue that may still run kernels on them failed AND could not be quiesced.  (CPU-tested through the test variant: bpm_debug_destroy_plan.)
+static int destroy_plan(int queue_failed, int quiesced) { return (queue_failed != 0 && quiesced == 0) ? 0 : 1; }
 extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
 extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
 extern "C" int bpm_device_count(int32_t* out) {
@@ -767,8 +782,21 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     const int drained = leave_direct(s);
     const bool queue_failed = s->dq != nullptr && (drained != 0 || s->dq->failed());
     const bool quiet = !queue_failed || s->dq->quiesce();
-    const bool free_buffers = bpm_debug_destroy_plan(queue_failed ? 1 : 0, quiet ? 1 : 0) == 1;
+    const bool free_buffers = destroy_plan(queue_failed ? 1 : 0, quiet ? 1 : 0) == 1;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    // Push exchange between processes: the library orders the teardown itself (round 3 relied on the caller's barrier).  Announce "closing" in
+    // every peer's control block -- a peer that still waits for this rank then reports it at once instead of sitting out its limit -- and wait,
+    // bounded (BPM_PUSH_CLOSE_TIMEOUT_S, default 3), until the peers have announced the same: ranks that end a run together unmap each other's
+    // arenas only after ALL of them have left their last kernels.  A peer that is late keeps what it mapped alive through its own mapping.
+    // (Ranks of ONE process -- local test groups -- are destroyed one after the other by one host thread: nothing to order, and a peer's
+    // control block may be gone already.)
+    if (s->push_connected && s->world > 1 && !s->local_group && s->stream && s->tab_all && s->ctrl && free_buffers) {
+        static const double cto = getenv("BPM_PUSH_CLOSE_TIMEOUT_S") ? atof(getenv("BPM_PUSH_CLOSE_TIMEOUT_S")) : 3.0;
+        hipLaunchKernelGGL(push_close_kernel, dim3(1), dim3(WAVE), 0, s->stream, s->ctrl, (const unsigned long long*)(s->tab_all + MAX_SEG), s->world, s->rank,
+                           cto > 0.0 ? 1u : 0u, (unsigned long long)(std::max(0.0, cto) * 1e8));
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s->stream);
+    }
     if (s->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s->comm);
     for (uint32_t p = 0; p < (uint32_t)MAX_SEG; ++p) {
         if (s->peer_opened[p] && s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
@@ -800,9 +828,9 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     return 0;
 }
 
-// The decision bpm_destroy takes about the sampler's device buffers, as a pure function (CPU-testable: tests/test_abi.py):
-// 1 = free them, 0 = leak them.  Buffers are freed unless the queue that may still run kernels on them failed AND could not be quiesced.
-extern "C" int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced) { return (queue_failed != 0 && quiesced == 0) ? 0 : 1; }
+#ifdef BPM_TEST_HOOKS
+// ---- test hooks (include/bipymc_hip_test.h; build_variants/libbipymc_test.so only) -----------------------------------------------------
+extern "C" int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced) { return destroy_plan(queue_failed, quiesced); }
 
 // Test hook: put the handle's queue into the state a timed-out drain leaves (refuse_quiesce != 0: and make quiesce() fail as if
 // hsa_queue_inactivate had been refused).  The queue of this device is then unusable for the rest of the PROCESS -- run in a child process.
@@ -824,6 +852,7 @@ extern "C" int bpm_debug_queue_pad(bpm_handle_t s, int32_t pos, int64_t* widx) {
     if (widx) *widx = w;
     return 0;
 }
+#endif   // BPM_TEST_HOOKS
 
 extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (!cfg || !out) return fail("bpm_create: null argument");
@@ -1011,6 +1040,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         if (s->plan_on) CKD(dev_alloc(&B.plan, (size_t)s->win_K * s->N * PLAN_WORDS));
         if (s->sorted_on) {
             CKD(dev_alloc(&B.sidx, (size_t)s->win_K * s->N));
+            HIPCKD(hipMemsetAsync(B.sidx, 0xFF, (size_t)s->win_K * s->N * sizeof(uint32_t), s->stream));      // "no slot": plan_kernel skips such positions
             CKD(dev_alloc(&B.plan_count, (size_t)s->win_K * 2 * s->world));
             HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&B.count_h), (size_t)s->win_K * 2 * s->world * sizeof(uint32_t), hipHostMallocDefault));
         }
@@ -1390,6 +1420,10 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             uint32_t acc = a.upd_off;
             for (uint32_t r = 0; r < s->world; ++r) { a.seg_off[r] = acc; acc += cnt[r]; }
             for (uint32_t r = s->world; r <= (uint32_t)MAX_SEG; ++r) a.seg_off[r] = acc;
+            // (the counts size this rank's launch: a window whose slot pass did not run -- round 3's first push runs, DESIGN.md section 6 -- must be
+            // an error here, not a launch of garbage size)
+            if (acc > a.upd_off + a.n_upd || cnt[s->rank] > a.n_upd)
+                return fail("owner-sorted update records: the counts of generation " + std::to_string((long long)s->t_abs) + " exceed its half generation (window not built?)");
             a.n_seg = s->world; a.seg_me = s->rank; a.acc_by_item = 1u;
             a.rec_sorted = s->plan_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N * PLAN_WORDS;
             a.rec_tab = a.rec_sorted + (uint64_t)a.seg_off[s->rank] * PLAN_WORDS;
@@ -1557,6 +1591,9 @@ static int push_check_error(bpm_sampler* s) {
     unsigned long long e = 0;
     HIPCK(hipMemcpy(&e, &s->ctrl->err, sizeof(e), hipMemcpyDeviceToHost));
     if (e != 0) s->push_failed = true;
+    if (e >= PUSH_ERR_CLOSED)
+        return fail("push exchange: rank " + std::to_string((long long)(e - PUSH_ERR_CLOSED)) + " closed its sampler (bpm_destroy) while rank " + std::to_string(s->rank) +
+                    " was still exchanging with it: the ranks of a world must make the same sequence of calls; the replicas are no longer consistent");
     if (e != 0) return fail("push exchange: rank " + std::to_string(s->rank) + " waited longer than the limit for rank " + std::to_string((long long)e - 1) +
                             " (a rank that died, or ranks that entered bpm_step more than BPM_PUSH_TIMEOUT_S apart); the replicas are no longer consistent");
     return 0;
@@ -1782,6 +1819,19 @@ struct HostCkpt {
     int64_t k_gen, t_abs, hist_rows, rows_logical, w_rows;
 };
 
+// Does this group's generation loop go through the library's own AQL queue(s)?  A single GPU's sampler, or -- with the push exchange, where
+// nothing of the loop is a collective call -- a rank of a world; group_direct: the R ranks of a local group, each on a queue of its own.
+// (run_generations and the arena self-test of bpm_push_selftest ask the same question: the probe must take the path the updates take.)
+static bool group_goes_direct(const Group& g, bool push, bool& group_direct) {
+    bpm_sampler* s0 = g.h[0];
+    group_direct = push && g.R > 1 && !g_host_timing && !local_serial(g);
+    for (int r = 0; r < g.R && group_direct; ++r)
+        group_direct = g.h[r]->dq_private && g.h[r]->dq_enabled && !g.h[r]->dq->failed() && !g.h[r]->trace_i32 && !g.h[r]->stamps && !g.h[r]->shape_needs_scratch;
+    return group_direct ||
+           (s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && (!s0->local_group || s0->dq_private) &&
+            s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed() && !s0->shape_needs_scratch);
+}
+
 static int run_generations(const Group& g, int64_t n_gens) {
     bpm_sampler* s0 = g.h[0];
     PhaseLaunch fn = pick_fused(s0);
@@ -1802,12 +1852,8 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // on the HIP stream between two drains (StreamSection); the synchronous mode, tracing and everything with an exchange
             // stay on the stream altogether.
             // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
-            bool group_direct = push && g.R > 1 && !g_host_timing && !local_serial(g);
-            for (int r = 0; r < g.R && group_direct; ++r)
-                group_direct = g.h[r]->dq_private && g.h[r]->dq_enabled && !g.h[r]->dq->failed() && !g.h[r]->trace_i32 && !g.h[r]->stamps && !g.h[r]->shape_needs_scratch;
-            const bool direct = group_direct ||
-                                (s0->dq && s0->dq_enabled && g.R == 1 && ((!g.rccl && s0->world == 1) || push) && (!s0->local_group || s0->dq_private) &&
-                                 s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed() && !s0->shape_needs_scratch);
+            bool group_direct = false;
+            const bool direct = group_goes_direct(g, push, group_direct);
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (direct && !s->dq_active) {
@@ -1982,7 +2028,9 @@ extern "C" int bpm_get_exchange_stats(bpm_handle_t s, int64_t* out) {
     out[3] = s->n_sparse_replays;
     out[4] = s->n_replay_gens;
     out[5] = s->n_push_gens;
-    out[6] = s->push_connected ? (s->ctrl_fine ? 2 : 1) : 0;
+    // bits 0-1: connected (2: control block fine-grained); bit 2 / 3: the arena self-test passed with system- / agent-scope packet fences;
+    // bit 4: it ran on the library's own queue
+    out[6] = (s->push_connected ? (s->ctrl_fine ? 2 : 1) : 0) | (s->probe_sys_ok ? 4 : 0) | (s->probe_agent_ok ? 8 : 0) | (s->probe_direct ? 16 : 0);
     out[7] = (int64_t)s->push_seq | (s->push_agent_scope ? (1ll << 62) : 0);
     return 0;
 }
@@ -2058,7 +2106,8 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
         } else if (b.pid == (int64_t)getpid()) {
             base = reinterpret_cast<void*>((uintptr_t)b.arena_addr);          // a rank of the same process (local test group): the pointer itself
         } else {
-            if (!b.has_ipc) return fail("bpm_push_connect: rank " + std::to_string(p) + " could not export an IPC handle of its buffer");
+            if (!b.has_ipc) return fail("bpm_push_connect: rank " + std::to_string(p) + " could not export an IPC handle of its buffer (hipIpcGetMemHandle failed there: on hosts "
+                                        "whose driver supports dmabuf IPC only, HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment before anything initialises HSA)");
             const hipError_t e = hipIpcOpenMemHandle(&base, b.handle, hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
@@ -2066,6 +2115,16 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
                             " (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank? peer access between the devices?)");
             }
             s->peer_opened[p] = true;
+            s->peer_base[p] = base;
+            // what was mapped must be at least as large as the arena the blob describes: a handle of some other, smaller allocation would make
+            // the first store beyond its end a GPU memory fault instead of an error here
+            void* rb = nullptr; size_t rsz = 0;
+            if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&rb), &rsz, base) == hipSuccess) {
+                const size_t avail = rsz - (size_t)((char*)base - (char*)rb);
+                if (avail < s->arena_bytes)
+                    return fail("bpm_push_connect: the buffer mapped for rank " + std::to_string(p) + " holds " + std::to_string(avail) + " bytes, its arena needs " +
+                                std::to_string(s->arena_bytes) + " (not the handle of that rank's exchange buffer)");
+            } else (void)hipGetLastError();
         }
         s->peer_base[p] = base;
         const unsigned long long a = (unsigned long long)(uintptr_t)base;
@@ -2094,9 +2153,31 @@ extern "C" int bpm_push_connect(bpm_handle_t s, const void* blobs) {
     return 0;
 }
 
-// Collective over the ranks (all processes call it together; a local group passes its R handles): every rank writes a pattern into
-// every other rank's control block through the mapped pointers, one cross-rank barrier, every rank checks what it received.
-// *ok = 1: this rank (every rank of the group) saw the pattern of all peers.
+// One launch of push_arena_probe_kernel for rank s (kernels.h): on the library's own queue when the self-test runs there, else on the stream.
+static int launch_arena_probe(bpm_sampler* s, int mode, int form, unsigned long long seed, double* save, int fence) {
+    ProbeGeo geo{s->L.blk, s->n_local, s->ld, (s->om && s->off_om) ? 2u * s->n_local : 0u, s->world, s->rank, 2u * s->ld + 8u};
+    unsigned long long* bad = &s->ctrl->arena_bad[form];
+    if (g_dq) {
+        struct { const unsigned long long* tab; ProbeGeo g; int mode; unsigned long long seed; double* save; unsigned long long* bad; } ka{s->tab_all, geo, mode, seed, save, bad};
+        const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(push_arena_probe_kernel));
+        if (!k || g_dq->launch(*k, PROBE_REGIONS, s->world, WAVE, &ka, sizeof(ka), fence) != 0) return fail("direct AQL queue: push_arena_probe_kernel: " + g_dq->why());
+        g_dq_need_acquire = true;
+        return 0;
+    }
+    hipLaunchKernelGGL(push_arena_probe_kernel, dim3(PROBE_REGIONS, s->world), dim3(WAVE), 0, s->stream, (const unsigned long long*)s->tab_all, geo, mode, seed, save, bad);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+// Collective over the ranks (all processes call it together; a local group passes its R handles), in two parts.
+// (1) control blocks: every rank writes a pattern into every other rank's (fine-grained) control block, one cross-rank barrier, every rank checks.
+// (2) arenas: every rank stores probe rows into ITS block of every peer's arena -- first and last row, the block's last slots, both ends of its
+//     om block: the addresses its update kernels will push to -- FROM THE QUEUE AND UNDER THE PACKET FENCES THE UPDATE KERNELS USE (the library's
+//     own AQL queue where the sampler runs on one), a cross-rank barrier, every rank verifies what arrived in its own arena and puts back what
+//     was there.  Once with system-scope fences (decides *ok with part 1), once with the agent-scope form (reported by bpm_get_exchange_stats:
+//     a caller skips "push with agent-scope fences" when its probe failed).  Round 3 probed the control block only, from the HIP stream: the
+//     arena was first touched by real updates.
+// *ok = 1: this rank (every rank of the group) received everything its peers sent.
 extern "C" int bpm_push_selftest(bpm_handle_t* handles, int32_t R, int32_t* ok) {
     if (!handles || R < 1 || !ok) return fail("bpm_push_selftest: bad argument");
     *ok = 0;
@@ -2111,21 +2192,66 @@ extern "C" int bpm_push_selftest(bpm_handle_t* handles, int32_t R, int32_t* ok) 
     const unsigned long long seed = 0xB1900000ull + handles[0]->push_seq;
     for (int r = 0; r < R; ++r) {
         bpm_sampler* s = handles[r];
+        HIPCK(hipMemsetAsync(&s->ctrl->arena_bad[0], 0, 2 * sizeof(unsigned long long), s->stream));
         hipLaunchKernelGGL(push_probe_kernel, dim3(1), dim3(WAVE), 0, s->stream, (const unsigned long long*)(s->tab_all + MAX_SEG), s->world, s->rank, seed);
         HIPCK(hipGetLastError());
     }
     CK(push_barrier(g));
     CK(group_sync(g));
-    bool all_ok = true;
+    bool ctrl_ok = true;
     for (int r = 0; r < R; ++r) {
         bpm_sampler* s = handles[r];
         PushCtrl c;
         HIPCK(hipMemcpy(&c, s->ctrl, sizeof(c), hipMemcpyDeviceToHost));
-        if (c.err != 0) all_ok = false;
+        if (c.err != 0) ctrl_ok = false;
         for (uint32_t p = 0; p < s->world; ++p)
-            if (p != s->rank && c.probe[p] != seed + p) all_ok = false;
+            if (p != s->rank && c.probe[p] != seed + p) ctrl_ok = false;
     }
-    *ok = all_ok ? 1 : 0;
+    // ---- part 2: the arenas, on the path the update kernels take
+    std::vector<double*> save((size_t)R, nullptr);
+    struct FreeSave { std::vector<double*>& v; ~FreeSave() { for (double* p : v) if (p) (void)hipFree(p); } } free_save{save};
+    for (int r = 0; r < R; ++r) CK(dev_alloc(&save[(size_t)r], (size_t)handles[r]->world * (2 * handles[r]->ld + 8)));
+    bool group_direct = false;
+    const bool direct = group_goes_direct(g, true, group_direct);
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        if (direct && !s->dq_active) { CK(wait_stream(s->stream)); s->dq_active = true; }
+    }
+    g_group_direct = group_direct;
+    g_dq = direct ? handles[0]->dq : nullptr;
+    g_dq_need_acquire = true;
+    int rc = 0;
+    for (int form = 0; form < 2 && rc == 0; ++form) {
+        // form 0: acquire + release at system scope around the writer (what the HSA memory model asks for between agents); form 1: the single-GPU
+        // form, acquire only at agent scope -- the probe rows themselves are system-scope write-through stores either way, as the pushed rows are
+        const int f_read = form == 0 ? (bpm::DirectQueue::ACQUIRE | bpm::DirectQueue::SYSTEM) : bpm::DirectQueue::ACQUIRE;
+        const int f_write = form == 0 ? (bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM) : bpm::DirectQueue::ACQUIRE;
+        for (int mode = 0; mode < 3 && rc == 0; ++mode) {
+            rc = push_barrier(g);
+            for (int r = 0; r < R && rc == 0; ++r) {
+                bind_rank_queue(handles[r]);
+                rc = launch_arena_probe(handles[r], mode, form, seed + 16u * (unsigned)form, save[(size_t)r], mode == 1 ? f_write : f_read);
+                if (g_dq) g_dq->flush();
+            }
+        }
+        if (rc == 0) rc = push_barrier(g);      // nobody goes on (to the next form, to a generation) while a peer still verifies
+    }
+    g_group_direct = false;
+    g_dq = nullptr;
+    for (int r = 0; r < R; ++r) { const int rl = leave_direct(handles[r]); if (rc == 0) rc = rl; }
+    CK(rc);
+    CK(group_sync(g));
+    bool sys_ok = true, agent_ok = true;
+    for (int r = 0; r < R; ++r) {
+        bpm_sampler* s = handles[r];
+        PushCtrl c;
+        HIPCK(hipMemcpy(&c, s->ctrl, sizeof(c), hipMemcpyDeviceToHost));
+        if (c.err != 0) { sys_ok = false; agent_ok = false; }
+        if (c.arena_bad[0] != 0) sys_ok = false;
+        if (c.arena_bad[1] != 0) agent_ok = false;
+    }
+    for (int r = 0; r < R; ++r) { handles[r]->probe_sys_ok = sys_ok; handles[r]->probe_agent_ok = agent_ok; handles[r]->probe_direct = direct; }
+    *ok = (ctrl_ok && sys_ok) ? 1 : 0;
     return 0;
 }
 
@@ -2141,6 +2267,7 @@ extern "C" int bpm_get_launch_stats(bpm_handle_t s, int64_t* out) {
     return 0;
 }
 
+#ifdef BPM_TEST_HOOKS
 // Test hook: the probe behind the choice of packet fences, on the memory type the state would use (coherent_alloc != 0) or on
 // ordinary device memory.  *wrong = elements that missed an update (0 = coherent without a release fence), -1 = could not run.
 extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc, int64_t* wrong) {
@@ -2155,6 +2282,7 @@ extern "C" int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc,
     *wrong = coherence_probe(dq, coherent_alloc != 0);
     return 0;
 }
+#endif   // BPM_TEST_HOOKS
 
 extern "C" int bpm_set_launch_path(bpm_handle_t s, int32_t direct, int32_t fence) {
     CK(check_handle(s));
@@ -2653,6 +2781,7 @@ extern "C" int bpm_get_trace(bpm_handle_t s, int32_t* out_i32, double* out_f64, 
     return 0;
 }
 
+#ifdef BPM_TEST_HOOKS
 // the host-side per-generation decisions, for parity against oracle/philox_ref.py
 extern "C" int bpm_debug_perm(bpm_handle_t s, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,
                               int32_t* out_inverse, int32_t* out_flip) {
@@ -2753,6 +2882,8 @@ extern "C" int bpm_debug_time_kernels(bpm_handle_t s, int32_t reps, float* updat
     }
     return 0;
 }
+
+#endif   // BPM_TEST_HOOKS
 
 #ifdef BPM_STAMPS
 // diagnostic build only: per-work-item s_memtime stamps of the LAST launched phase kernel

@@ -100,6 +100,7 @@ class DeMcMpi(object):
         if self.exchange not in ("auto", "push", "replay", "rows", "dense"):
             raise ValueError("exchange must be one of auto, push, replay, rows, dense")
         if self.comm.size > 1:
+            L.want_dmabuf_ipc()            # (multi-rank only; a no-op when the launcher exported the variable, as bench.py's does)
             if self.comm.rank == 0:
                 from .engine import HipEngine
                 if factory is not _default_engine_factory:
@@ -155,8 +156,12 @@ class DeMcMpi(object):
             ok = all(o[0] for o in oks)
             if ok:
                 self.comm.Barrier()
-                ok = bool(eng.push_selftest())
-                ok = all(self.comm.allgather(ok))
+                try:                                                  # (a rank that raises here must still enter the collective below)
+                    mine = bool(eng.push_selftest())
+                except Exception as e:                                # noqa: BLE001
+                    mine, err = False, "self-test: %s" % e
+                oks = self.comm.allgather((mine, err))
+                ok = all(o[0] for o in oks)
             if ok:
                 eng.set_exchange("push")
                 self.exchange_used = "push"

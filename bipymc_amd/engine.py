@@ -22,9 +22,11 @@ def _iptr(a):
 class HipEngine(object):
     def __init__(self, algo, n_chains, dim, target_id, target_params, seed, device=0, rank=0, world_size=1,
                  nccl_uid=None, gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
-                 p_snooker=0.0, outlier_every=0, keep_history=True, running_moments=False):
+                 p_snooker=0.0, outlier_every=0, keep_history=True, running_moments=False, lib=None):
+        """lib: the ctypes library to run on -- default the product library; tests that need the hooks of include/bipymc_hip_test.h pass
+        `_lib.load_test()` (the same sources built with -DBPM_TEST_HOOKS)."""
         self._h = C.c_void_p()
-        self.lib = L.load()
+        self.lib = lib if lib is not None else L.load()
         self.n_chains, self.dim = int(n_chains), int(dim)
         self.rank, self.world_size = int(rank), int(world_size)
         if self.n_chains % self.world_size != 0:
@@ -54,9 +56,12 @@ class HipEngine(object):
         cfg.outlier_every = int(outlier_every)
         cfg.keep_history = 1 if keep_history else 0
         cfg.running_moments = 1 if running_moments else 0
-        L.check(self.lib.bpm_create(C.byref(cfg), C.byref(self._h)))
+        self._ck(self.lib.bpm_create(C.byref(cfg), C.byref(self._h)))
         self.algo, self.target_id = int(algo), int(target_id)
         self.n_cr = int(n_cr) if algo == L.ALGO_DREAM else 1
+
+    def _ck(self, rc):
+        L.check(rc, self.lib)
 
     @staticmethod
     def unique_id():
@@ -67,7 +72,7 @@ class HipEngine(object):
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             h, self._h = self._h, C.c_void_p()
-            L.check(self.lib.bpm_destroy(h))         # non-zero: the queue failed and buffers were leaked (include/bipymc_hip.h)
+            self._ck(self.lib.bpm_destroy(h))         # non-zero: the queue failed and buffers were leaked (include/bipymc_hip.h)
 
     def __del__(self):
         try:
@@ -81,17 +86,17 @@ class HipEngine(object):
         if t0.size != self.dim:
             raise ValueError("theta_0 has %d entries, dim is %d" % (t0.size, self.dim))
         var = np.ascontiguousarray(np.broadcast_to(np.asarray(varepsilon, dtype=np.float64), (self.dim,)))
-        L.check(self.lib.bpm_init_chains(self._h, _dptr(t0), _dptr(var)))
+        self._ck(self.lib.bpm_init_chains(self._h, _dptr(t0), _dptr(var)))
 
     def set_state(self, X):
         X = np.ascontiguousarray(X, dtype=np.float64)
         if X.shape != (self.n_chains, self.dim):
             raise ValueError("state must have shape (n_chains, dim)")
-        L.check(self.lib.bpm_set_state(self._h, _dptr(X)))
+        self._ck(self.lib.bpm_set_state(self._h, _dptr(X)))
 
     def get_state(self):
         X = np.empty((self.n_chains, self.dim), dtype=np.float64)
-        L.check(self.lib.bpm_get_state(self._h, _dptr(X)))
+        self._ck(self.lib.bpm_get_state(self._h, _dptr(X)))
         return X
 
     def set_history(self, hist_local, X):
@@ -99,16 +104,16 @@ class HipEngine(object):
         X = np.ascontiguousarray(X, dtype=np.float64)
         assert hist_local.ndim == 3 and hist_local.shape[1:] == (self.n_local, self.dim)
         assert X.shape == (self.n_chains, self.dim)
-        L.check(self.lib.bpm_set_history(self._h, hist_local.shape[0], _dptr(hist_local), _dptr(X)))
+        self._ck(self.lib.bpm_set_history(self._h, hist_local.shape[0], _dptr(hist_local), _dptr(X)))
 
     def set_loglike(self, ll_local):
         ll = np.ascontiguousarray(ll_local, dtype=np.float64)
         assert ll.shape == (self.n_local,)
-        L.check(self.lib.bpm_set_loglike(self._h, _dptr(ll)))
+        self._ck(self.lib.bpm_set_loglike(self._h, _dptr(ll)))
 
     def get_loglike(self):
         ll = np.empty(self.n_local, dtype=np.float64)
-        L.check(self.lib.bpm_get_loglike(self._h, _dptr(ll)))
+        self._ck(self.lib.bpm_get_loglike(self._h, _dptr(ll)))
         return ll
 
     # ---- running ----------------------------------------------------
@@ -119,57 +124,57 @@ class HipEngine(object):
         o.epsilon = -1.0 if epsilon is None else float(epsilon)
         o.u_epsilon = -1.0 if u_epsilon is None else float(u_epsilon)
         o.gamma = -1.0 if gamma is None else float(gamma)
-        L.check(self.lib.bpm_begin_run(self._h, C.byref(o)))
+        self._ck(self.lib.bpm_begin_run(self._h, C.byref(o)))
 
     def step(self, n_gens):
-        L.check(self.lib.bpm_step(self._h, int(n_gens)))
+        self._ck(self.lib.bpm_step(self._h, int(n_gens)))
 
     def step_timed(self, n_gens, read=True):
         """n_gens generations, synchronous, timed on the device -> (ms from the end of the first update launch to the end of the
         last, launches in that interval).  read=False returns nothing: fetch the figures with last_step_time() afterwards (reading
         the events costs tens of microseconds of host time)."""
         if not read:
-            L.check(self.lib.bpm_step_timed(self._h, int(n_gens), None, None))
+            self._ck(self.lib.bpm_step_timed(self._h, int(n_gens), None, None))
             return None
         ms = C.c_float(0.0)
         n = C.c_int64(0)
-        L.check(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms), C.byref(n)))
+        self._ck(self.lib.bpm_step_timed(self._h, int(n_gens), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
     def last_step_time(self):
         ms = C.c_float(0.0)
         n = C.c_int64(0)
-        L.check(self.lib.bpm_get_step_time(self._h, C.byref(ms), C.byref(n)))
+        self._ck(self.lib.bpm_get_step_time(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
     def step_profiled(self, n_gens):
         """-> (summed update-kernel time in ms, number of launches)"""
         ms = C.c_double(0.0)
         n = C.c_int64(0)
-        L.check(self.lib.bpm_step_profiled(self._h, int(n_gens), C.byref(ms), C.byref(n)))
+        self._ck(self.lib.bpm_step_profiled(self._h, int(n_gens), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
     def synchronize(self):
-        L.check(self.lib.bpm_synchronize(self._h))
+        self._ck(self.lib.bpm_synchronize(self._h))
 
     def propose(self):
         prop = np.empty((self.n_local, self.dim), dtype=np.float64)
         ids = np.empty(self.n_local, dtype=np.int32)
         n = C.c_int32(0)
-        L.check(self.lib.bpm_propose(self._h, _dptr(prop), _iptr(ids), C.byref(n)))
+        self._ck(self.lib.bpm_propose(self._h, _dptr(prop), _iptr(ids), C.byref(n)))
         return prop[:n.value], ids[:n.value]
 
     def commit(self, ll_prop):
         ll = np.ascontiguousarray(ll_prop, dtype=np.float64)
-        L.check(self.lib.bpm_commit(self._h, _dptr(ll) if ll.size else None))
+        self._ck(self.lib.bpm_commit(self._h, _dptr(ll) if ll.size else None))
 
     def reserve_history(self, rows):
-        L.check(self.lib.bpm_reserve_history(self._h, int(rows)))
+        self._ck(self.lib.bpm_reserve_history(self._h, int(rows)))
 
     # ---- results ----------------------------------------------------
     def stats(self):
         st = L.BpmStats()
-        L.check(self.lib.bpm_get_stats(self._h, C.byref(st)))
+        self._ck(self.lib.bpm_get_stats(self._h, C.byref(st)))
         n = st.n_cr
         return dict(local_n_accepted=st.local_n_accepted, local_n_rejected=st.local_n_rejected,
                     n_nan_alpha=st.n_nan_alpha, k_gen=st.k_gen, t_abs=st.t_abs, history_rows=st.history_rows,
@@ -185,20 +190,22 @@ class HipEngine(object):
         per half generation) or "dense" (all-gather of whole blocks)"""
         if mode == "push-agent":          # the push exchange with agent-scope packet fences (include/bipymc_hip.h: bpm_set_exchange)
             mode, cap = "push", 1
-        L.check(self.lib.bpm_set_exchange(self._h, self.EXCHANGE_MODES[mode], int(cap)))
+        self._ck(self.lib.bpm_set_exchange(self._h, self.EXCHANGE_MODES[mode], int(cap)))
 
     def exchange_stats(self):
         out = (C.c_int64 * 8)()
-        L.check(self.lib.bpm_get_exchange_stats(self._h, out))
+        self._ck(self.lib.bpm_get_exchange_stats(self._h, out))
         return dict(mode=["dense", "rows", "replay", "push"][out[0]], cap=int(out[1]), chunks=int(out[2]), replays=int(out[3]),
-                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(out[6]), push_flags_fine_grained=int(out[6]) == 2, barriers=int(out[7]) & ((1 << 62) - 1),
-                    push_fence_scope="agent" if int(out[7]) >> 62 & 1 else "system")
+                    replay_gens=int(out[4]), push_gens=int(out[5]), push_connected=bool(int(out[6]) & 3), push_flags_fine_grained=(int(out[6]) & 3) == 2,
+                    # bpm_push_selftest's arena probe: stores into the peers' arenas arrived under system- / agent-scope packet fences; run on the own queue
+                    arena_probe_system=bool(int(out[6]) & 4), arena_probe_agent=bool(int(out[6]) & 8), arena_probe_on_own_queue=bool(int(out[6]) & 16),
+                    barriers=int(out[7]) & ((1 << 62) - 1), push_fence_scope="agent" if int(out[7]) >> 62 & 1 else "system")
 
     # ---- push exchange (world_size > 1): map the ranks' buffers into each other ------------------------------------------
     def push_export(self):
         """-> bytes: what the other ranks need to map this rank's exchange buffer (bpm_push_export)"""
         buf = C.create_string_buffer(L.PUSH_BLOB_BYTES)
-        L.check(self.lib.bpm_push_export(self._h, buf))
+        self._ck(self.lib.bpm_push_export(self._h, buf))
         return buf.raw
 
     def push_connect(self, blobs):
@@ -207,13 +214,13 @@ class HipEngine(object):
         if len(blobs) != self.world_size or any(len(b) != L.PUSH_BLOB_BYTES for b in blobs):
             raise ValueError("push_connect needs one export per rank")
         buf = C.create_string_buffer(b"".join(blobs), L.PUSH_BLOB_BYTES * self.world_size)
-        L.check(self.lib.bpm_push_connect(self._h, buf))
+        self._ck(self.lib.bpm_push_connect(self._h, buf))
 
     def push_selftest(self):
         """collective over the ranks (one engine per process): -> True when this rank received every peer's pattern"""
         arr = (C.c_void_p * 1)(self._h)
         ok = C.c_int32(0)
-        L.check(self.lib.bpm_push_selftest(arr, 1, C.byref(ok)))
+        self._ck(self.lib.bpm_push_selftest(arr, 1, C.byref(ok)))
         return bool(ok.value)
 
     @staticmethod
@@ -224,13 +231,13 @@ class HipEngine(object):
     def launch_stats(self):
         """How the update kernels were dispatched: the library's own AQL queue or the HIP stream (bpm_get_launch_stats)."""
         out = (C.c_int64 * 6)()
-        L.check(self.lib.bpm_get_launch_stats(self._h, out))
+        self._ck(self.lib.bpm_get_launch_stats(self._h, out))
         return dict(has_queue=bool(out[0]), direct=int(out[1]), stream=int(out[2]), queue_active=bool(out[3]),
                     coherent_state=bool(out[4]), fence={3: "acquire+release", 1: "acquire", 0: "none"}.get(int(out[5]), int(out[5])))
 
     def set_launch_path(self, direct=True, fence=-1):
         """direct=False: HIP stream launches only; fence: 3 acquire + release, 1 acquire only, 0 none, -1 keep (bpm_set_launch_path)."""
-        L.check(self.lib.bpm_set_launch_path(self._h, 1 if direct else 0, int(fence)))
+        self._ck(self.lib.bpm_set_launch_path(self._h, 1 if direct else 0, int(fence)))
 
     def history_rows(self):
         return int(self.stats()["history_rows"])
@@ -240,44 +247,44 @@ class HipEngine(object):
         if g_hi is None:
             g_hi = self.history_rows()
         out = np.empty((max(0, g_hi - g_lo), self.n_local, self.dim), dtype=np.float64)
-        L.check(self.lib.bpm_get_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
+        self._ck(self.lib.bpm_get_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
         return out
 
     def get_loglike_history(self, g_lo=0, g_hi=None):
         if g_hi is None:
             g_hi = self.history_rows()
         out = np.empty((max(0, g_hi - g_lo), self.n_local), dtype=np.float64)
-        L.check(self.lib.bpm_get_loglike_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
+        self._ck(self.lib.bpm_get_loglike_history(self._h, int(g_lo), int(g_hi), _dptr(out)))
         return out
 
     def reduce_moments(self, n_burn=0):
         """-> (count, S1, S2, shift): raw moments of the local super-chain rows >= n_burn."""
         s1 = np.empty(self.dim); s2 = np.empty(self.dim); sh = np.empty(self.dim)
         n = C.c_int64(0)
-        L.check(self.lib.bpm_reduce_moments(self._h, int(n_burn), _dptr(s1), _dptr(s2), _dptr(sh), C.byref(n)))
+        self._ck(self.lib.bpm_reduce_moments(self._h, int(n_burn), _dptr(s1), _dptr(s2), _dptr(sh), C.byref(n)))
         return int(n.value), s1, s2, sh
 
     def set_adapt_state(self, p_cr=None, delta_m=None, n_cr_updates=None, t_abs=-1):
         keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None
                 for a in (p_cr, delta_m, n_cr_updates)]
-        L.check(self.lib.bpm_set_adapt_state(self._h, *[None if a is None else _dptr(a) for a in keep], int(t_abs)))
+        self._ck(self.lib.bpm_set_adapt_state(self._h, *[None if a is None else _dptr(a) for a in keep], int(t_abs)))
 
     def eval_loglike(self, X):
         X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64)
         assert X.shape[1] == self.dim
         out = np.empty(X.shape[0], dtype=np.float64)
-        L.check(self.lib.bpm_eval_loglike(self._h, _dptr(X), X.shape[0], _dptr(out)))
+        self._ck(self.lib.bpm_eval_loglike(self._h, _dptr(X), X.shape[0], _dptr(out)))
         return out
 
     # ---- parity hooks -------------------------------------------------
     def set_trace(self, on=True):
-        L.check(self.lib.bpm_set_trace(self._h, 1 if on else 0))
+        self._ck(self.lib.bpm_set_trace(self._h, 1 if on else 0))
 
     def get_trace(self):
         ti = np.empty((self.n_local, L.TRACE_I32), dtype=np.int32)
         tf = np.empty((self.n_local, L.TRACE_F64), dtype=np.float64)
         tm = np.empty((self.n_local, self.dim), dtype=np.uint8)
-        L.check(self.lib.bpm_get_trace(self._h, _iptr(ti), _dptr(tf), tm.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self.lib.bpm_get_trace(self._h, _iptr(ti), _dptr(tf), tm.ctypes.data_as(C.POINTER(C.c_uint8))))
         return dict(cr_idx=ti[:, 0], d_prime=ti[:, 1], jump=ti[:, 2], accepted=ti[:, 3], snooker=ti[:, 4],
                     partners=ti[:, 5:5 + L.MAX_PARTNERS], alpha=tf[:, 0], ll_prop=tf[:, 1], delta=tf[:, 2],
                     gamma=tf[:, 3], mask=tm.astype(bool))
@@ -286,15 +293,16 @@ class HipEngine(object):
         order = np.empty(self.n_chains, dtype=np.int32)
         inv = np.empty(self.n_chains, dtype=np.int32)
         flip = C.c_int32(0)
-        L.check(self.lib.bpm_debug_perm(self._h, int(t), 1 if shuffle else 0, float(flip_prob), _iptr(order),
+        self._ck(self.lib.bpm_debug_perm(self._h, int(t), 1 if shuffle else 0, float(flip_prob), _iptr(order),
                                         _iptr(inv), C.byref(flip)))
         return order, inv, bool(flip.value)
 
 
 def selftest_philox(n=4096, seed=42, device=0):
-    lib = L.load()
+    """the inline Philox against rocRAND's device engine (a test hook: runs on the test variant of the library)"""
+    lib = L.load_test()
     mine = np.empty((n, 4), dtype=np.uint32)
     ref = np.empty((n, 4), dtype=np.uint32)
     L.check(lib.bpm_selftest_philox(int(device), int(n), int(seed), mine.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                    ref.ctypes.data_as(C.POINTER(C.c_uint32))))
+                                    ref.ctypes.data_as(C.POINTER(C.c_uint32))), lib)
     return mine, ref

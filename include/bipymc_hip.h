@@ -174,8 +174,9 @@ int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
  * count seen.  mode 0: the dense all-gather of whole blocks.  The same values on every rank. */
 int bpm_set_exchange(bpm_handle_t h, int32_t mode, int32_t cap);
 /* out[8] = {mode, current capacity of mode 1, chunks run with mode 1, chunks of mode 1 repeated dense,
- *           generations exchanged by replay, generations exchanged by push, 1 if the push exchange is connected (2: with the
- *           control block in fine-grained memory of its own),
+ *           generations exchanged by replay, generations exchanged by push, bits 0-1: 1 if the push exchange is connected (2: with the
+ *           control block in fine-grained memory of its own) | bit 2 / bit 3: the arena probe of bpm_push_selftest passed with system- /
+ *           agent-scope packet fences | bit 4: it ran on the library's own queue,
  *           barriers so far | bit 62 when the push exchange fences at agent scope} */
 int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
 /* mode 3, "push" (the default once connected): where the reference's ranks meet in MPI_Allgather twice per generation
@@ -191,8 +192,17 @@ int bpm_get_exchange_stats(bpm_handle_t h, int64_t* out);
  *   bpm_push_export   blob[BPM_PUSH_BLOB_BYTES]: what the other ranks need to map this rank's buffer
  *   bpm_push_connect  blobs = the exports of ALL ranks in rank order (world_size x BPM_PUSH_BLOB_BYTES), moved by the caller's own
  *                     communicator (the reference's counterpart is mpi_comm itself, demc.py:15)
- *   bpm_push_selftest collective: every rank writes a pattern into every peer, one barrier, every rank checks (*ok); handles = this
- *                     process's ranks (one, or the R ranks of a local test group)
+ *   bpm_push_selftest collective; handles = this process's ranks (one, or the R ranks of a local test group).  (1) every rank writes a pattern
+ *                     into every peer's control block, one barrier, every rank checks; (2) every rank stores probe rows into ITS block of
+ *                     every peer's arena (first and last row, the block's last slots, both ends of its outlier block: where its update
+ *                     kernels will push) from the queue and under the packet fences the update kernels use, a barrier, every rank verifies
+ *                     what arrived and restores what was there -- with system-scope fences (*ok = (1) and this), then with the agent-scope
+ *                     form (bpm_get_exchange_stats out[6] bit 3).  A mapping that points elsewhere, or stores that are not visible behind
+ *                     the hand-over, end as *ok = 0 (-> an RCCL exchange), not as a fault or a divergence in the first generation.
+ *   bpm_destroy       of a connected rank of a world of processes announces "closing" to its peers and waits, bounded
+ *                     (BPM_PUSH_CLOSE_TIMEOUT_S, default 3 s), for theirs before it unmaps and frees: the library orders the teardown, the
+ *                     caller needs no barrier of its own.  A rank that still exchanges with a closed rank gets an error at its next
+ *                     bpm_synchronize ("closed its sampler") instead of waiting for its time limit.
  * A sampler created with a nccl_uid that starts with "BPMPUSH" has no RCCL communicator at all (ranks sharing one GPU, which RCCL
  * refuses; nodes without RCCL): the push exchange is then its only one.  Every rank must enter bpm_step within BPM_PUSH_TIMEOUT_S
  * (default 30) seconds of the others; a rank that waited longer reports it at the next bpm_synchronize. */
@@ -215,12 +225,6 @@ int bpm_get_launch_stats(bpm_handle_t h, int64_t* out);
  * exists); 0 is refused (fence-less packets belong to an experiment build only).  Results do not depend on the
  * launch path (tested). */
 int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
-/* Test hook: why packets may drop the release fence only together with write-through stores -- 48 dependent dispatches with
- * acquire-only packets and PLAIN stores hand every block of a 2 MB buffer from workgroup to workgroup (XCD to XCD); *wrong = elements
- * that missed an update (> 0 on hipMalloc memory: the probe must FAIL there), -1 if there is no queue.  coherent_alloc != 0 (the
- * memory type of round 2's experiment) is an error in the product library. */
-int bpm_debug_coherence_probe(int32_t device, int32_t coherent_alloc, int64_t* wrong);
-
 /* Host-callback ln_like_fn (samplers.py:36-43): one half generation = propose + commit.
  * bpm_propose writes the proposals of this rank's chains of the current phase into out_prop
  * (n_out rows of dim) and their global ids into out_ids (capacity n_local each); the caller evaluates
@@ -244,24 +248,11 @@ int bpm_get_stats(bpm_handle_t h, bpm_stats_t* out);
 int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_m, const double* n_cr_updates,
                         int64_t t_abs);
 
-/* test hooks: bpm_destroy's decision about the device buffers as a pure function (1 free, 0 leak), and the injection of a failed
- * queue (the device's queue is unusable for the rest of the process afterwards: child processes only) */
-int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);
-int bpm_debug_fail_queue(bpm_handle_t h, int32_t refuse_quiesce);
-/* test hook: no-op packets on the handle's own AQL queue until its next packet takes position `pos` (0 ... 254) of an epoch of 256 packets;
- * *widx = the queue's write index afterwards (a test then puts a drain's packets at a chosen place of the ring) */
-int bpm_debug_queue_pad(bpm_handle_t h, int32_t pos, int64_t* widx);
-/* test hooks (no sampler state involved) */
-int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out); /* test hook: the order statistics, first argmax and cut (Q1 - 2 IQR) the outlier check would select from `omega` (n_chains values) */
-int bpm_debug_outlier_select(bpm_handle_t h, const double* omega, double out[6]);
-/* diagnostic: the update and the replay kernel of the handle's last half generation re-launched `reps` times and timed
- * (destructive; tools/emulate_ranks.py).  No reference counterpart. */
-int bpm_debug_time_kernels(bpm_handle_t h, int32_t reps, float* update_us, float* replay_us);
-/* device target on n points */
-int bpm_selftest_philox(int32_t device, int32_t n, uint64_t seed, uint32_t* out_mine, uint32_t* out_rocrand);
-/* per-generation host decisions (flip, shuffle order and its inverse) for generation t */
-int bpm_debug_perm(bpm_handle_t h, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,
-                   int32_t* out_inverse, int32_t* out_flip);
+/* ln_like of n points (row-major (n, dim)) with the sampler's device target: what `ln_like_fn(theta)` returns for the shipped analytic
+ * targets (utils/d100_gauss.py:14-35, dblgauss_rv.py:11-32, banana_rv.py:11-40) */
+int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out);
+/* (the test surface -- bpm_debug_*, bpm_selftest_philox, the BPM_TEST_PATHS kernel-path switches -- is NOT part of this library: it is
+ * compiled only into build_variants/libbipymc_test.so and declared in include/bipymc_hip_test.h) */
 /* per-chain integer/float trace of the LAST generation (parity tests):
  * out_i32[n_local*32] = (cr_idx, d_prime, gamma_jump, accepted, snooker, partner ids[23], ...),
  * out_f64[n_local*4] = (alpha, ll_prop, delta, gamma), out_mask[n_local*dim] = CR mask */

@@ -135,8 +135,104 @@ def local_group_check(case, R):
     return ls["direct"] - ls0["direct"], ls["stream"] - ls0["stream"]
 
 
+def selftest_main():
+    """_push_worker.py --selftest <dir> <rank> <world> <wrong>: connect, run bpm_push_selftest, print what it said.  wrong = 1: rank 1
+    publishes the export of its sampler with the ARENA HANDLE OF ANOTHER sampler of the same shape (a decoy that stays alive): rank 0 then
+    maps -- and probes -- the wrong buffer, and rank 1 must see that nothing arrived in its arena.  Blob layout: sampler.hip, struct PushBlob
+    (the arena's hipIpcMemHandle_t at bytes 80..144)."""
+    d_, rank, world, wrong = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    from _file_comm import FileComm
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import mixture_nd
+    comm = FileComm(d_, rank, world)
+    tid, tp, d = mixture_nd.BimodeGauss_ND(8)._bpm_target_spec()
+    kw = dict(algo=L.ALGO_DREAM, n_chains=96 * world, dim=d, target_id=tid, target_params=tp, seed=11, rank=rank, world_size=world,
+              nccl_uid=HipEngine.push_uid(), burnin_gen=20, n_cr_gen=3, outlier_every=10)
+    e = HipEngine(**kw)
+    blob = e.push_export()
+    decoy = None
+    if wrong and rank == 1:
+        decoy = HipEngine(**kw)
+        other = decoy.push_export()
+        blob = blob[:80] + other[80:144] + blob[144:]
+    e.push_connect(comm.allgather(blob))
+    x0 = start_state("selftest", 96 * world, d)
+    e.set_state(x0)                                     # (a state is in place: the self-test must leave it as it found it)
+    comm.Barrier()
+    ok = e.push_selftest()
+    xs = e.exchange_stats()
+    same = bool(np.array_equal(e.get_state(), x0))
+    print("SELFTEST rank=%d ok=%d arena_system=%d arena_agent=%d own_queue=%d state_intact=%d" %
+          (rank, ok, xs["arena_probe_system"], xs["arena_probe_agent"], xs["arena_probe_on_own_queue"], same), flush=True)
+    oks = comm.allgather(bool(ok))
+    if all(oks):                                        # a good connection goes on to run: the probe left nothing behind
+        e.begin_run()
+        comm.Barrier()
+        e.step(12)
+        e.synchronize()
+        print("RAN rank=%d sum=%r" % (rank, float(e.get_state().sum())), flush=True)
+    comm.Barrier()
+    e.close()
+    if decoy is not None:
+        decoy.close()
+
+
+def teardown_main():
+    """_push_worker.py --teardown <dir> <rank> <world> <variant>.  variant "late": rank 0 closes right behind its last step while rank 1
+    is still busy with its own results for a while -- bpm_destroy's hand-over makes rank 0 wait for it (bounded); nobody faults, results are
+    the single-rank run's.  variant "more": rank 1 steps AGAIN after rank 0 has closed -- an error naming the closed rank, at once."""
+    import time
+    d_, rank, world, variant = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    from _file_comm import FileComm
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    comm = FileComm(d_, rank, world)
+    spec, algo, N, kw, G = case_spec("dream_gauss100")
+    tid, tp, d = spec
+    e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=rank, world_size=world,
+                  nccl_uid=HipEngine.push_uid(), **kw)
+    e.push_connect(comm.allgather(e.push_export()))
+    comm.Barrier()
+    assert e.push_selftest()
+    e.set_state(start_state("dream_gauss100", N, d))
+    e.begin_run(flip=0.4)
+    comm.Barrier()
+    e.step(G // 2)
+    e.step(G - G // 2)
+    if rank == 0:
+        e.synchronize()
+        t0 = time.time()
+        e.close()                                       # NO barrier of the caller's in front of it
+        print("CLOSED rank=0 after %.2f s" % (time.time() - t0), flush=True)
+        return
+    if variant == "late":
+        time.sleep(1.0)                                 # (rank 0 is inside bpm_destroy by now, waiting for this rank's announcement)
+        e.synchronize()
+        st = e.stats()
+        np.savez(os.path.join(d_, "late_rank%d.npz" % rank), state=e.get_state(), p_cr=st["p_cr"], acc=np.array([st["local_n_accepted"]]))
+        t0 = time.time()
+        e.close()
+        print("CLOSED rank=%d after %.2f s" % (rank, time.time() - t0), flush=True)
+    else:
+        e.synchronize()
+        time.sleep(1.5)                                 # rank 0 has announced "closing" (and is waiting, or gone)
+        t0 = time.time()
+        try:
+            e.step(2)
+            e.synchronize()
+            print("MORE no error", flush=True)
+        except L.BpmError as err:
+            print("MORE error after %.2f s: %s" % (time.time() - t0, err), flush=True)
+        e.close()
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--group":
+    if sys.argv[1] == "--selftest":
+        selftest_main()
+    elif sys.argv[1] == "--teardown":
+        teardown_main()
+    elif sys.argv[1] == "--group":
         nd, ns = local_group_check(sys.argv[2], int(sys.argv[3]))
         print("GROUP ok direct=%d stream=%d" % (nd, ns))
     else:

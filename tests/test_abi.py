@@ -17,10 +17,23 @@ def built():
     return so
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "bipymc_hip.h")).read()
+@pytest.fixture(scope="module")
+def built_test(built):
+    so = os.path.join(ROOT, "build_variants", "libbipymc_test.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bipymc_amd", "csrc")])
+    return so
+
+
+def _declared_symbols(header="bipymc_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bpm_[a-z_0-9]+)\s*\(", text)))
+
+
+def _exported(so):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    return set(re.findall(r" T (bpm_[a-z_0-9]+)", out))
 
 
 def test_header_and_binding_agree():
@@ -28,13 +41,28 @@ def test_header_and_binding_agree():
     declared = _declared_symbols()
     assert len(declared) >= 25
     assert sorted(_lib.SIGNATURES) == declared
+    assert sorted(_lib.TEST_SIGNATURES) == _declared_symbols("bipymc_hip_test.h")
 
 
 def test_library_exports_every_declared_symbol(built):
-    out = subprocess.check_output(["nm", "-D", "--defined-only", built]).decode()
-    exported = set(re.findall(r" T (bpm_[a-z_0-9]+)", out))
+    exported = _exported(built)
     missing = [s for s in _declared_symbols() if s not in exported]
     assert not missing, missing
+
+
+def test_product_library_carries_no_test_surface(built, built_test):
+    """bpm_debug_* / bpm_selftest_* and BPM_TEST_PATHS live in build_variants/libbipymc_test.so (-DBPM_TEST_HOOKS,
+    include/bipymc_hip_test.h) only.  The product exports exactly what include/bipymc_hip.h declares and does not contain the variable's name."""
+    exported = _exported(built)
+    assert exported == set(_declared_symbols()), sorted(exported ^ set(_declared_symbols()))
+    assert not [s for s in exported if "debug" in s or "selftest_philox" in s]
+    blob = open(built, "rb").read()
+    assert b"BPM_TEST_PATHS" not in blob and b"bpm_debug" not in blob
+    hooks = _declared_symbols("bipymc_hip_test.h")
+    assert len(hooks) >= 8 and all("debug" in h or "selftest" in h for h in hooks)
+    test_exported = _exported(built_test)
+    assert test_exported == set(_declared_symbols()) | set(hooks)
+    assert b"BPM_TEST_PATHS" in open(built_test, "rb").read()
 
 
 def test_library_loads_and_reports_abi(built):
@@ -88,12 +116,12 @@ def test_product_never_imports_the_oracle():
                 assert not bad.search(text), os.path.join(dirpath, f)
 
 
-def test_destroy_plan_never_frees_under_a_failed_queue(built):
+def test_destroy_plan_never_frees_under_a_failed_queue(built_test):
     """bpm_destroy's decision about the sampler's device buffers (sampler.hip: bpm_debug_destroy_plan): freed unless the library's own
     queue failed AND could not be quiesced (kernels that are slow, not dead, would write freed memory).  The reference
     has no counterpart: its chains are NumPy arrays (chain.py:13-29)."""
     from bipymc_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_test()                              # (a hook of the test variant: the product's bpm_destroy calls the same function)
     assert lib.bpm_debug_destroy_plan(0, 1) == 1        # healthy queue, drained: free
     assert lib.bpm_debug_destroy_plan(0, 0) == 1        # (no failure: nothing can still run)
     assert lib.bpm_debug_destroy_plan(1, 1) == 1        # failed, then inactivated: free

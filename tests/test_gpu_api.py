@@ -242,6 +242,12 @@ def test_rccl_one_rank_communicator(capsys):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def _test_lib_path():
+    from bipymc_amd import _lib as L
+    assert os.path.exists(L.TEST_LIB_PATH), "build_variants/libbipymc_test.so missing: make -C bipymc_amd/csrc"
+    return L.TEST_LIB_PATH
+
+
 def test_alternative_kernel_paths_on_one_gpu():
     """Kernel paths that a small single-GPU run does not take by itself must reproduce the default one bit for bit,
     for every kernel shape.  They are selected through the library's ONE test variable, BPM_TEST_PATHS (sampler.hip: test_path):
@@ -279,8 +285,9 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         env = dict(os.environ)
         for k in ("BPM_TEST_PATHS", "BPM_DIRECT_QUEUE", "BPM_QUEUE_INFLIGHT"):
             env.pop(k, None)
-        if paths:
-            env["BPM_TEST_PATHS"] = paths
+        if paths:                 # (the product library does not read BPM_TEST_PATHS: the alternative paths exist in the test variant only --
+            env["BPM_TEST_PATHS"] = paths      # whose default path thereby is compared with the product's as well)
+            env["BPM_LIB_PATH"] = _test_lib_path()
         env.update(extra)
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npy")
@@ -853,8 +860,8 @@ def test_release_fence_is_needed_on_ordinary_memory():
     (asking for it is an error)."""
     import subprocess
     import sys
-    code = ("import ctypes as C, os, sys; sys.path.insert(0, os.getcwd()); from bipymc_amd import _lib as L; lib = L.load(); w = C.c_int64(-2); "
-            "rc = lib.bpm_debug_coherence_probe(0, 1, C.byref(w)); L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w))); print(rc, w.value)")
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, os.getcwd()); from bipymc_amd import _lib as L; lib = L.load_test(); w = C.c_int64(-2); "
+            "rc = lib.bpm_debug_coherence_probe(0, 1, C.byref(w)); L.check(lib.bpm_debug_coherence_probe(0, 0, C.byref(w)), lib); print(rc, w.value)")
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(__file__), ".."), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     rc_coherent, ordinary_wrong = (int(v) for v in out.stdout.split()[-2:])
@@ -880,7 +887,7 @@ e = HipEngine(algo=L.ALGO_DREAM, n_chains=512, dim=d, target_id=tid, target_para
 e.set_state(np.random.RandomState(0).normal(size=(512, d)))
 e.begin_run(); e.step(20)
 assert e.launch_stats()["direct"] == 40
-L.check(e.lib.bpm_debug_fail_queue(e._h, refuse))
+L.check(e.lib.bpm_debug_fail_queue(e._h, refuse), e.lib)
 try:
     e.close()
     print("DESTROY ok")
@@ -897,7 +904,8 @@ e2.close()
     root = os.path.join(os.path.dirname(__file__), "..")
     sums = []
     for refuse in (0, 1):
-        out = subprocess.run([sys.executable, "-c", code, str(refuse)], cwd=root, capture_output=True, text=True, timeout=300)
+        out = subprocess.run([sys.executable, "-c", code, str(refuse)], cwd=root, capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, BPM_LIB_PATH=_test_lib_path()))          # (bpm_debug_fail_queue: a hook of the test variant)
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
         if refuse:
             assert "DESTROY error:" in out.stdout and "leaked" in out.stdout, out.stdout
@@ -1111,7 +1119,7 @@ e.synchronize()                                   # (the first table build is be
 w = C.c_int64(0)
 n = 1
 for epoch, start in enumerate((252, 251, 252, 250, 252, 253, 254, 252)):   # 2 update packets, then the drain's fence kernel + barrier packet: fence at start + 2
-    L.check(e.lib.bpm_debug_queue_pad(e._h, start, C.byref(w)))
+    L.check(e.lib.bpm_debug_queue_pad(e._h, start, C.byref(w)), e.lib)
     assert w.value == 256 * epoch + start, (w.value, epoch, start)           # epochs 0 ... 3 are the ring's first lap
     e.step(1)
     e.synchronize()
@@ -1127,7 +1135,7 @@ ls = e.launch_stats()
 assert ls["direct"] - ls0["direct"] == 2 * n and ls["stream"] == ls0["stream"], (ls0, ls)
 print("DRAINS-OK", n)
 '''
-    env = dict(os.environ, BPM_QUEUE_TIMEOUT_S="15")
+    env = dict(os.environ, BPM_QUEUE_TIMEOUT_S="15", BPM_LIB_PATH=_test_lib_path())       # (bpm_debug_queue_pad: a hook of the test variant)
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "DRAINS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]

@@ -22,6 +22,14 @@ def _engine(**kw):
     return HipEngine(**kw)
 
 
+def _hooks_engine(**kw):
+    """an engine on the TEST VARIANT of the library (build_variants/libbipymc_test.so, include/bipymc_hip_test.h): the product library
+    exports no bpm_debug_* entry point"""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    return HipEngine(lib=L.load_test(), **kw)
+
+
 def _gauss_params(d, rho=0.5):
     return R.gauss_equicorr_params(rho, np.sqrt(np.arange(d) + 1.0))
 
@@ -53,7 +61,7 @@ def test_philox_equals_rocrand_on_device():
 
 @pytest.mark.parametrize("N", [4, 5, 10, 64, 1000, 8192, 65536])
 def test_shuffle_and_flip_bit_exact(N):
-    eng = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=99)
+    eng = _hooks_engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=99)
     for t in (0, 1, 17, 70000):
         order, inv, flip = eng.debug_perm(t, True, 0.5)
         exp = P.shuffle_idx(99, t, N)
@@ -508,8 +516,8 @@ def test_outlier_quartile_selection_equals_numpy(N):
     can produce: ties, chains outside a prior's support (ln-like = -inf), signed zeros, all chains equal, a wide dynamic range."""
     import ctypes as C
     from bipymc_amd import _lib as L
-    eng = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=2, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1,
-                  outlier_every=5)
+    eng = _hooks_engine(algo=R.ALGO_DREAM, n_chains=N, dim=2, target_id=R.TARGET_MIXTURE_PAIRS, target_params=_mix_params(), seed=1,
+                        outlier_every=5)
     rs = np.random.RandomState(N)
     cases = [rs.normal(size=N) * 10 - 20,
              np.round(rs.normal(size=N) * 3),                                   # many ties
@@ -521,7 +529,7 @@ def test_outlier_quartile_selection_equals_numpy(N):
     for om in cases:
         om = np.ascontiguousarray(om, dtype=np.float64)
         out = np.zeros(6)
-        L.check(eng.lib.bpm_debug_outlier_select(eng._h, om.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        L.check(eng.lib.bpm_debug_outlier_select(eng._h, om.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))), eng.lib)
         srt = np.sort(om)
         k0, k1 = int(np.floor(0.25 * (N - 1))), int(np.floor(0.75 * (N - 1)))
         exp = [srt[k0], srt[min(k0 + 1, N - 1)], srt[k1], srt[min(k1 + 1, N - 1)]]

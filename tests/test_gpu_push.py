@@ -18,6 +18,12 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 
+def _test_lib_path():
+    from bipymc_amd import _lib as L
+    assert os.path.exists(L.TEST_LIB_PATH), "build_variants/libbipymc_test.so missing: make -C bipymc_amd/csrc"
+    return L.TEST_LIB_PATH
+
+
 def _single(case, world=1):
     from _push_worker import single_rank_reference
     return single_rank_reference(case, world)
@@ -48,6 +54,7 @@ def test_push_exchange_local_group_with_a_queue_per_rank(case, R):
     multi-GPU world do across GPUs."""
     env = dict(os.environ)
     env["BPM_TEST_PATHS"] = "groupqueues"
+    env["BPM_LIB_PATH"] = _test_lib_path()            # (BPM_TEST_PATHS is read by the test variant of the library only)
     env["BPM_PUSH_TIMEOUT_S"] = "20"
     env["BPM_QUEUE_TIMEOUT_S"] = "60"
     out = subprocess.run([sys.executable, os.path.join(HERE, "_push_worker.py"), "--group", case, str(R)], env=env, capture_output=True,
@@ -174,6 +181,7 @@ print("LEFT-PUSH synchronize ok")
 '''
     env = dict(os.environ)
     env["BPM_TEST_PATHS"] = "groupqueues"
+    env["BPM_LIB_PATH"] = _test_lib_path()            # (BPM_TEST_PATHS is read by the test variant of the library only)
     env["BPM_PUSH_TIMEOUT_S"] = "2"
     env["BPM_QUEUE_TIMEOUT_S"] = "60"
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(HERE, ".."), env=env, capture_output=True, text=True, timeout=200)
@@ -215,3 +223,69 @@ def test_connect_refuses_wrong_blobs_and_can_be_repeated():
     assert ok.value == 1 and ranks[0].exchange_stats()["push_flags_fine_grained"]
     for e in ranks + [other, single]:
         e.close()
+
+
+def _run_mode(mode, R, tmp_path, *extra, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BPM_PUSH_TIMEOUT_S"] = "20"
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_push_worker.py"), mode, str(tmp_path), str(r), str(R)] + [str(x) for x in extra],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(R)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode("utf-8", "replace"))
+    return [p.returncode for p in procs], outs
+
+
+def _fields(line):
+    return dict(kv.split("=") for kv in line.split()[1:] if "=" in kv)
+
+
+@pytest.mark.parametrize("wrong", [0, 1])
+def test_selftest_probes_every_peers_arena_from_the_librarys_own_queue(wrong, tmp_path):
+    """bpm_push_selftest stores probe rows into every peer's ARENA (first / last row of its block, the block's last slots, its
+    om block) from the library's own queue, under system- and agent-scope packet fences, and every rank verifies what arrived.  wrong = 0: ok on
+    both ranks, the state that was in place is untouched, the world then runs.  wrong = 1: rank 1 hands out the arena handle of ANOTHER buffer --
+    rank 0's stores land elsewhere, rank 1 answers ok = 0 (-> the callers fall back to an RCCL exchange), nothing faults, nothing hangs."""
+    rcs, outs = _run_mode("--selftest", 2, tmp_path, wrong)
+    assert rcs == [0, 0], "\n".join(o[-2500:] for o in outs)
+    st = [_fields([ln for ln in o.splitlines() if ln.startswith("SELFTEST")][0]) for o in outs]
+    assert all(f["own_queue"] == "1" and f["state_intact"] == "1" for f in st), st
+    if not wrong:
+        assert all(f["ok"] == "1" and f["arena_system"] == "1" and f["arena_agent"] == "1" for f in st), st
+        sums = [[ln for ln in o.splitlines() if ln.startswith("RAN")][0].split("sum=")[1] for o in outs]
+        assert sums[0] == sums[1]                                   # the replicas agree after a run behind the self-test
+    else:
+        assert st[1]["ok"] == "0" and st[1]["arena_system"] == "0", st      # rank 1 never received rank 0's probe rows
+        assert st[0]["ok"] == "1", st                                       # (rank 1 mapped rank 0 correctly: the decision is collective, demc.py)
+        assert not any("RAN" in o for o in outs)
+
+
+def test_destroy_orders_the_teardown_across_ranks(tmp_path):
+    """the library itself orders the teardown.  Rank 0 closes right behind its last step, with no barrier of the caller's,
+    while rank 1 is busy for another second: bpm_destroy announces "closing" and waits (bounded) for rank 1's announcement before it unmaps --
+    both ranks end cleanly and rank 1's results are the single-rank run's."""
+    ref = _single("dream_gauss100", world=2)
+    rcs, outs = _run_mode("--teardown", 2, tmp_path, "late", env_extra={"BPM_PUSH_CLOSE_TIMEOUT_S": "20"})
+    assert rcs == [0, 0], "\n".join(o[-2500:] for o in outs)
+    waited = float([ln for ln in outs[0].splitlines() if ln.startswith("CLOSED")][0].split()[3])
+    assert 0.3 < waited < 15.0, outs[0][-500:]                              # it waited for rank 1 (about a second), not for the bound
+    o = np.load(os.path.join(str(tmp_path), "late_rank1.npz"))
+    assert np.array_equal(o["state"], ref["state"]) and np.array_equal(o["p_cr"], ref["p_cr"])
+
+
+def test_a_rank_that_goes_on_after_a_peer_closed_is_told_so_at_once(tmp_path):
+    """... and a rank that steps again after its peer has closed (a mis-sequenced caller; the reference's ranks would hang in comm.Allgather,
+    demc.py:93-94) gets an error that names the closed rank within seconds -- not after BPM_PUSH_TIMEOUT_S, and never a store into freed memory."""
+    rcs, outs = _run_mode("--teardown", 2, tmp_path, "more", env_extra={"BPM_PUSH_CLOSE_TIMEOUT_S": "4", "BPM_PUSH_TIMEOUT_S": "60"})
+    assert rcs == [0, 0], "\n".join(o[-2500:] for o in outs)
+    line = [ln for ln in outs[1].splitlines() if ln.startswith("MORE")][0]
+    assert line.startswith("MORE error after") and "rank 0 closed its sampler" in line, line
+    assert float(line.split()[3]) < 30.0, line

@@ -3,6 +3,7 @@ frequencies the reference's NumPy draws would have (dream.py:51-80, demc.py:169-
 import numpy as np
 import pytest
 
+from oracle import philox_ref as P
 from oracle import sampler_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +30,7 @@ def test_dream_decision_frequencies():
     partner_hist = np.zeros(N)
     same_pool_violations = 0
     for g in range(G):
-        order, _, flip = e.debug_perm(g, True, 0.5)
+        order, flip = P.shuffle_idx(123, g, N), P.flip_draw(123, g, 0.5)     # (== the device's: test_gpu_parity.py::test_shuffle_and_flip_bit_exact)
         e.step(1)
         tr = e.get_trace()
         cr_counts += np.bincount(tr["cr_idx"], minlength=3)
@@ -95,7 +96,7 @@ def test_jitter_moments_on_device():
     X = np.zeros((N, d))
     e.set_state(X)
     e.begin_run(epsilon=0.5)
-    order, _, flip = e.debug_perm(0, True, 0.5)
+    order, flip = P.shuffle_idx(9, 0, N), P.flip_draw(9, 0, 0.5)
     e.step(1)
     first_group = order[N // 2:] if flip else order[:N // 2]                # updated against a pool that is still all zeros
     X1 = e.get_state()[first_group]                                         # x' = 0 + gamma*(0 - 0) + e_n
@@ -109,7 +110,7 @@ def test_jitter_moments_on_device():
     e.set_state(X)
     e.set_trace(True)
     e.begin_run(epsilon=0.0, u_epsilon=0.05)
-    order, _, flip = e.debug_perm(0, True, 0.5)
+    order, flip = P.shuffle_idx(10, 0, N), P.flip_draw(10, 0, 0.5)
     e.step(1)
     first_group = np.zeros(N, dtype=bool)
     first_group[order[N // 2:] if flip else order[:N // 2]] = True          # their pool still held the initial states

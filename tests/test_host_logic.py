@@ -341,6 +341,8 @@ def test_exchange_is_chosen_collectively(monkeypatch):
 
         def push_selftest(self):
             self.calls.append("selftest")
+            if self.fail_at == "selftest-raises":
+                raise RuntimeError("hipErrorLaunchFailure")
             return self.fail_at != "selftest"
 
         def set_exchange(self, mode, cap=0):
@@ -365,7 +367,7 @@ def test_exchange_is_chosen_collectively(monkeypatch):
         s._connect_exchange()
         return s
 
-    good = [(b"y" * 256, None), (True, None), True]
+    good = [(b"y" * 256, None), (True, None), (True, None)]
     s = run(Eng(), good)
     assert s.exchange_used == "push" and s._engine.mode == "push" and s._engine.calls == ["export", "connect", "selftest"]
     # the OTHER rank could not map this one: nobody runs the self-test, everybody takes the fallback
@@ -379,6 +381,11 @@ def test_exchange_is_chosen_collectively(monkeypatch):
         warnings.simplefilter("always")
         s = run(Eng(fail_at="selftest"), good)
     assert s.exchange_used == "replay"
+    # this rank's self-test RAISES: it still enters the collective (the other rank is not left waiting) and everybody falls back
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = run(Eng(fail_at="selftest-raises"), good)
+    assert s.exchange_used == "replay" and s.comm.other == [] and any("self-test: hipErrorLaunchFailure" in str(x.message) for x in w)
     # exchange="push" (no RCCL to fall back to): an error on every rank
     with pytest.raises(RuntimeError, match="push exchange could not be connected"):
         run(Eng(fail_at="export"), [(None, "export: no arena"), (False, None)], exchange="push")

@@ -75,8 +75,9 @@ if __name__ == "__main__":
             env.pop("BPM_TEST_PATHS", None)
             if v.startswith("lib="):           # an experiment build of the library instead of a test path
                 env["BPM_LIB_PATH"] = os.path.join(ROOT, v[4:])
-            elif v:
+            elif v:                            # (a test path: read by the test variant of the library only)
                 env["BPM_TEST_PATHS"] = v
+                env["BPM_LIB_PATH"] = os.path.join(ROOT, "build_variants", "libbipymc_test.so")
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", ",".join(names)], env=env, capture_output=True, text=True, timeout=900)
             if out.returncode != 0:
                 print("variant %r failed:\n%s" % (v, out.stderr[-1500:]))

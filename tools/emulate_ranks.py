@@ -10,6 +10,8 @@ ranks take turns, so a kernel trace shows each rank's kernels alone.
 cfg5: BASELINE config 5's per-rank shape instead (32768 chains of the 8-D mixture per rank, 4 lanes per chain, steady state)."""
 import ctypes as C
 import os
+# (this tool uses test hooks / BPM_TEST_PATHS: it runs on the test variant of the library, include/bipymc_hip_test.h)
+os.environ.setdefault("BPM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_variants", "libbipymc_test.so"))
 import sys
 import time
 

@@ -8,6 +8,8 @@ hand-overs: the extra dependent dispatch + announce -> poll latency.  What it ca
 usage: BPM_TEST_PATHS=groupqueues python tools/push_barrier_cost.py [R] [chains_per_rank] [generations]"""
 import ctypes as C
 import os
+# (this tool uses test hooks / BPM_TEST_PATHS: it runs on the test variant of the library, include/bipymc_hip_test.h)
+os.environ.setdefault("BPM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_variants", "libbipymc_test.so"))
 import sys
 import time
 

@@ -7,6 +7,8 @@ usage: queue_position_sweep.py            (parent)   -> exit code 1 on any diffe
 import ctypes as C
 import hashlib
 import os
+# (this tool uses test hooks / BPM_TEST_PATHS: it runs on the test variant of the library, include/bipymc_hip_test.h)
+os.environ.setdefault("BPM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_variants", "libbipymc_test.so"))
 import subprocess
 import sys
 
