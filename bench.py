@@ -47,6 +47,7 @@ N_CR_GEN = 50
 BYTES_PER_UPDATE = 8 * DIM * (2 * DEL_PAIRS + 3) + 16          # 7216
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
 POSTERIOR_MIN_GENS = 1200                                      # post-burn-in generations the moment gate is evaluated over
+ALT_WATCHDOG_S = 120                                           # N > 1: wall-clock bound of the alternative-exchange runs behind the headline
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -77,12 +78,17 @@ def visible_gpu_count(timeout=180.0):
     return -1
 
 
-def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys.stdout, err=sys.stderr):
+def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys.stdout, err=sys.stderr, deadline_s=None):
     """Start n rank processes of this script as children, relay rank 0's last JSON line to `out`, everything else to `err`.
     Returns the exit code: 0 only when every rank exited 0 and rank 0 printed its line.  Fewer visible GPUs than ranks is an
     error before anything starts (RCCL refuses two ranks on one device; no silent oversubscription).  When one rank fails
     the others are given grace_s seconds, then ended (their exact PIDs) -- a rank that died inside a collective would leave
-    its peers waiting for ever.  worker_cmd / n_visible: test hooks (tests/test_bench_launcher.py)."""
+    its peers waiting for ever -- and when ALL ranks hang without exiting the wall-clock limit deadline_s (default
+    BENCH_LAUNCH_DEADLINE_S or 1500 s) ends them the same way: exit code 124.  worker_cmd / n_visible: test hooks
+    (tests/test_bench_launcher.py)."""
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("BENCH_LAUNCH_DEADLINE_S", "1500"))
+    t_start = time.time()
     if n_visible is None:
         n_visible = visible_gpu_count()
     if n_visible < n:
@@ -123,13 +129,17 @@ def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys
                 rc = rc or (c if 0 < c < 256 else 1)
                 if first_fail_t is None:
                     first_fail_t = time.time()
-        if live and first_fail_t is not None and time.time() - first_fail_t > grace_s:
+        timed_out = live and time.time() - t_start > deadline_s
+        if live and ((first_fail_t is not None and time.time() - first_fail_t > grace_s) or timed_out):
             for r in sorted(live):
-                err.write("bench.py: ending rank %d (pid %d): another rank failed\n" % (r, procs[r].pid))
+                err.write("bench.py: ending rank %d (pid %d): %s\n" % (r, procs[r].pid, "the run exceeded its wall-clock limit of %.0f s" % deadline_s
+                                                                        if timed_out else "another rank failed"))
                 procs[r].kill()
             for r in sorted(live):
                 procs[r].wait()
             live.clear()
+            if timed_out:
+                rc = rc or 124
         if live:
             time.sleep(0.05)
     th.join(timeout=5.0)
@@ -401,6 +411,211 @@ def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000, fatal=T
     raise SystemExit("bench.py: no exchange reproduced the single-rank run on every rank: " + json.dumps(log))
 
 
+def _everyone(dist, world, v):
+    box = [None] * world
+    dist.all_gather_object(box, v)
+    return box
+
+
+def _collectively(dist, world, fn):
+    """fn() on every rank; -> (True, [results]) only when NO rank raised (every rank learns the others' outcome before anyone goes on into
+    the next collective), else (False, ["rank r: error", ...])"""
+    try:
+        res, err = fn(), None
+    except BaseException as e:                                            # noqa: BLE001 -- reported, never fatal: SystemExit of a helper included
+        res, err = None, "%s: %s" % (type(e).__name__, e)
+    box = _everyone(dist, world, (res, err))
+    errs = ["rank %d: %s" % (i, b[1]) for i, b in enumerate(box) if b[1]]
+    return (not errs), (errs if errs else [b[0] for b in box])
+
+
+def _timed_generations(eng, dist, world, X0, n_chains, burn, gens, coll_max):
+    """burn untimed generations (CR adaptation), then `gens` generations under the host clock between barriers; max over ranks.
+    -> dict(value, ms_per_step, replicas_identical)"""
+    import hashlib
+    eng.set_state(X0)
+    eng.set_adapt_state(t_abs=0)
+    eng.begin_run()
+    dist.barrier()
+    eng.step(burn)
+    eng.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    eng.step(gens)
+    eng.synchronize()
+    dist.barrier()
+    el = coll_max(time.perf_counter() - t0)
+    sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]
+    shas = _everyone(dist, world, sha)
+    return dict(value=n_chains * gens / el, ms_per_step=el / gens * 1e3, steps=gens, replicas_identical=len(set(shas)) == 1)
+
+
+def exchange_alternatives(eng, dist, world, X0, n_chains, make_single, make_rccl_engine, headline, coll_max, rccl_ranks_torch, share_gpu=False,
+                          gens=200, burn=BURNIN_GEN):
+    """OUTSIDE the headline's timed region: the same workload under the exchanges the headline did NOT use,
+    each >= `gens` steady-state generations behind `burn` untimed burn-in generations.  A failure of an alternative is recorded, never fatal.
+      dense       the exchange north_star names and the reference has -- MPI_Allgather twice per generation (bipymc/demc.py:93-94,116-117) as one
+                  in-place ncclAllGather of a rank block -- on a SECOND sampler created with the library's own RCCL communicator
+      push-agent  the push exchange with agent-scope packet fences (4 us less per hand-over on one GPU; between GPUs outside the HSA memory model,
+                  so never the headline): only when the arena self-test passed under that form, validated against a single-rank run first
+    -> list of dicts(mode, value, ms_per_step, rccl_ranks, replicas_identical | error | skipped)"""
+    out = []
+    # ---- dense, through the library's own communicator
+    entry = dict(mode="dense", collective="ncclAllGather of a rank block, in place, twice per generation (demc.py:93-94,116-117)",
+                 rccl_ranks=None, rccl_ranks_of_the_torch_process_group=rccl_ranks_torch)
+    if share_gpu:
+        entry["skipped"] = "the ranks of this rehearsal share one GPU: RCCL refuses two ranks on one device (torch.distributed runs over gloo, rccl_ranks null)"
+    elif headline == "dense":
+        entry["skipped"] = "the headline itself ran under the dense exchange"
+    else:
+        box = {}
+
+        def create():
+            box["eng"] = make_rccl_engine()
+            box["eng"].set_exchange(mode="dense")
+            return True
+        ok, res = _collectively(dist, world, create)
+        if ok:
+            e2 = box["eng"]
+            ok, res = _collectively(dist, world, lambda: _timed_generations(e2, dist, world, X0, n_chains, burn, gens, coll_max))
+            if ok:
+                entry.update(res[0])
+                entry["rccl_ranks"] = world                       # the communicator bpm_create made: ncclCommInitRank(world) succeeded on every rank
+                entry["exchange_stats"] = e2.exchange_stats()
+        if not ok:
+            entry["error"] = res[:4]
+        if box.get("eng") is not None:
+            try:
+                dist.barrier()
+                box["eng"].close()
+            except Exception as e:                                    # noqa: BLE001
+                entry.setdefault("error", []).append("close: %s" % e)
+    out.append(entry)
+    # ---- push with agent-scope fences
+    if headline == "push":
+        entry = dict(mode="push-agent", fence_scope="agent", rccl_ranks=None,
+                     note="agent-scope packet fences around the update kernels; the pushed rows are system-scope write-through stores either way.  Between "
+                          "GPUs this is outside the HSA memory model: reported beside the headline (system scope: what the sampler classes select), never as it")
+        xs = eng.exchange_stats()
+        if not xs.get("arena_probe_agent", False):
+            entry["skipped"] = "the arena self-test failed under agent-scope fences (bpm_push_selftest)"
+        else:
+            def run():
+                got = validate_exchange(eng, dist, X0, make_single, ["push-agent"], gens=300, fatal=False)
+                if not got.get("mode"):
+                    raise RuntimeError("300 generations under agent-scope fences did not reproduce the single-rank run: %s" % json.dumps(got["validation"]))
+                eng.set_exchange(mode="push-agent")
+                return _timed_generations(eng, dist, world, X0, n_chains, burn, gens, coll_max)
+            ok, res = _collectively(dist, world, run)
+            if ok:
+                entry.update(res[0])
+                entry["validated_against_single_rank_run"] = True
+            else:
+                entry["error"] = res[:4]
+            try:
+                eng.set_exchange(mode="dense" if not ok else "push")      # (clears a time-out mark, then back to what the headline used)
+                eng.set_exchange(mode="push")
+            except Exception:                                         # noqa: BLE001
+                pass
+        out.append(entry)
+    return out
+
+
+def host_callback_config(device, budget_s=3.0):
+    """f1 under the driver's clock: cfg2's shape -- DREAM, 100-D Gaussian, 8192 chains -- with the likelihood as a HOST CALLBACK:
+    every half generation the proposals come back (bpm_propose), a vectorised NumPy ln_like evaluates the block, the values go in (bpm_commit).
+    The path every user-written likelihood takes (samplers.py:36-43; examples/ex_para_fit.py:39-72 calls it row by row)."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    N, d = CHAINS_PER_GPU, DIM
+    sig = np.sqrt(np.arange(d) + 1.0)
+    rho = 0.5
+    c0 = -0.5 * (d * np.log(2 * np.pi) + 2 * np.sum(np.log(sig)) + (d - 1) * np.log(1 - rho) + np.log(1 + (d - 1) * rho))
+    a, b = 1.0 / (1 - rho), rho / ((1 - rho) * (1 + (d - 1) * rho))
+    isig = 1.0 / sig
+
+    def ln_like(X):                                                  # (n, d) -> (n,): the equicorrelated Gaussian in O(n d)
+        z = X * isig
+        s1 = z.sum(axis=1)
+        return c0 - 0.5 * (a * np.einsum("ij,ij->i", z, z) - b * s1 * s1)
+    rs = np.random.RandomState(1234)
+    X0 = sig * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, device=device,
+                  del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3)
+    try:
+        e.set_state(X0)
+        e.set_loglike(ln_like(X0))
+        e.reserve_history(4000)
+        e.begin_run()
+        for _ in range(3):                                            # warm-up
+            for _h in range(2):
+                props, _ids = e.propose()
+                e.commit(ln_like(props))
+        gens, t_py, t0 = 0, 0.0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s * 0.8 and gens < 3000:
+            for _h in range(2):
+                props, _ids = e.propose()
+                tp0 = time.perf_counter()
+                ll = ln_like(props)
+                t_py += time.perf_counter() - tp0
+                e.commit(ll)
+            gens += 1
+        e.synchronize()
+        el = time.perf_counter() - t0
+        st = e.stats()
+    finally:
+        e.close()
+    half = N // 2
+    d2h = N * 4 + half * d * 8 + 2 * N * 8                            # work-item ids, proposals of the half's chains, (log_corr, .) pairs
+    h2d = 2 * N * 8                                                   # the pairs with the ln_like values filled in
+    return dict(config="cfg2 shape with a host-callback ln_like_fn (vectorised NumPy): DREAM gauss d=100 N=8192 steady, bpm_propose / bpm_commit",
+                value=N * gens / el, unit="chain-updates/s", n_chains=N, dim=d, steps=gens, ms_per_step=el / gens * 1e3,
+                start="exact draws of the target",
+                acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
+                pcie=dict(d2h_bytes_per_half_generation=d2h, h2d_bytes_per_half_generation=h2d, staging="pinned host buffers, one read-back per propose"),
+                share_of_time_in_the_python_call=t_py / el,
+                note="the host clock includes the callback; not a roofline configuration (PCIe + Python bound by construction)")
+
+
+# the generation after which cfg2 from the REFERENCE'S start passes the moment gate, as measured on MI355X (tools/convergence_from_reference_start.py,
+# profiles/r04_convergence_from_reference_start.txt: seeds 42 and 7); the asserted form is tests/test_gpu_statistics.py
+REFERENCE_START_GATE_GENS = 6000
+
+
+def posterior_from_reference_start(device, max_gens=REFERENCE_START_GATE_GENS, window=1000, step=250):
+    """posterior.start alternative: config 2 from theta_0 = 0, varepsilon = 1e-6 (bipymc/chain.py:25-27,
+    tests/test_100dgauss.py:67-69) instead of exact draws: the generation at which the trailing 1000 generations first pass the gate of the headline
+    (pooled variance ratio within 1 %, every |mean| < 0.05 sigma).  Population sums per generation, no history.  Untimed."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils.d100_gauss import Gauss_100D
+    tid, tp, _ = Gauss_100D(rho=0.5, dim=DIM)._bpm_target_spec()
+    N = CHAINS_PER_GPU
+    sig2 = np.arange(DIM) + 1.0
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=DIM, target_id=tid, target_params=tp, seed=42, device=device, del_pairs=DEL_PAIRS,
+                  burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False, running_moments=True)
+    first, last = None, None
+    try:
+        e.init_chains(np.zeros(DIM), 1e-6)
+        e.begin_run()
+        T = 0
+        while T < max_gens and first is None:
+            e.step(step)
+            T += step
+            if T < window:
+                continue
+            cnt, s1, s2, sh = e.reduce_moments((1 + T - window) * N)
+            mean, var = sh + s1 / cnt, s2 / cnt - (s1 / cnt) ** 2
+            vr, mm = float(np.mean(var / sig2)), float(np.max(np.abs(mean) / np.sqrt(sig2)))
+            last = dict(generations_end=T, var_ratio_mean=vr, max_abs_mean_over_sigma=mm)
+            if abs(vr - 1.0) < 0.01 and mm < 0.05:
+                first = T
+    finally:
+        e.close()
+    return dict(start="the reference's: theta_0 = 0, varepsilon = 1e-6 (every chain within 1e-3 of the origin)", window_generations=window,
+                gate_first_passed_at_generation=first, gate_pass=first is not None, limit_generations=max_gens, last_window=last)
+
+
 def main(argv=None):
     global CHAINS_PER_GPU
     ap = argparse.ArgumentParser()
@@ -410,6 +625,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-exchange-alternatives", action="store_true", help="N > 1: skip the untimed runs under the exchanges the headline did not use")
     ap.add_argument("--preheat", type=float, default=0.5, help="seconds of untimed steady-state generations before burn-in (0: none)")
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU, help="experiments only; the default is the BASELINE workload")
     ap.add_argument("--exchange", default=None, help="N > 1: push (default) | replay | rows | dense")
@@ -513,7 +729,9 @@ def main(argv=None):
             exchange_info = connect_exchange(eng, dist, rank, world, "push-or-nothing")
             if exchange_info["mode"] == "push":
                 eng.reserve_history(1 + total_gens)
-                got = validate_exchange(eng, dist, X0, make_single, ["push-agent", "push"], gens=min(1000, total_gens), fatal=False)
+                # the headline runs under what the sampler classes select (DeMcMpi._connect_exchange: set_exchange("push") = system-scope packet
+                # fences, what the HSA memory model asks for between agents); the agent-scope form is timed beside it as an alternative
+                got = validate_exchange(eng, dist, X0, make_single, ["push"], gens=min(1000, total_gens), fatal=False)
                 tried += got["validation"]
                 if got.get("mode"):
                     exchange_info.update(got)
@@ -659,6 +877,12 @@ def main(argv=None):
         if not left:
             if rank == 0:
                 sys.stderr.write("bench.py: the ranks' replicas differ at the end of the run and no further exchange candidate is left: " + json.dumps(attempts) + "\n")
+            try:
+                dist.barrier()
+                eng.close()
+                dist.destroy_process_group()
+            except Exception:                                          # noqa: BLE001
+                pass
             return 3
         if rank == 0:
             sys.stderr.write("bench.py: the ranks' replicas differ under exchange %r: measuring again under %r\n" % (exchange_info.get("candidate"), left[0]))
@@ -666,7 +890,7 @@ def main(argv=None):
         eng.set_adapt_state(t_abs=0)
         exchange_info.update(mode="push" if left[0].startswith("push") else left[0], candidate=left[0], candidates_left=left[1:],
                              fence_scope={"push-agent": "agent", "push": "system"}.get(left[0]))
-    eng.close()
+    out = None
     if rank == 0:
         copy_gbs = measured_copy_bandwidth(torch, local_rank)
         out = {
@@ -706,8 +930,50 @@ def main(argv=None):
             out["ranks"] = per_rank
             out["config"]["replicas_identical"] = len(set(p["final_state_sha256_16"] for p in per_rank)) == 1
             out["config"]["exchange"]["attempts_discarded"] = attempts
+            out["config"]["exchange"]["never_measured"] = ("agent-scope packet fences between GPUs (push-agent) have never run on a multi-GPU node; "
+                                                           "the headline uses system scope")
+    # ---- N > 1: the exchanges the headline did not use, outside its timed region; never fatal, bounded by a watchdog (a first contact with RCCL
+    # that hangs must not cost the headline its line: the line is then printed without the alternatives and the ranks leave)
+    if dist is not None and not args.no_exchange_alternatives:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["exchange_alternatives"] = [dict(error="the alternative exchanges did not finish within %d s: line printed without them" % ALT_WATCHDOG_S)]
+                json_out.write(json.dumps(out) + "\n")
+                json_out.flush()
+            os._exit(0)
+        dog = threading.Timer(ALT_WATCHDOG_S, bail)
+        dog.daemon = True
+        dog.start()
+
+        def coll_max(x):
+            t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        try:
+            alts = exchange_alternatives(eng, dist, world, X0, n_chains, make_single, lambda: make_engine(rccl_uid()), (exchange_info or {}).get("mode"),
+                                         coll_max, world if dist.get_backend() == "nccl" else None, share_gpu=args.share_gpu)
+        except BaseException as e:                                     # noqa: BLE001 -- never fatal
+            alts = [dict(error="%s: %s" % (type(e).__name__, e))]
+        dog.cancel()
+        if rank == 0:
+            out["exchange_alternatives"] = alts
+    if dist is not None:
+        dist.barrier()                                                 # (the library orders the teardown itself; this keeps the ranks' exits together)
+    eng.close()
+    if rank == 0:
         if world == 1 and not use_dist and not args.no_other_configs and CHAINS_PER_GPU == 8192:
             out["configs"] = other_configs(local_rank)
+            try:
+                out["configs"].append(host_callback_config(local_rank))
+            except Exception as e:                                     # noqa: BLE001
+                out["configs"].append(dict(config="cfg2 shape with a host-callback ln_like_fn", error=str(e)))
+            if not args.no_moments:
+                try:
+                    out["posterior"]["start_alternatives"] = [posterior_from_reference_start(local_rank)]
+                except Exception as e:                                 # noqa: BLE001
+                    out["posterior"]["start_alternatives"] = [dict(start="the reference's: theta_0 = 0, varepsilon = 1e-6", error=str(e))]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         json_out.write(json.dumps(out) + "\n")

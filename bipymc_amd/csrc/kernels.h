@@ -104,6 +104,26 @@ __device__ __forceinline__ double* cridx_ptr(const Layout& L, uint32_t c) {
     return L.G + (c + rank_of(L, c) * (L.n_local * (L.ld + 1u)) + L.n_local * (L.ld + 1u));
 }
 
+// Kernels with several chains per wavefront (LPC < 64: d <= 32) and a device target keep no per-chain scalars on their path (round 4):
+//   * ln_like of the CURRENT state is re-evaluated from the own row, which the update has in registers anyway, instead of read from the
+//     cache `ll` -- a scattered 8-byte load per update that cost a memory transaction of its own (and, on accept, a scattered 8-byte store).
+//     The value is the one the cache would hold, bit for bit: the same Target::eval on the same row (the row was written by the update that
+//     produced the cached value).  The reference re-evaluates too (samplers.py:330).  The host refreshes the cache with one eval_ll_kernel
+//     where something else reads it (bpm_get_loglike, the outlier check): sampler.hip, ll_stale.
+//   * accepted updates are counted per WAVEFRONT (ballot + popcount) into ACC_SHARDS counters behind the per-chain ones
+//     (acc_count[n_local + shard]); the host sums everything (demc.py:143-150 needs the total only).
+// Timing-only build without that traffic (profiles/r04_small_d.txt): cfg3 11.47 -> 10.47 us per generation, cfg5 47.9 -> 43.4; built for real:
+// 10.9 and 45.3.  It is a RUN-TIME choice of the host (PhaseArgs::lean, the same bits either way): a launch that is latency bound rather
+// than transaction bound -- cfg5's per-GPU share, 32768 chains: one wavefront per SIMD -- pays for the extra exp / log of the re-evaluation
+// (9.3 -> 9.9 us per generation) and keeps the cached form; from 49152 chains per GPU the lean form runs.
+constexpr int ACC_SHARDS = 1024;
+template <int TARGET, int LPC>
+constexpr bool lean_scalars() { return LPC < WAVE && TARGET != TARGET_HOST; }
+// ... and where the target costs a dozen flops (the banana: no exp, no log) the lean form is the only one compiled: as a run-time switch it
+// cost cfg3 0.2 us per generation (11.1 instead of 10.9)
+template <int TARGET>
+constexpr bool lean_always() { return TARGET == TARGET_BANANA; }
+
 constexpr int PLAN_WORDS = 16;    // chain id | header block (4 words) | up to 10 partner ids | pad
 constexpr int MAX_SEG = 16;       // ranks the owner-sorted record table serves (more: records by position, a wavefront per position replays)
 constexpr int MAX_PEERS = MAX_SEG - 1;   // other ranks an owner pushes its accepted rows to (push exchange)
@@ -179,6 +199,8 @@ struct PhaseArgs {
     uint32_t hist_by_pos;       // 1: the history row and its ln-like are appended at the update's POSITION in this generation's shuffle order
                                 // (work items of a wavefront write consecutive rows) instead of at the chain's index; the host remembers the
                                 // generation, and rows are put back into chain order when anything reads them (sampler.hip: normalize_history)
+    uint32_t lean;              // 1 (several chains per wavefront, device target, many chains): ln_like of the current state is re-evaluated from the own
+                                // row instead of read from `ll`, `ll` is not written, accepted updates are counted per wavefront (kernels.h: lean_scalars)
     uint32_t wt;                // 1: the dispatch packet of this launch carries NO release fence -- what a later kernel reads (accepted state
                                 // rows, ln-like cache, accept counters) leaves through agent-scope (write-through) stores (store_row_wt)
     uint64_t seed;
@@ -591,10 +613,14 @@ __device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c)
 
 // Build the proposal of chain c (dream.py:43-93 / demc.py:161-182).
 // ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
-template <int ALGO, int LPC, int DPL, int NP>
+struct NoEarly { template <class W> __device__ __forceinline__ void operator()(W&) const {} };
+// EARLY: work on the own row (wk.x) that the caller wants done while the partner rows are still on their way -- the re-evaluation of the
+// current state's ln_like (lean_scalars): behind the proposal it sat on the critical path of the latency-bound launches (cfg5's share:
+// 10.05 instead of 9.3 us per generation), here it runs in the shadow of the partner fetches.
+template <int ALGO, int LPC, int DPL, int NP, int LOAD_LL = 1 /* 1 always, 0 never, 2 unless a.lean */, class EARLY = NoEarly>
 __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
                                               uint32_t* s_part, Work<DPL>& wk, const uint32_t* rec = nullptr,
-                                              unsigned long long* bpm_stamp = nullptr) {
+                                              unsigned long long* bpm_stamp = nullptr, EARLY early = EARLY()) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
     // FAST: partner ids straight into registers, every lane for itself, when a lane IS a chain (LPC == 1: no other
     // lane to share the work with, so the LDS hand-over loop would only re-evaluate the same Philox block once per
@@ -612,7 +638,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)      // timing experiment only (wrong results): what the chain-indexed ln-like cache and accept counter cost
         if (LPC < WAVE) wk.ll_cur = wk.x[0] * 1e-300; else
 #endif
-        wk.ll_cur = a.ll[c - a.lo];
+        if (LOAD_LL == 1 || (LOAD_LL == 2 && !a.lean)) wk.ll_cur = a.ll[c - a.lo];   // (else: the caller re-evaluates it from wk.x -- lean_scalars)
         // the accept counter: one wavefront per chain reads it here (a scalar load, early) and stores + 1 on accept; with several chains per
         // wavefront the read is a scattered 4-byte load per update -- there an accepted update bumps it with a device-scope atomic add without
         // return instead (one writer per address and launch: nothing serialises): cfg3 12.7 -> 11.9 us per generation, cfg5 52.2 -> 48.2
@@ -777,6 +803,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     }
     BPM_STAMP(7);
     if (dims_late) wpair[0] = chain_block(a.seed, c, a.t, SLOT_DIM0 + (uint32_t)q);      // overlaps with the row fetches
+    if (DREAM) early(wk);
 
     // ---- per-pair draws: one Philox block per coordinate pair
     double eps_n[DPL], eps_u[DPL];
@@ -917,6 +944,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         const uint32_t cb = ids_in_regs ? part.get(1) : part.lds[1];
         load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
         load_row<LPC, DPL>(row_ptr(a.L, cb), q, ld, rb);
+        early(wk);
 #pragma unroll
         for (int s = 0; s < DPL; ++s) {
             double pv = gamma * (ra[s] - rb[s]);
@@ -987,7 +1015,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 }
 
 // Metropolis test (samplers.py:328-336), append (chain.py:51-54), Welford moments, CR outputs.
-template <int ALGO, int LPC, int DPL>
+template <int ALGO, int LPC, int DPL, int LEAN = 0 /* 0 never, 1 when a.lean, 2 always */>
 __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bool active, int q,
                                               const Work<DPL>& wk, double ll_prop) {
     const uint32_t ld = a.L.ld;
@@ -998,11 +1026,18 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     alpha = fmin(1.0, alpha);
     alpha = fmax(0.0, alpha);                            // np.clip(np.min((1, .)), 0, 1); NaN stays NaN in NumPy
     const bool accepted = !is_nan && (u01_53(wk.acc_hi, wk.acc_lo) < alpha);
+    const bool lean = LEAN == 2 || (LEAN == 1 && a.lean != 0u);
+    if (lean) {      // one counter bump per wavefront (all lanes are still here): acc_count[n_local + shard]
+        const unsigned long long m = __ballot(active && accepted && q == 0);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && m != 0ull)
+            __hip_atomic_fetch_add(&a.acc_count[a.L.n_local + ((blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE)) & (ACC_SHARDS - 1))],
+                                   (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!active) return;
     // accept bookkeeping without same-address atomics (8192 of them serialise at ~12 ns each):
     // every chain owns one counter, the host sums them (demc.py:143-150)
     if (q == 0) {
-        if (accepted) {
+        if (accepted && !lean) {
 #if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)
             if (LPC < WAVE) {} else
 #endif
@@ -1020,20 +1055,21 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     if (a.x_next) {
         // synchronous generation (samplers.py:300-308 delayed_accept): updates are banked, applied after the launch
         store_row<LPC, DPL>(a.x_next + (uint32_t)(li * ld), q, ld, nv);
-        if (accepted && q == 0) a.ll[li] = new_ll;
+        if (accepted && q == 0 && !lean) a.ll[li] = new_ll;
     } else if (accepted) {
+        // (lean: the ln-like cache is not written -- nothing on this path reads it, the host refreshes it on demand)
         if (a.wt == 2u) {
             store_row_wt16<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
 #if defined(BPM_TEST_HOOKS) && defined(BPM_FAKE_NO_LL)
             if (LPC < WAVE) {} else
 #endif
-            if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == 0 && !lean) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (a.wt) {
             store_row_wt<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
-            if (q == 0) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == 0 && !lean) __hip_atomic_store(&a.ll[li], new_ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             store_row<LPC, DPL>(row_ptr(a.L, c), q, ld, nv);
-            if (q == 0) a.ll[li] = new_ll;
+            if (q == 0 && !lean) a.ll[li] = new_ll;
         }
     }
     if (a.pack && accepted) {
@@ -1248,15 +1284,21 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     Work<DPL> wk;
     wk.item = w;
     wk.pos_own = a.upd_off + (active ? w : 0u);
+    constexpr bool LEAN = lean_scalars<TARGET, LPC>();
+    // (LEAN: ln_like of the current state from the own row == the cached value, bit for bit -- see lean_scalars)
+    const uint32_t dim_early = a.L.dim;      // (captured by value, a few registers: a by-reference capture put one instantiation's constants on the stack)
+    constexpr bool LEAN_CT = LEAN && lean_always<TARGET>();
+    const bool lean_early = LEAN_CT || (LEAN && a.lean != 0u);
+    auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
 #ifdef BPM_STAMPS
     bpm_stamp[1] = 0; BPM_STAMP(1);
-    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp);
+    make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : (LEAN ? 2 : 1))>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp, early);
 #else
-    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec);
+    make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : (LEAN ? 2 : 1))>(a, c, active, q, cw, s_part, wk, rec, nullptr, early);
 #endif
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     BPM_STAMP(5);
-    finish_update<ALGO, LPC, DPL>(a, c, active, q, wk, ll_prop);
+    finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0))>(a, c, active, q, wk, ll_prop);
     BPM_STAMP(6);
 #ifdef BPM_STAMPS
     if (bpm_stamp[2] == 0) bpm_stamp[2] = bpm_rt0;
@@ -2204,17 +2246,18 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_partial_kernel(const doub
         const uint32_t p = p0 + threadIdx.x % ppp, r = threadIdx.x / ppp;
         double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0;
         if (r < rpi && p < np) {
-            const double2 sh = reinterpret_cast<const double2*>(shift)[p];
+            const double shx = shift[2u * p], shy = shift[2u * p + 1u];      // (two scalars: as a double2 the pair lived in scratch memory across the loop)
             for (uint64_t m = b0 + r; m < b1; m += (uint64_t)rpi * MOM_UNR) {
                 double2 v[MOM_UNR];
 #pragma unroll
                 for (int u = 0; u < MOM_UNR; ++u) {
                     const uint64_t mm = m + (uint64_t)u * rpi;
-                    v[u] = mm < b1 ? reinterpret_cast<const double2*>(H + mm * ld)[p] : sh;
+                    v[u] = make_double2(shx, shy);
+                    if (mm < b1) v[u] = reinterpret_cast<const double2*>(H + mm * ld)[p];
                 }
 #pragma unroll
                 for (int u = 0; u < MOM_UNR; ++u) {
-                    const double d0 = v[u].x - sh.x, d1 = v[u].y - sh.y;
+                    const double d0 = v[u].x - shx, d1 = v[u].y - shy;
                     sa0 += d0; sb0 += d0 * d0;
                     sa1 += d1; sb1 += d1 * d1;
                 }

@@ -32,6 +32,7 @@
 
 #include "../../include/bipymc_hip.h"
 #include "kernels.h"
+#include "kernels_wide.h"
 #ifdef BPM_TEST_HOOKS
 #include "rocrand_check.h"
 #endif
@@ -224,7 +225,7 @@ static void launch_hot(const PhaseArgs& a, hipStream_t s) {
 template <int ALGO, int T, int NP, int LPC, int DPL>
 static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 #ifdef BPM_PRELOAD
-    if constexpr (DPL <= 8) {   // frequent cases take a specialised instantiation (kernels.h: HOT): steady state, DREAM's burn-in, a rank of a world (d <= 512)
+    {   // frequent cases take a specialised instantiation (kernels.h: HOT): steady state, DREAM's burn-in, a rank of a world
         constexpr bool CAN_PLAN = (LPC == WAVE && DPL == 2);               // the shape that can read plan records
         const bool wp = CAN_PLAN && a.rec_tab != nullptr;
         constexpr bool DREAM_ = ALGO == ALGO_DREAM;
@@ -279,25 +280,59 @@ static bool pick_shape(uint32_t ld, Shape& sh) {
     else if (np <= 64) sh = {64, 2, 3};   // (two / four chains per wavefront, 32x4 and 16x8, measured no faster: DESIGN.md)
     else if (np <= 128) sh = {64, 4, 4};
     else if (np <= 256) sh = {64, 8, 5};
-    else if (np <= 512) sh = {64, 16, 6};     // d <= 1024, 2048: the same kernels with 8 / 16 coordinate pairs per lane (general instantiation only)
-    else if (np <= 1024) sh = {64, 32, 7};
-    else return false;
+    // d > 512: one wavefront per chain LOOPING over the row (kernels_wide.h) -- no dimension limit, no scratch.  (Round 3 had 16 and 32 coordinates
+    // per lane for d <= 1024 / 2048: the looped kernel is faster than the first -- 0.71 / 0.74 / 0.76 of the HBM roof at d = 640 / 1000 / 1024 against
+    // 0.56 / 0.71 / 0.74 -- and replaces the second, which spilled: profiles/r04_wide_rows.txt.)
+    else sh = {64, 0, 6};
     return true;
 }
-#define SHAPE_TABLE(FN, ...)                                                                     \
+constexpr int SHAPE_WIDE = 6;
+// [shape]: the register-resident kernels by (lanes per chain, coordinates per lane), then the looped wide-row kernel
+#define SHAPE_TABLE(FN, WIDE, ...)                                                               \
     {FN<__VA_ARGS__ 1, 2>, FN<__VA_ARGS__ 4, 2>, FN<__VA_ARGS__ 16, 2>, FN<__VA_ARGS__ 64, 2>, \
-     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>, FN<__VA_ARGS__ 64, 16>, FN<__VA_ARGS__ 64, 32>}
+     FN<__VA_ARGS__ 64, 4>, FN<__VA_ARGS__ 64, 8>, WIDE}
 #define COMMA ,
+// ---- the looped wide-row kernels (kernels_wide.h): same argument block and launch paths as phase_fused_kernel
+template <int ALGO, int T, int NP>
+static void launch_wide(const PhaseArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.n_items + (BPM_BLOCK_WAVE / WAVE) - 1) / (BPM_BLOCK_WAVE / WAVE));
+#ifdef BPM_PRELOAD
+    static hipFunction_t fn = nullptr;
+    launch_packed(phase_wide_kernel<ALGO, T, NP, STAGE_FUSED>, fn, a, grid, (unsigned)BPM_BLOCK_WAVE, s);
+#else
+    hipExtLaunchKernelGGL((phase_wide_kernel<ALGO, T, NP, STAGE_FUSED>), dim3(grid), dim3(BPM_BLOCK_WAVE), 0, s, nullptr, take_stop_event(), 0, a);
+    ++g_timed_launches;
+#endif
+}
+template <int ALGO>
+static void launch_wide_propose(const PhaseArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.n_items + (BPM_BLOCK_WAVE / WAVE) - 1) / (BPM_BLOCK_WAVE / WAVE));
+#ifdef BPM_PRELOAD
+    hipLaunchKernelGGL((phase_wide_kernel<ALGO, TARGET_HOST, 0, STAGE_PROPOSE>), dim3(grid), dim3(BPM_BLOCK_WAVE), 0, s, a.rec_tab, a.rec_off, a.n_items, a.mode, a);
+#else
+    hipLaunchKernelGGL((phase_wide_kernel<ALGO, TARGET_HOST, 0, STAGE_PROPOSE>), dim3(grid), dim3(BPM_BLOCK_WAVE), 0, s, a);
+#endif
+}
+template <int ALGO>
+static void launch_wide_commit(const PhaseArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.n_items + (BPM_BLOCK_WAVE / WAVE) - 1) / (BPM_BLOCK_WAVE / WAVE));
+    hipLaunchKernelGGL((phase_wide_commit_kernel<ALGO>), dim3(grid), dim3(BPM_BLOCK_WAVE), 0, s, a);
+}
+template <int T>
+static void launch_eval_wide(const double* X, uint32_t n, uint32_t ld, uint32_t dim, const double* tp, double* out, hipStream_t s) {
+    hipLaunchKernelGGL((eval_ll_wide_kernel<T>), dim3((n + (BPM_BLOCK_WAVE / WAVE) - 1) / (BPM_BLOCK_WAVE / WAVE)), dim3(BPM_BLOCK_WAVE), 0, s, X, n, ld, dim, tp, out);
+}
 // update-kernel variants: [DE-MC (1 pair) | DREAM del_pairs = 3 (compile-time) | DREAM any del_pairs][shape]
-static PhaseLaunch g_fused_gauss[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
-                                          SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
-                                          SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
-static PhaseLaunch g_fused_mixture[3][8] = {SHAPE_TABLE(launch_fused, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
-                                            SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
-                                            SHAPE_TABLE(launch_fused, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
+static PhaseLaunch g_fused_gauss[3][7] = {SHAPE_TABLE(launch_fused, launch_wide<ALGO_DEMC COMMA TARGET_GAUSS COMMA 1>, ALGO_DEMC COMMA TARGET_GAUSS COMMA 1 COMMA),
+                                          SHAPE_TABLE(launch_fused, launch_wide<ALGO_DREAM COMMA TARGET_GAUSS COMMA 3>, ALGO_DREAM COMMA TARGET_GAUSS COMMA 3 COMMA),
+                                          SHAPE_TABLE(launch_fused, launch_wide<ALGO_DREAM COMMA TARGET_GAUSS COMMA 0>, ALGO_DREAM COMMA TARGET_GAUSS COMMA 0 COMMA)};
+static PhaseLaunch g_fused_mixture[3][7] = {SHAPE_TABLE(launch_fused, launch_wide<ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1>, ALGO_DEMC COMMA TARGET_MIXTURE COMMA 1 COMMA),
+                                            SHAPE_TABLE(launch_fused, launch_wide<ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3>, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 3 COMMA),
+                                            SHAPE_TABLE(launch_fused, launch_wide<ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0>, ALGO_DREAM COMMA TARGET_MIXTURE COMMA 0 COMMA)};
 static PhaseLaunch g_fused_banana[3] = {launch_fused<ALGO_DEMC, TARGET_BANANA, 1, 1, 2>, launch_fused<ALGO_DREAM, TARGET_BANANA, 3, 1, 2>,
                                         launch_fused<ALGO_DREAM, TARGET_BANANA, 0, 1, 2>};
-static PhaseLaunch g_propose[2][8] = {SHAPE_TABLE(launch_propose, ALGO_DEMC COMMA), SHAPE_TABLE(launch_propose, ALGO_DREAM COMMA)};
+static PhaseLaunch g_propose[2][7] = {SHAPE_TABLE(launch_propose, launch_wide_propose<ALGO_DEMC>, ALGO_DEMC COMMA),
+                                      SHAPE_TABLE(launch_propose, launch_wide_propose<ALGO_DREAM>, ALGO_DREAM COMMA)};
 template <int ALGO, int NP, int LPC, int DPL>
 static void launch_replay(const PhaseArgs& a, hipStream_t s) {
     // (a workgroup per 64 positions that compacts the remote accepted chains in LDS and rebuilds only those -- 8192 wavefronts
@@ -313,15 +348,17 @@ static void launch_replay_sorted(const PhaseArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((phase_replay_sorted_kernel<ALGO, DPL, NP>), dim3((max_cnt + REPLAY_WG / WAVE - 1) / (REPLAY_WG / WAVE), a.n_seg), dim3(REPLAY_WG),
                        0, s, a);
 }
-// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][dims per lane 2 / 4 / 8 / 16 / 32]: owner-sorted records exist for one wavefront per chain only
-#define RS_ROW(A, P) {launch_replay_sorted<A, P, 2>, launch_replay_sorted<A, P, 4>, launch_replay_sorted<A, P, 8>, launch_replay_sorted<A, P, 16>, launch_replay_sorted<A, P, 32>}
-static PhaseLaunch g_replay_sorted[3][5] = {RS_ROW(ALGO_DEMC, 1), RS_ROW(ALGO_DREAM, 3), RS_ROW(ALGO_DREAM, 0)};
+// [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][dims per lane 2 / 4 / 8]: owner-sorted records exist for one wavefront per chain only
+#define RS_ROW(A, P) {launch_replay_sorted<A, P, 2>, launch_replay_sorted<A, P, 4>, launch_replay_sorted<A, P, 8>}
+static PhaseLaunch g_replay_sorted[3][3] = {RS_ROW(ALGO_DEMC, 1), RS_ROW(ALGO_DREAM, 3), RS_ROW(ALGO_DREAM, 0)};
 // [DE-MC | DREAM del_pairs = 3 | DREAM any del_pairs][shape]: the same pair-count variants as the update kernels (no target: no ln-like)
-static PhaseLaunch g_replay[3][8] = {SHAPE_TABLE(launch_replay, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 3 COMMA),
-                                     SHAPE_TABLE(launch_replay, ALGO_DREAM COMMA 0 COMMA)};
-static PhaseLaunch g_commit[2][8] = {SHAPE_TABLE(launch_commit, ALGO_DEMC COMMA), SHAPE_TABLE(launch_commit, ALGO_DREAM COMMA)};
-static EvalLaunch g_eval_gauss[8] = SHAPE_TABLE(launch_eval, TARGET_GAUSS COMMA);
-static EvalLaunch g_eval_mixture[8] = SHAPE_TABLE(launch_eval, TARGET_MIXTURE COMMA);
+// (wide rows have no replay kernel: a world of wide-row samplers exchanges by push or by the dense all-gather -- bpm_set_exchange refuses the rest)
+static PhaseLaunch g_replay[3][7] = {SHAPE_TABLE(launch_replay, nullptr, ALGO_DEMC COMMA 1 COMMA), SHAPE_TABLE(launch_replay, nullptr, ALGO_DREAM COMMA 3 COMMA),
+                                     SHAPE_TABLE(launch_replay, nullptr, ALGO_DREAM COMMA 0 COMMA)};
+static PhaseLaunch g_commit[2][7] = {SHAPE_TABLE(launch_commit, launch_wide_commit<ALGO_DEMC>, ALGO_DEMC COMMA),
+                                     SHAPE_TABLE(launch_commit, launch_wide_commit<ALGO_DREAM>, ALGO_DREAM COMMA)};
+static EvalLaunch g_eval_gauss[7] = SHAPE_TABLE(launch_eval, launch_eval_wide<TARGET_GAUSS>, TARGET_GAUSS COMMA);
+static EvalLaunch g_eval_mixture[7] = SHAPE_TABLE(launch_eval, launch_eval_wide<TARGET_MIXTURE>, TARGET_MIXTURE COMMA);
 
 // ---- the sampler ------------------------------------------------------------------------
 struct bpm_sampler {
@@ -485,6 +522,10 @@ struct bpm_sampler {
     bool outlier_due = false;    // set by finish_generation, served by the group driver (all ranks take part)
     // per-generation cache (host-callback path keeps it between propose and commit)
     PhaseArgs cur_args[2];
+    // several chains per wavefront + device target (kernels.h: lean_scalars): the update kernels neither read nor write the ln-like cache `ll`
+    // (they re-evaluate it from the own row); ll_stale says that generations have run since it was last evaluated -- refresh_ll brings it up
+    // to date for whoever reads it (bpm_get_loglike, the outlier check)
+    bool lean = false, ll_stale = false;
     bool gen_adapt_on = false;
     bool gen_cr_reduce = false;       // this generation's (delta, cr) slots are reduced (adaptation on AND the gate of dream.py:123 open)
 };
@@ -645,6 +686,14 @@ static int eval_local_ll(bpm_sampler* s) {
     return 0;
 }
 
+// the ln-like cache of the local chains, current again (stream work: the caller has drained the library's own queue)
+static int refresh_ll(bpm_sampler* s) {
+    if (!s->ll_stale) return 0;
+    CK(eval_local_ll(s));
+    s->ll_stale = false;
+    return 0;
+}
+
 // History rows [r0, r1) into chain order (see bpm_sampler::hist_by_pos).  On the sampler's stream: the caller has drained the library's
 // own queue (check_handle / StreamSection).
 static int normalize_history(bpm_sampler* s, int64_t r0, int64_t r1) {
@@ -715,6 +764,7 @@ static int push_gen_sums(bpm_sampler* s, int64_t row, const double* src = nullpt
 // after the state matrix was (re)initialised: history := [state], moments reset
 static int reset_history(bpm_sampler* s) {
     CK(eval_local_ll(s));
+    s->ll_stale = false;
     s->hist_rows = 0;
     s->rows_logical = 1;
     s->w_rows = 0;
@@ -884,8 +934,10 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     s->rank = (uint32_t)cfg->rank;
     s->n_local = s->N / s->world;
     s->lo = s->rank * s->n_local;
-    if (!pick_shape(s->ld, s->shape)) { delete s; return fail("bpm_create: dim > 2048 not supported"); }
-    s->shape_needs_scratch = s->shape.dpl > 16;
+    (void)pick_shape(s->ld, s->shape);
+    // (the one limit on dim: a coordinate pair's Philox block is addressed by a 16-bit slot, philox.h: SLOT_BITS)
+    if (s->dim / 2u + SLOT_DIM0 >= (1u << SLOT_BITS)) { delete s; return fail("bpm_create: dim must stay below 131056 (16-bit Philox slot per coordinate pair)"); }
+    s->shape_needs_scratch = false;        // (round 3's 32-coordinates-per-lane shape spilled to scratch memory; the looped kernel replaced it)
     if ((uint64_t)s->N * (s->ld + 2) >= (1ull << 31)) { delete s; return fail("bpm_create: n_chains * (dim + 2) must stay below 2^31 (32-bit device offsets)"); }
     const int tid = cfg->target_id;
     const int np = cfg->n_target_params;
@@ -988,7 +1040,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc_state(&s->ll, s->n_local, s->coherent));
     CKD(dev_alloc_state(&s->w_mean, row_d, s->coherent));
     CKD(dev_alloc_state(&s->w_m2, row_d, s->coherent));
-    CKD(dev_alloc(&s->tparams, (size_t)np));
+    CKD(dev_alloc(&s->tparams, (size_t)np + 2));       // (+2: the wide-row kernels read the Gaussian's 1/sigma as pairs)
+    HIPCKD(hipMemsetAsync(s->tparams, 0, ((size_t)np + 2) * sizeof(double), s->stream));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
     CKD(dev_alloc_state(&s->cr_state, 3 * MAX_CR, s->coherent));
     if (cfg->algo == BPM_ALGO_DREAM) {       // (+ the ticket of the one-dispatch form behind the sums)
@@ -1002,6 +1055,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipStreamSynchronize(s->stream));
     }
     // position-ordered history append: one wavefront per chain writes whole 128-byte lines whatever the row's place, nothing to gain there
+    // the lean form of the small-d update kernels (kernels.h: lean_scalars) where a launch is transaction bound: from 49152 chains per GPU
+    // (cfg3's 65536 and cfg5's 262144 gain 0.6 / 2.6 us per generation, cfg5's per-GPU share of 32768 would lose 0.6)
+    // (the banana's kernels have the lean form only: its ln_like is a dozen flops)
+    s->lean = s->shape.idx < 3 && tid != BPM_TARGET_HOST_CALLBACK &&
+              (tid == BPM_TARGET_BANANA_2D || ((s->n_local >= 49152u || test_path("lean")) && !test_path("nolean")));
     s->hist_by_pos = s->world == 1 && s->shape.idx < 3 && cfg->keep_history != 0 && tid != BPM_TARGET_HOST_CALLBACK && cfg->algo != BPM_ALGO_DEMC_SYNC &&
                      !test_path("histchain");
     if (s->hist_by_pos) CKD(dev_alloc(&s->hist_tmp, (size_t)s->n_local * (s->ld + 1)));
@@ -1011,8 +1069,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         CKD(dev_alloc(&s->gs_part, (size_t)s->gs_nb * 2 * s->ld));
     }
     CKD(dev_alloc(&s->counters, 8));      // [2] NaN ratios of this run; [4] outlier resets since creation
-    CKD(dev_alloc_state(&s->acc_count, s->n_local, s->coherent));
-    HIPCKD(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));
+    CKD(dev_alloc_state(&s->acc_count, (size_t)s->n_local + ACC_SHARDS, s->coherent));      // per-chain counters | per-wavefront shards (kernels.h: lean_scalars)
+    HIPCKD(hipMemsetAsync(s->acc_count, 0, ((size_t)s->n_local + ACC_SHARDS) * sizeof(uint32_t), s->stream));
     HIPCKD(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), s->stream));
     if (want_om) {
         if (!s->om) CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
@@ -1096,8 +1154,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         const char* xe = getenv("BPM_EXCHANGE");
         const bool want_dense = xe && std::strcmp(xe, "dense") == 0;
         const bool want_rows = xe && std::strcmp(xe, "rows") == 0;
-        s->replay_enabled = !want_dense && !want_rows;
-        s->sparse_enabled = !want_dense && want_rows;
+        s->replay_enabled = !want_dense && !want_rows && s->shape.idx != SHAPE_WIDE;      // (wide rows: dense, or push once connected)
+        s->sparse_enabled = !want_dense && want_rows && s->shape.idx != SHAPE_WIDE;
         CKD(dev_alloc(&s->accbits_all, (size_t)s->N));
         HIPCKD(hipMemsetAsync(s->accbits_all, 0, (size_t)s->N, s->stream));
         s->xnsub = 1u;
@@ -1115,7 +1173,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         HIPCKD(hipMemsetAsync(s->xstat, 0, 2 * sizeof(uint32_t), s->stream));
         CKD(dev_alloc(&s->ckpt_G, (size_t)s->world * s->L.blk));
         CKD(dev_alloc(&s->ckpt_ll, s->n_local));
-        CKD(dev_alloc(&s->ckpt_acc, s->n_local));
+        CKD(dev_alloc(&s->ckpt_acc, (size_t)s->n_local + ACC_SHARDS));
         CKD(dev_alloc(&s->ckpt_counters, 4));
     }
     HIPCKD(hipStreamSynchronize(s->stream));
@@ -1192,6 +1250,7 @@ extern "C" int bpm_set_loglike(bpm_handle_t s, const double* ll_local) {
 extern "C" int bpm_get_loglike(bpm_handle_t s, double* ll_local) {
     CK(check_handle(s));
     CK(set_device(s));
+    CK(refresh_ll(s));
     HIPCK(hipMemcpyAsync(ll_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     return 0;
@@ -1215,7 +1274,7 @@ extern "C" int bpm_begin_run(bpm_handle_t s, const bpm_run_opts_t* o) {
     s->k_gen = 0;                                                                    // demc.py:78
     s->phase = 0;
     HIPCK(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), s->stream));
-    HIPCK(hipMemsetAsync(s->acc_count, 0, s->n_local * sizeof(uint32_t), s->stream));     // demc.py:67
+    HIPCK(hipMemsetAsync(s->acc_count, 0, ((size_t)s->n_local + ACC_SHARDS) * sizeof(uint32_t), s->stream));     // demc.py:67
     HIPCK(hipStreamSynchronize(s->stream));
     s->run_open = true;
     // the tables of the window this run starts in (and of the next one) are built from here on, beside whatever the caller does
@@ -1437,6 +1496,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         const bool outlier_phase = dream && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen;
         a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr && !outlier_phase) ? 1u : 0u;
         { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
+        a.lean = s->lean ? 1u : 0u;
         a.algo = (uint32_t)s->cfg.algo;
         a.P = (uint32_t)s->cfg.del_pairs;
         a.n_cr = (uint32_t)s->cfg.n_cr;
@@ -1469,6 +1529,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
 }
 
 static int finish_generation(bpm_sampler* s) {
+    if (s->lean) s->ll_stale = true;
     if (s->gen_adapt_on && !s->gen_cr_reduce) s->w_rows += 1;       // (the update kernels advanced the Welford moments all the same)
     if (s->gen_cr_reduce) {
         // this generation's (delta, cr) slots -> partial sums -> totals, p_cr (kernels.h: "CR reduction in two dispatches"; beyond
@@ -1611,6 +1672,7 @@ static int group_outlier_check(const Group& g) {
         s->outlier_due = false;
         if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
         CK(normalize_history(s, 0, s->hist_rows));          // (omega and the repair of the last row go by chain)
+        CK(refresh_ll(s));                                   // (the (omega | ln-like) block carries the chains' current ln-like)
         const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
         hipLaunchKernelGGL(outlier_omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->ll, s->n_local, r0, rows,
                            s->om + (size_t)s->rank * 2 * s->n_local);
@@ -1710,7 +1772,7 @@ static int exchange_sparse(const Group& g) {
 
 static void launch_replay_any(bpm_sampler* s, const PhaseArgs& a) {
     const int v = s->cfg.algo != BPM_ALGO_DREAM ? 0 : (s->cfg.del_pairs == 3 ? 1 : 2);
-    if (a.rec_sorted && s->shape.idx >= 3) g_replay_sorted[v][s->shape.idx - 3](a, s->stream);
+    if (a.rec_sorted && s->shape.idx >= 3 && s->shape.idx < SHAPE_WIDE) g_replay_sorted[v][s->shape.idx - 3](a, s->stream);
     else g_replay[v][s->shape.idx](a, s->stream);
 }
 
@@ -1913,7 +1975,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             hc[(size_t)r] = HostCkpt{s->k_gen, s->t_abs, s->hist_rows, s->rows_logical, s->w_rows};
             HIPCK(hipMemcpyAsync(s->ckpt_G, s->G, (size_t)s->world * s->L.blk * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
             HIPCK(hipMemcpyAsync(s->ckpt_ll, s->ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-            HIPCK(hipMemcpyAsync(s->ckpt_acc, s->acc_count, (size_t)s->n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+            HIPCK(hipMemcpyAsync(s->ckpt_acc, s->acc_count, ((size_t)s->n_local + ACC_SHARDS) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
             HIPCK(hipMemcpyAsync(s->ckpt_counters, s->counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
             HIPCK(hipMemsetAsync(s->xstat, 0, 2 * sizeof(uint32_t), s->stream));
             for (uint32_t b = 0; b < s->xnsub; ++b)      // own counters armed (the capacity, hence the layout, may have changed)
@@ -1939,7 +2001,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 bpm_sampler* s = g.h[r];
                 HIPCK(hipMemcpyAsync(s->G, s->ckpt_G, (size_t)s->world * s->L.blk * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
                 HIPCK(hipMemcpyAsync(s->ll, s->ckpt_ll, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-                HIPCK(hipMemcpyAsync(s->acc_count, s->ckpt_acc, (size_t)s->n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+                HIPCK(hipMemcpyAsync(s->acc_count, s->ckpt_acc, ((size_t)s->n_local + ACC_SHARDS) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
                 HIPCK(hipMemcpyAsync(s->counters, s->ckpt_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
                 const HostCkpt& k = hc[(size_t)r];
                 s->k_gen = k.k_gen; s->t_abs = k.t_abs; s->hist_rows = k.hist_rows; s->rows_logical = k.rows_logical; s->w_rows = k.w_rows;
@@ -2004,6 +2066,8 @@ extern "C" int bpm_set_exchange(bpm_handle_t s, int32_t mode, int32_t cap) {
     if (mode == 3 && s->push_failed) return fail("bpm_set_exchange: a wait of the push exchange ran into its limit earlier (the ranks' barrier counters no longer agree): this sampler can only go on with an RCCL exchange");
     if (mode != 3 && s->push_no_rccl) return fail("bpm_set_exchange: this sampler was created without an RCCL communicator: the push exchange is its only one");
     if (!s->PK) return mode ? fail("bpm_set_exchange: this sampler only has the dense exchange (world_size 1, synchronous DE-MC or host callback)") : 0;
+    if ((mode == 1 || mode == 2) && s->shape.idx == SHAPE_WIDE)
+        return fail("bpm_set_exchange: rows wider than 512 coordinates exchange by push (3) or by the dense all-gather (0): the looped kernel has no replay / packed-rows form");
     if (s->push_enabled && mode != 3) s->cur = -1;      // (windows built with this rank's records only are rebuilt: ensure_perm_table)
     if (s->push_failed && mode != 3) {                  // leaving a push exchange that timed out: the next bpm_synchronize must not report it again
         CK(set_device(s));
@@ -2681,10 +2745,10 @@ extern "C" int bpm_get_stats(bpm_handle_t s, bpm_stats_t* out) {
     if (!out) return fail("bpm_get_stats: null argument");
     unsigned long long c[8];
     double cr[3 * MAX_CR];
-    std::vector<uint32_t> acc(s->n_local);
+    std::vector<uint32_t> acc((size_t)s->n_local + ACC_SHARDS);       // per-chain counters and per-wavefront shards: the total is what counts
     HIPCK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipMemcpyAsync(cr, s->cr_state, sizeof(cr), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipMemcpyAsync(acc.data(), s->acc_count, s->n_local * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipMemcpyAsync(acc.data(), s->acc_count, acc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
     std::memset(out, 0, sizeof(*out));
     int64_t n_acc = 0;

@@ -24,9 +24,9 @@ def case_spec(case):
                 dict(burnin_gen=30, n_cr_gen=3, del_pairs=2, outlier_every=10), 45)
     if case == "demc_banana_snooker":
         return banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 40, dict(p_snooker=0.3), 25
-    if case == "dream_gauss700":           # 16 coordinates per lane (d <= 1024): the general update kernel with pushes
+    if case == "dream_gauss700":           # the looped wide-row kernel (d > 512) with pushes
         return d100_gauss.Gauss_100D(dim=700)._bpm_target_spec(), L.ALGO_DREAM, 48, dict(burnin_gen=6, n_cr_gen=2), 14
-    if case == "dream_gauss1300":          # 32 coordinates per lane (d <= 2048): spills to scratch, HIP stream launches even where ranks have queues
+    if case == "dream_gauss1300":          # the looped wide-row kernel (kernels_wide.h) pushing its accepted rows chunk by chunk
         return d100_gauss.Gauss_100D(dim=1300)._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=6, n_cr_gen=2), 12
     if case == "cfg4_shape":          # BASELINE configs[3] per-rank shape: 8192 chains of the 100-D Gaussian per rank
         return d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, None, dict(burnin_gen=4, n_cr_gen=2), 12

@@ -126,3 +126,26 @@ def test_destroy_plan_never_frees_under_a_failed_queue(built_test):
     assert lib.bpm_debug_destroy_plan(0, 0) == 1        # (no failure: nothing can still run)
     assert lib.bpm_debug_destroy_plan(1, 1) == 1        # failed, then inactivated: free
     assert lib.bpm_debug_destroy_plan(1, 0) == 0        # failed and not quiesced: LEAK
+
+
+def test_no_kernel_spills_or_touches_scratch_memory(built):
+    """kernels are dispatched through the library's own AQL queue by what the code object says about them.  No kernel of the
+    library may spill registers or execute a scratch instruction -- whatever its shape (round 3's 32-coordinates-per-lane update kernel spilled
+    ~1 KB per lane and had to stay on the HIP stream; the looped wide-row kernel replaced it).  Read from the code object's metadata and its
+    disassembly; no GPU needed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import LLVM, kernel_resources
+    ks = kernel_resources(built)
+    assert len(ks) > 150
+    assert not [k["name"] for k in ks if k["spill"] != 0]
+    wide = [k for k in ks if "phase_wide_kernel" in k["name"] or "eval_ll_wide" in k["name"] or "phase_wide_commit" in k["name"]]
+    assert len(wide) >= 10 and all(k["priv"] == 0 and k["vgpr"] <= 128 for k in wide), wide
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, built, os.path.join(td, "x.so")])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        asm = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co]).decode()
+    assert asm.count("scratch_load") + asm.count("scratch_store") == 0

@@ -165,3 +165,66 @@ def test_exchange_is_chosen_by_reproducing_the_single_rank_run():
     with pytest.raises(SystemExit) as ei:
         bench.validate_exchange(_StubEngine(good=[]), _StubDist(), X0, lambda: _StubEngine(), cands, gens=3)
     assert "no exchange reproduced" in str(ei.value)
+
+
+def test_launcher_has_a_wall_clock_limit_when_every_rank_hangs():
+    """all ranks hanging WITHOUT exiting (a collective nobody leaves) used to leave the parent polling for ever."""
+    stub = "import time; time.sleep(600)"
+    out, err = io.StringIO(), io.StringIO()
+
+    class E(object):
+        def fileno(self):
+            return sys.stderr.fileno()
+
+        def write(self, s):
+            err.write(s)
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [], worker_cmd=[sys.executable, "-c", stub], out=out, err=E(), n_visible=2, deadline_s=1.5)
+    assert rc == 124 and out.getvalue() == "" and time.time() - t0 < 30
+    assert "wall-clock limit" in err.getvalue()
+
+
+class _AltEngine(_StubEngine):
+    def __init__(self, probe_agent=True, **kw):
+        super(_AltEngine, self).__init__(**kw)
+        self.probe_agent, self.closed = probe_agent, False
+
+    def exchange_stats(self):
+        return dict(mode=self.mode, arena_probe_agent=self.probe_agent, arena_probe_system=True)
+
+    def close(self):
+        self.closed = True
+
+
+def test_exchange_alternatives_are_timed_beside_the_headline_and_never_fatal():
+    """the N > 1 line carries the exchange north_star names (the dense all-gather on a second sampler with the library's own
+    RCCL communicator) and the agent-scope push beside the headline; an alternative that fails is recorded, the headline stands."""
+    import numpy as np
+    X0 = np.arange(12.0).reshape(3, 4)
+    made = []
+
+    def make_rccl():
+        made.append(_AltEngine(good=["dense"]))
+        return made[-1]
+    eng = _AltEngine(good=["push", "push-agent"])
+    alts = bench.exchange_alternatives(eng, _StubDist(), 1, X0, 3, lambda: _StubEngine(), make_rccl, "push", lambda x: x, 1, gens=5, burn=2)
+    assert [a["mode"] for a in alts] == ["dense", "push-agent"]
+    d, pa = alts
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["rccl_ranks"] == 1 and d["replicas_identical"] is True and made[0].closed and made[0].mode == "dense"
+    assert pa["value"] > 0 and pa["validated_against_single_rank_run"] is True and pa["fence_scope"] == "agent" and "never as it" in pa["note"]
+    assert eng.mode == "push"                                   # the sampler is handed back in the headline's mode
+    # the second sampler cannot be created (RCCL's first contact fails): recorded; the agent form did not reproduce the single-rank run: recorded
+    def boom():
+        raise RuntimeError("ncclCommInitRank failed: unhandled system error")
+    eng = _AltEngine(good=["push"])
+    alts = bench.exchange_alternatives(eng, _StubDist(), 1, X0, 3, lambda: _StubEngine(), boom, "push", lambda x: x, None, gens=5, burn=2)
+    assert "ncclCommInitRank failed" in alts[0]["error"][0] and alts[0]["rccl_ranks"] is None and "value" not in alts[0]
+    assert "did not reproduce the single-rank run" in alts[1]["error"][0] and eng.mode == "push"
+    # the agent-scope arena probe failed: the form is not even tried; ranks sharing one GPU: no RCCL, said so
+    eng = _AltEngine(good=["push", "push-agent"], probe_agent=False)
+    alts = bench.exchange_alternatives(eng, _StubDist(), 1, X0, 3, lambda: _StubEngine(), make_rccl, "push", lambda x: x, None, share_gpu=True, gens=5, burn=2)
+    assert "RCCL refuses two ranks on one device" in alts[0]["skipped"] and alts[0]["rccl_ranks"] is None and alts[0]["rccl_ranks_of_the_torch_process_group"] is None
+    assert "arena self-test failed under agent-scope" in alts[1]["skipped"]
+    # a headline that already ran dense has nothing to add
+    alts = bench.exchange_alternatives(_AltEngine(good=["dense"]), _StubDist(), 1, X0, 3, lambda: _StubEngine(), make_rccl, "dense", lambda x: x, 1, gens=5, burn=2)
+    assert len(alts) == 1 and "headline itself" in alts[0]["skipped"]

@@ -297,11 +297,30 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
-@pytest.mark.parametrize("exchange", ["replay", "rows", "dense"])
-@pytest.mark.parametrize("case", ["dream_gauss900", "dream_gauss1100"])
+@pytest.mark.parametrize("case,exchange", [("dream_gauss400", "replay"), ("dream_gauss400", "rows"), ("dream_gauss400", "dense"), ("dream_gauss900", "dense"),
+                                           ("dream_gauss2500", "dense")])
 def test_multi_rank_equals_single_rank_with_wide_rows(case, exchange):
-    """d = 900 / 1100: 16 / 32 coordinates per lane (the latter spills to scratch memory) through the RCCL exchanges' kernels, two emulated ranks."""
+    """d = 400: 8 coordinates per lane through the RCCL exchanges' kernels; d = 900 / 2500: the looped wide-row kernel (kernels_wide.h) as a rank
+    of a world, dense exchange (the push exchange: tests/test_gpu_push.py); two emulated ranks."""
     _multi_rank_case(case, 2, exchange)
+
+
+def test_wide_rows_have_no_replay_or_packed_rows_exchange():
+    """Rows wider than 512 coordinates run on the looped kernel, which has no replay / packed-rows form: asking for those exchanges is an error that
+    names the two that exist (push, dense) -- not a silent fall-back."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D(dim=600)._bpm_target_spec()
+    uid = b"BPMLOCAL" + bytes(120)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=16, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid) for r in range(2)]
+    assert ranks[0].exchange_stats()["mode"] == "dense"
+    for mode in ("replay", "rows"):
+        with pytest.raises(L.BpmError, match="exchange by push"):
+            ranks[0].set_exchange(mode=mode)
+    ranks[0].set_exchange(mode="dense")
+    for e in ranks:
+        e.close()
 
 
 @pytest.mark.parametrize("exchange", ["replay", "rows", "rows_overflow", "dense"])
@@ -329,7 +348,7 @@ def _multi_rank_case(case, R, exchange):
         spec, algo, N, kw = mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 48, dict(burnin_gen=8, n_cr_gen=3)
     elif case == "demc_banana_snooker":
         spec, algo, N, kw = banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 40, dict(p_snooker=0.3)
-    elif case in ("dream_gauss900", "dream_gauss1100"):       # 16 / 32 coordinates per lane (the latter spills to scratch)
+    elif case in ("dream_gauss400", "dream_gauss900", "dream_gauss2500"):       # 8 coordinates per lane / the looped wide-row kernel
         spec, algo, N, kw = d100_gauss.Gauss_100D(dim=int(case[11:]))._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=6, n_cr_gen=2)
     else:
         spec, algo, N, kw = d100_gauss.Gauss_100D(dim=7)._bpm_target_spec(), L.ALGO_DREAM, 32, dict(burnin_gen=20, n_cr_gen=2, del_pairs=2)

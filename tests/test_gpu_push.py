@@ -40,7 +40,7 @@ def test_push_exchange_local_group_equals_single_rank(case, R):
 
 @pytest.mark.parametrize("case,R", [("dream_gauss700", 2), ("dream_gauss700", 4), ("dream_gauss1300", 2)])
 def test_push_exchange_with_wide_rows(case, R):
-    """d = 700 / 1300 (16 / 32 coordinates per lane, the general update kernel; the widest shape spills to scratch memory) over the push exchange."""
+    """d = 700 and d = 1300 (the looped wide-row kernel, one and several passes over a chunk of 256 coordinates) over the push exchange."""
     from _push_worker import local_group_check
     nd, ns = local_group_check(case, R)
     assert nd == 0 and ns > 0

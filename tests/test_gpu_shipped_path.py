@@ -119,41 +119,69 @@ def test_histories_appended_in_shuffle_order_come_back_in_chain_order(algo, N, d
     eng.close()
 
 
-@pytest.mark.parametrize("N,d,pairs", [(96, 130, 3), (40, 300, 2), (64, 64, 3), (50, 33, 1), (48, 640, 3), (40, 1024, 2)])
+@pytest.mark.parametrize("N,d,pairs", [(96, 130, 3), (40, 300, 2), (64, 64, 3), (50, 33, 1), (48, 640, 3), (40, 1024, 2), (44, 512, 3), (36, 514, 3)])
 def test_wide_rows_on_the_shipped_path_equal_the_oracle(N, d, pairs):
-    """One wavefront per chain with 2, 4, 8 or 16 coordinates per lane (d = 33 ... 1024) on the shipped path -- own queue, acquire-only packets,
-    16-byte write-through stores of 2 ... 8 chunks per lane, plan records -- against the oracle (dream.py:32-140), burn-in and steady state."""
+    """One wavefront per chain with 2, 4 or 8 coordinates per lane (d = 33 ... 512) and the looped kernel beyond, on the shipped path -- own queue,
+    acquire-only packets, 16-byte write-through stores, plan records -- against the oracle (dream.py:32-140), burn-in and steady state."""
     params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) + 1.0))
     X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
     _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, X0, 9, dict(del_pairs=pairs, n_cr=3, burnin_gen=4, n_cr_gen=2), hist_rows=(4, 9))
 
 
-def test_widest_rows_run_on_the_stream_and_equal_the_oracle():
-    """1024 < d <= 2048: 16 coordinate pairs per lane -- the update kernels spill to scratch memory, which the HIP runtime provisions for its own
-    queues only, so these samplers launch on the HIP stream (launch_stats says so); results against the oracle as everywhere.  Beyond 2048: refused."""
-    from bipymc_amd import _lib as L
+@pytest.mark.parametrize("algo,N,d,kw", [
+    (R.ALGO_DREAM, 24, 1800, dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2)),
+    (R.ALGO_DREAM, 16, 4096, dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2)),
+    (R.ALGO_DREAM, 12, 10000, dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1)),
+    (R.ALGO_DREAM, 21, 1025, dict(del_pairs=2, n_cr=4, burnin_gen=4, n_cr_gen=2)),          # odd d (a padded row), pairs at run time, four CR values
+    (R.ALGO_DREAM, 33, 513, dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2)),            # the first width on the looped kernel
+    (R.ALGO_DREAM, 10, 2047, dict(del_pairs=7, n_cr=1, burnin_gen=0)),                       # CR = 1 only: no counting pass
+    (R.ALGO_DEMC, 30, 1500, dict(p_snooker=0.3)),
+    (R.ALGO_DEMC, 9, 3001, dict(p_snooker=0.0)),
+])
+def test_looped_wide_row_kernel_on_the_shipped_path_equals_the_oracle(algo, N, d, kw):
+    """d > 512: one wavefront per chain LOOPING over its row in chunks of 256 coordinates (kernels_wide.h) -- no dimension
+    limit, no scratch memory, so it runs on the library's own queue like every other shape (round 3: d <= 2048 only, the widest shape spilled and ran on
+    the HIP stream).  The reference has no limit (dream.py:52-58,61,85-89 work on self.dim).  Against the oracle as everywhere: accept counts equal,
+    state / whole history / p_cr to 1e-10, burn-in with CR adaptation and steady state; d = 4096 and 10 000 included."""
     from bipymc_amd.engine import HipEngine
-    N, d = 24, 1800
-    params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) + 1.0))
-    kw = dict(del_pairs=3, n_cr=3, burnin_gen=4, n_cr_gen=2)
-    eng = HipEngine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=5, **kw)
-    ora = R.OracleSampler(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, **kw)
-    X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    params = R.gauss_equicorr_params(0.3, np.sqrt(np.arange(d) % 50 + 1.0))
+    eng = HipEngine(algo=algo, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=5, **kw)
+    ora = R.OracleSampler(algo, N, d, R.TARGET_GAUSS_EQUICORR, params, 5, **kw)
+    X0 = np.random.RandomState(21).normal(size=(N, d)) * np.sqrt(np.arange(d) % 50 + 1.0)
     eng.set_state(X0)
     ora.set_state(X0)
     ls0 = eng.launch_stats()
     eng.begin_run()
-    eng.step(9)
+    G = 11 if algo == R.ALGO_DEMC else 9                  # (DE-MC: k = 0 and k = 10, the gamma = 1 generations of demc.py:174-177)
+    eng.step(G)
     eng.synchronize()
-    ora.run(9)
+    ora.run(G)
     ls = eng.launch_stats()
-    assert ls["stream"] - ls0["stream"] == 18 and ls["direct"] == ls0["direct"], (ls0, ls)
+    assert ls["direct"] - ls0["direct"] == 2 * G and ls["stream"] == ls0["stream"], (ls0, ls)      # the library's own queue
     st = eng.stats()
     assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
     np.testing.assert_allclose(eng.get_state(), ora.X, rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(eng.get_history(), np.stack(ora.history, axis=0), rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+    np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=1e-9, atol=1e-7)
+    if algo == R.ALGO_DREAM:
+        # (p_cr: ratios of sums over >= 500 coordinates of (jump / history std)^2 after a handful of history rows -- the running Welford moments
+        # and NumPy's two-pass std agree to ~1e-9 there)
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-7)
+        assert np.array_equal(st["n_cr_updates"], ora.cr.n_cr_updates)
     eng.close()
-    with pytest.raises(L.BpmError, match="dim > 2048 not supported"):
-        HipEngine(algo=R.ALGO_DREAM, n_chains=N, dim=2050, target_id=R.TARGET_GAUSS_EQUICORR,
-                  target_params=R.gauss_equicorr_params(0.3, np.ones(2050)), seed=5, **kw)
+
+
+def test_the_one_dimension_limit_is_the_philox_slot():
+    """A coordinate pair's draws are addressed by a 16-bit slot (philox.h: SLOT_BITS): dim < 131056; no other limit (memory aside)."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    with pytest.raises(L.BpmError, match="below 131056"):
+        HipEngine(algo=R.ALGO_DEMC, n_chains=4, dim=131056, target_id=R.TARGET_GAUSS_EQUICORR,
+                  target_params=R.gauss_equicorr_params(0.3, np.ones(131056)), seed=5)
+    e = HipEngine(algo=R.ALGO_DEMC, n_chains=4, dim=131055, target_id=R.TARGET_GAUSS_EQUICORR,
+                  target_params=R.gauss_equicorr_params(0.0, np.ones(131055)), seed=5)
+    e.set_state(np.zeros((4, 131055)))
+    e.begin_run()
+    e.step(2)
+    assert np.all(np.isfinite(e.get_state()))
+    e.close()
