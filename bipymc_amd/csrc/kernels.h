@@ -199,8 +199,10 @@ struct PhaseArgs {
     uint32_t hist_by_pos;       // 1: the history row and its ln-like are appended at the update's POSITION in this generation's shuffle order
                                 // (work items of a wavefront write consecutive rows) instead of at the chain's index; the host remembers the
                                 // generation, and rows are put back into chain order when anything reads them (sampler.hip: normalize_history)
+#ifndef BPM_LEAN_LAST
     uint32_t lean;              // 1 (several chains per wavefront, device target, many chains): ln_like of the current state is re-evaluated from the own
                                 // row instead of read from `ll`, `ll` is not written, accepted updates are counted per wavefront (kernels.h: lean_scalars)
+#endif
     uint32_t wt;                // 1: the dispatch packet of this launch carries NO release fence -- what a later kernel reads (accepted state
                                 // rows, ln-like cache, accept counters) leaves through agent-scope (write-through) stores (store_row_wt)
     uint64_t seed;
@@ -217,6 +219,9 @@ struct PhaseArgs {
     uint32_t cr_gate;      // dream.py:123 history length > n_cr_gen
     uint32_t hist_len;     // rows of every chain's history before this generation
     double gamma_scale, gamma_demc, epsilon, u_epsilon, p_snooker;
+#ifdef BPM_LEAN_LAST
+    uint32_t lean, pad_lean;
+#endif
 };
 
 // Sum over the LPC lanes of a chain subgroup, result in every lane of the subgroup.
@@ -1288,14 +1293,19 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     // (LEAN: ln_like of the current state from the own row == the cached value, bit for bit -- see lean_scalars)
     const uint32_t dim_early = a.L.dim;      // (captured by value, a few registers: a by-reference capture put one instantiation's constants on the stack)
     constexpr bool LEAN_CT = LEAN && lean_always<TARGET>();
-    const bool lean_early = LEAN_CT || (LEAN && a.lean != 0u);
-    auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
 #ifdef BPM_STAMPS
     bpm_stamp[1] = 0; BPM_STAMP(1);
-    make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : (LEAN ? 2 : 1))>(a, c, active, q, cw, s_part, wk, rec, bpm_stamp, early);
+    unsigned long long* const stamp_arg = bpm_stamp;
 #else
-    make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : (LEAN ? 2 : 1))>(a, c, active, q, cw, s_part, wk, rec, nullptr, early);
+    unsigned long long* const stamp_arg = nullptr;
 #endif
+    if constexpr (LEAN) {
+        const bool lean_early = LEAN_CT || a.lean != 0u;
+        auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
+        make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : 2)>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, early);
+    } else {      // (one wavefront per chain: exactly the call of rounds 1-3)
+        make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, stamp_arg);
+    }
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     BPM_STAMP(5);
     finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0))>(a, c, active, q, wk, ll_prop);

@@ -136,11 +136,15 @@ def test_snooker_only_sampler_leaves_the_gaussian_invariant(d):
     EVERY update is a snooker update (p_snooker = 1.0), the population starts as exact draws of the equicorrelated Gaussian (rho = 0.5, sigma_i^2 = i + 1)
     and must stay there: over 500 generations of 8192 chains the pooled variance within 1 %, every mean within 0.05 sigma, at d = 3, 8 and 100 (one lane,
     four lanes, one wavefront per chain).  An exponent of d instead of d - 1 shifts the stationary radial law by a factor |x - z| -- at d = 3 the variance by
-    tens of per cent."""
-    N, G, rho = 8192, 500, 0.5
+    tens of per cent.  (d = 100: 32768 chains -- with rho = 0.5 the pooled variance of a SAMPLE of 8192 exact draws already scatters by 0.8 %, the common
+    factor carries a quarter of every coordinate's variance and a line move per update mixes 100 dimensions slowly: 8192 chains gave 0.9899, the start's own
+    sampling error (r0 below: the start's pooled variance ratio, reported with a failure).)"""
+    N, G, rho = (32768 if d == 100 else 8192), 500, 0.5
     params = R.gauss_equicorr_params(rho, np.sqrt(np.arange(d) + 1.0))
     e = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=2026 + d, p_snooker=1.0)
-    e.set_state(_equicorr_draws(N, d, rho, 77 + d))
+    X0 = _equicorr_draws(N, d, rho, 77 + d)
+    r0 = float(np.mean(X0.var(axis=0) / (np.arange(d) + 1.0)))     # the start's own pooled variance ratio (sampling error of N exact draws)
+    e.set_state(X0)
     e.reserve_history(G + 2)
     e.begin_run()
     e.step(G)
@@ -152,7 +156,7 @@ def test_snooker_only_sampler_leaves_the_gaussian_invariant(d):
     sig2 = np.arange(d) + 1.0
     acc = st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
     assert 0.02 < acc < 0.9, acc                                   # the chains do move
-    assert abs(np.mean(var / sig2) - 1.0) < 0.01, (d, np.mean(var / sig2), acc)
+    assert abs(np.mean(var / sig2) - 1.0) < 0.01, (d, np.mean(var / sig2), r0, acc)
     assert np.max(np.abs(mean) / np.sqrt(sig2)) < 0.05, (d, np.max(np.abs(mean) / np.sqrt(sig2)))
     # ... and the correlation structure: the variance of the standardised coordinates' sum is d (1 + (d - 1) rho)
     X = e.get_state() / np.sqrt(sig2)
