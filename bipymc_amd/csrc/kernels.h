@@ -39,7 +39,7 @@
 #define BPM_STAMP(i) do { } while (0)
 #endif
 
-// The last-workgroup tickets below (cr_partial_kernel<.., true>, outlier_select_pass_kernel) publish with relaxed agent-scope atomics,
+// The last-workgroup ticket below (outlier_select_pass_kernel) publishes with relaxed agent-scope atomics,
 // `s_waitcnt vmcnt(0)`, then a relaxed fetch_add on the ticket.  That is NOT release/acquire in the HIP / LLVM memory model; it is
 // correct on gfx942 / gfx950 because (a) stores and atomics are counted in vmcnt there (gfx10+ counts stores in vscnt) and (b) agent-scope
 // atomics are performed at the memory side, past the per-XCD L2s -- an agent-scope release would instead write back the whole L2
@@ -67,6 +67,15 @@ constexpr int WAVE = 64;
 #define BPM_BLOCK_WAVE 128
 #endif
 constexpr int block_for(int lpc) { return (lpc == 4 || lpc == 16) ? 256 : BPM_BLOCK_WAVE; }
+// ... and of the burn-in flavours (HOT 3 / 4) of the one-wavefront-per-chain shapes: 16 wavefronts = 16 chains per workgroup, whose CR statistics
+// the workgroup sums itself (cr_level1: "CR reduction" below).  1024-thread workgroups cost the update nothing (cfg2 steady: 10.8 us either way).
+constexpr bool hot_is_adapt(int hot) { return hot == 3 || hot == 4; }
+// (one wavefront per chain: only with 2 coordinates per lane, d <= 128 -- a 1024-thread workgroup caps the kernel at 128 VGPRs, and the burn-in kernels
+// of the wider register-resident shapes need more: those shapes take level 1 from the slots, like every other path)
+constexpr bool crp_shape(int lpc, int dpl) { return lpc < WAVE || dpl == 2; }
+constexpr int block_for_hot(int lpc, int hot, int dpl) { return (lpc == WAVE && dpl == 2 && hot_is_adapt(hot)) ? 1024 : block_for(lpc); }
+// chains (positions) per level-1 partial sum of the CR statistics: a function of the kernel SHAPE alone (every rank, every launch path agrees)
+constexpr int cr_g1(int lpc) { return lpc == WAVE ? 16 : WAVE / lpc; }
 constexpr int MAX_CR = 8;
 constexpr int TRACE_I32 = 32;   // ints per chain in the debug trace
 constexpr int TRACE_F64 = 4;
@@ -215,6 +224,8 @@ struct PhaseArgs {
     uint32_t n_items;
     uint32_t algo;
     uint32_t P, n_cr;
+    double* cr_part1;      // != nullptr: this launch sums its updates' CR statistics itself, chunk by chunk of cr_g1 positions (HOT 3 / 4 only)
+    uint32_t cr_chunk0, cr_n1;   // first chunk of this half generation, chunks per generation (the stride of the m-major partial arrays)
     uint32_t adapt_on;     // dream.py:92  burnin_gen > k
     uint32_t cr_gate;      // dream.py:123 history length > n_cr_gen
     uint32_t hist_len;     // rows of every chain's history before this generation
@@ -271,55 +282,62 @@ __device__ __forceinline__ int gsum_i(int v) {
     return v;
 }
 
-// ---- CR reduction in two dispatches (round 2) ---------------------------------------------------------------------------
-// One reduction kernel per burn-in generation used to do everything in ONE workgroup of 1024 threads: 16 loads and 64
-// compare-accumulates per thread, then the update of p_cr -- 10 us as the third dependent dispatch of a generation whose two update
-// kernels take 8.3 us each (an EMPTY third dispatch costs 2.4 us: profiles/r02_cr_in_kernel_experiment.txt).  Now:
-//   * cr_partial_kernel: up to CR_PARTS workgroups of 256 (1024 beyond 65536 chains) threads, workgroup b sums the slots of chains [b, b + 1) span in a fixed
-//     order (thread: its strided slots in index order; wavefront: DPP tree; workgroup: its wavefronts in order) and writes
-//     part[k][b] -- no ticket, one load round trip;
-//   * cr_final_kernel: one wavefront folds the <= 64 partial sums (one coalesced load per sum, a fixed DPP tree) into the totals,
-//     re-estimates p_cr and writes cr_state.
-// 22.5 instead of 24.9 us per burn-in generation at cfg2.  (Letting every wavefront of the NEXT generation's update kernels do the
-// fold instead of cr_final_kernel -- two rotating totals buffers, workgroup 0 writing them -- measured slower: 24.4 us at cfg2,
-// 102 instead of 90 us at N = 262144; a last-workgroup ticket inside one kernel was the round-1 form for N > 16384.)
-// Same arithmetic in the same order on every path and every rank: results do not depend on the number of GPUs.
-constexpr int CR_PARTS = 64;
-// workgroup size of cr_partial_kernel: a function of N alone (the summation order depends on it, and every rank of a world must add
-// in the same order); 1024 threads beyond 65536 chains keep the slots per thread at <= 4 (93 -> 90 us per generation at N = 262144)
-__host__ __device__ inline uint32_t cr_part_threads(uint32_t N) { return N > 65536u ? 1024u : 256u; }
-__host__ __device__ inline uint32_t cr_part_span(uint32_t N) {       // chains per workgroup: a multiple of the workgroup size, at most CR_PARTS workgroups
-    const uint32_t per = (N + CR_PARTS - 1u) / CR_PARTS, t = cr_part_threads(N);
-    return (per + t - 1u) / t * t;
-}
-// dream.py:132-140 for one generation: its partial sums folded into the totals T = (p_cr | delta_m | n_cr_updates).  Nothing changes
-// when no update contributed; p_cr is re-estimated once every CR value has been used, then normalised.  All 64 lanes take part.
+// ---- CR reduction (round 4) --------------------------------------------------------------------------------------------------
+// dream.py:119-140 once per generation from the (delta, cr) slots of ALL N chains.  Rounds 2-3 spent two dependent dispatches on it behind
+// the two update kernels (cr_partial_kernel over the slots in chain order + cr_final_kernel: 2.9 + 3.0 us of cfg2's 22 us burn-in
+// generation, each at the floor of a dependent launch).  Now the first level is done where the statistics are born:
+//   level 1  sums over CHUNKS OF cr_g1 CONSECUTIVE POSITIONS of the generation's shuffle order, each half generation chunked by itself,
+//            positions in order (for every CR value m: delta_m += delta, n_m += 1 of the chunk's updates that drew m).  On a single GPU the
+//            burn-in flavours of the update kernel (HOT 3 / 4) write them: a workgroup of 16 wavefronts = 16 chains through LDS (one wavefront
+//            per chain), or a wavefront by itself (several chains per wavefront).  Everywhere else -- a rank of a world (it updates only its own
+//            chains; the slots of all chains are in its replica), the general kernel, the looped wide-row kernel, the host-callback path --
+//            cr_level1_kernel computes THE SAME sums from the slots (one thread per chunk, positions through the shuffle table): same chunks,
+//            same order, same bits, whatever the number of GPUs and the launch path (tested: p_cr of worlds == single rank, nohot == default).
+//   level 2  (only beyond 512 chunks: N > 8192 at 16 positions per chunk) cr_mid_kernel: one wavefront per 64 consecutive chunks, a fixed DPP tree.
+//   final    cr_final_kernel: one wavefront; lane l adds partials l, l + 64, ... in order (all loads in flight at once), a fixed DPP tree over the
+//            lanes, then dream.py:132-140.  (Folding in the last workgroup of the generation's last launch instead -- an agent-scope ticket, no
+//            dispatch at all -- was built and measured SLOWER: 21.1 vs 20.7 us per generation at cfg2, the sign round 3 found for its ticket form.)
+// cfg2 burn-in: 22.0 -> 18.7 us per generation in the timing-only build that left cr_partial_kernel out (profiles/r04_burnin.txt).
+constexpr uint32_t CR_FINAL_MAX = 512;        // partial sums cr_final_kernel folds by itself (8 per lane)
+__host__ __device__ inline uint32_t cr_chunks_of(uint32_t n_half, uint32_t g1) { return (n_half + g1 - 1u) / g1; }
 struct CrTotals { double p[MAX_CR], d[MAX_CR], n[MAX_CR]; };
-template <bool ATOMIC_LOADS = false>      // true: the partial sums were written by other workgroups of the SAME launch (agent-scope stores)
-__device__ __forceinline__ void cr_fold(const double* tot, const double* part, uint32_t nb, uint32_t n_cr, CrTotals& T) {
+// totals T = (p_cr | delta_m | n_cr_updates) + one generation's partial sums part[m * stride + b], b < nb <= 64 ROUNDS (delta) and
+// part[(MAX_CR + m) * stride + b] (counts), by ONE wavefront: lane l holds partials l, l + 64, ... -- ALL loads of the kernel issued before the first
+// add (a loop with a round trip per 64 partials cost 5 us at cfg2; a workgroup of 16 wavefronts with an LDS hand-over 4.7) -- adds them in order, the
+// lanes' sums meet in the fixed DPP tree.  (A partial beyond nb reads as +0.0: x + 0.0 == x, the result is a function of nb alone.)  Nothing changes
+// when no update contributed; p_cr is re-estimated once every CR value has been used, then normalised.  All 64 lanes take part.
+template <int ROUNDS>
+__device__ __forceinline__ void cr_fold(const double* tot, const double* part, uint32_t nb, uint32_t stride, uint32_t n_cr, CrTotals& T) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    double sd[MAX_CR], sn[MAX_CR];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) {
-        sd[m] = 0.0; sn[m] = 0.0;
-        if (m < (int)n_cr && lane < nb) {
-            if (ATOMIC_LOADS) {
-                sd[m] = __hip_atomic_load(&part[m * CR_PARTS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sn[m] = __hip_atomic_load(&part[(MAX_CR + m) * CR_PARTS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                sd[m] = part[m * CR_PARTS + lane];
-                sn[m] = part[(MAX_CR + m) * CR_PARTS + lane];
-            }
-        }
-    }
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) { T.p[m] = tot[m]; T.d[m] = tot[MAX_CR + m]; T.n[m] = tot[2 * MAX_CR + m]; }
     bool any = false;
 #pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) {
-        if (m < (int)n_cr) {                       // uniform
-            const double td = gsum<WAVE>(sd[m]), tn = gsum<WAVE>(sn[m]);
-            if (tn > 0.0) { any = true; T.n[m] += tn; T.d[m] += td; }
+    for (int m0 = 0; m0 < MAX_CR; m0 += 4) {                 // four CR values at a time: 8 ROUNDS doubles in registers
+        if (m0 < (int)n_cr) {                                // uniform
+            double vd[4][ROUNDS], vn[4][ROUNDS];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const uint32_t b = (uint32_t)r * WAVE + lane;
+                    vd[mm][r] = 0.0; vn[mm][r] = 0.0;
+                    if (m0 + mm < (int)n_cr && b < nb) {     // (agent-scope loads: written by kernels whose packets may carry no release fence)
+                        vd[mm][r] = __hip_atomic_load(&part[(uint64_t)(m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vn[mm][r] = __hip_atomic_load(&part[(uint64_t)(MAX_CR + m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                if (m0 + mm < (int)n_cr) {                   // uniform
+                    double sd = 0.0, sn = 0.0;
+#pragma unroll
+                    for (int r = 0; r < ROUNDS; ++r) { sd += vd[mm][r]; sn += vn[mm][r]; }
+                    const double td = gsum<WAVE>(sd), tn = gsum<WAVE>(sn);
+                    if (tn > 0.0) { any = true; T.n[m0 + mm] += tn; T.d[m0 + mm] += td; }
+                }
+            }
         }
     }
     if (!any) return;
@@ -344,6 +362,11 @@ __device__ __forceinline__ void cr_write_totals(const CrTotals& T, uint32_t n_cr
             __hip_atomic_store(&out[MAX_CR + m], T.d[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&out[2 * MAX_CR + m], T.n[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+}
+// One chunk's sums from values in order: acc_d / acc_n of CR value m (the lane's or the thread's own m), element k contributes when idx == m.
+// THE definition of a level-1 partial: the update kernels and cr_level1_kernel both add through this function, in position order.
+__device__ __forceinline__ void cr_chunk_add(double& acc_d, double& acc_n, int m, int idx, double delta) {
+    if (idx == m) { acc_d += delta; acc_n += 1.0; }
 }
 
 __device__ __forceinline__ double box_muller(uint32_t w1, uint32_t w2) {
@@ -1211,7 +1234,7 @@ __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_pl
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 template <int ALGO, int TARGET, int LPC, int DPL, int NP, int HOT = 0>
-__global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
+__global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kernel(
 #ifdef BPM_PRELOAD
     // the four values that locate a wavefront's update record, as leading scalar arguments: with
     // -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs at wavefront launch (no kernarg load, one miss less
@@ -1252,10 +1275,14 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     const uint32_t* pl_plan = a.rec_tab;
     const uint32_t pl_upd_off = a.rec_off, pl_n_items = a.n_items, pl_mode = a.mode;
 #endif
-    __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
+    constexpr int BLK = block_for_hot(LPC, HOT, DPL);
+    // CRP: this flavour sums its updates' CR statistics itself (level 1 of the CR reduction); with one wavefront per chain the 16 wavefronts of the
+    // workgroup meet at a barrier for it, so none of them may leave early
+    constexpr bool CRP = ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL);
+    __shared__ uint32_t s_part[(BLK / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
     const int cw = lane / LPC, q = lane % LPC;      // chain slot inside the workgroup, lane inside the chain subgroup
-    const uint32_t w = blockIdx.x * (block_for(LPC) / LPC) + cw;
+    const uint32_t w = blockIdx.x * (BLK / LPC) + cw;
 #ifdef BPM_STAMPS
     unsigned long long bpm_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long bpm_rt0;
@@ -1266,7 +1293,10 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     uint32_t c;
     bool active;
     const uint32_t* rec = nullptr;
-    if (LPC == WAVE && pl_plan) {
+    bool run = true;                     // (false: an idle wavefront of a CRP workgroup -- it only joins the barrier)
+    double cr_d = 0.0;
+    int cr_i = -1;
+    if (LPC == WAVE && pl_plan && !(CRP && w >= pl_n_items)) {
         // the update's record (by position in shuffle order) carries the chain id: wavefront-uniform scalar loads
         active = w < pl_n_items;
         if (!active) return;
@@ -1283,7 +1313,10 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     } else {
         active = resolve_chain(a, w, c);
     }
-    if (LPC == WAVE && !active) return;          // whole wavefront idle
+    if (LPC == WAVE && !active) {                // whole wavefront idle
+        if (CRP) run = false; else return;
+    }
+  if (run) {
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
     Work<DPL> wk;
@@ -1309,6 +1342,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     BPM_STAMP(5);
     finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0))>(a, c, active, q, wk, ll_prop);
+    if (CRP && active && a.adapt_on && a.cr_gate) { cr_d = wk.delta; cr_i = wk.cr_idx; }      // what finish_update wrote into the chain's slots
     BPM_STAMP(6);
 #ifdef BPM_STAMPS
     if (bpm_stamp[2] == 0) bpm_stamp[2] = bpm_rt0;
@@ -1322,6 +1356,39 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_fused_kernel(
     }
     if (a.stamps && lane == 0) for (int i = 0; i < 8; ++i) a.stamps[(uint64_t)w * 8 + i] = bpm_stamp[i];
 #endif
+  }   // run
+    // ---- level 1 of the CR reduction ("CR reduction" above): this launch's updates, chunk by chunk of cr_g1 positions, in position order
+    if (CRP && a.cr_part1) {
+        constexpr int G1 = cr_g1(LPC);
+        if (LPC == WAVE) {                                   // 16 wavefronts = 16 chains = one chunk: through LDS
+            __shared__ double s_crd[G1];
+            __shared__ int s_cri[G1];
+            if (q == 0) { s_crd[cw] = cr_d; s_cri[cw] = cr_i; }
+            __syncthreads();
+            if (cw == 0 && q < (int)a.n_cr) {                 // lane m of the first wavefront: CR value m
+                double sd = 0.0, sn = 0.0;
+#pragma unroll
+                for (int k = 0; k < G1; ++k) cr_chunk_add(sd, sn, q, s_cri[k], s_crd[k]);
+                const uint32_t ch = a.cr_chunk0 + blockIdx.x;
+                __hip_atomic_store(&a.cr_part1[(uint64_t)q * a.cr_n1 + ch], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.cr_part1[(uint64_t)(MAX_CR + q) * a.cr_n1 + ch], sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {                                             // a wavefront holds G1 chains = one chunk: lane m sums CR value m over them
+            const int wl = lane & (WAVE - 1);
+            double sd = 0.0, sn = 0.0;
+#pragma unroll
+            for (int k = 0; k < G1; ++k) {
+                const double dk = readlane_f64(cr_d, k * LPC);
+                const int ik = __builtin_amdgcn_readlane(cr_i, k * LPC);
+                cr_chunk_add(sd, sn, wl, ik, dk);
+            }
+            const uint32_t ch = a.cr_chunk0 + (blockIdx.x * (BLK / WAVE) + (uint32_t)(lane / WAVE));
+            if (wl < (int)a.n_cr && (ch - a.cr_chunk0) * (uint32_t)G1 < a.n_items) {
+                __hip_atomic_store(&a.cr_part1[(uint64_t)wl * a.cr_n1 + ch], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.cr_part1[(uint64_t)(MAX_CR + wl) * a.cr_n1 + ch], sn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // Replay exchange, receiving side: one work item per position of the half generation's update group; the item of a
@@ -1462,76 +1529,84 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
 }
 
 // ---------------------------------------------------------------------------------
-// Crossover-probability re-estimation (dream.py:125-140), once per generation, from the
-// (delta, cr_idx) slots of ALL N chains of the exchange buffer: identical on every rank.
+// Crossover-probability re-estimation (dream.py:125-140), once per generation: the kernels of "CR reduction" above.
 // cr_state: p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
 // ---------------------------------------------------------------------------------
-// TICKET (N > 65536, where a fourth dispatch costs more than it saves: 93.5 vs 90 us per generation at N = 262144): the LAST workgroup
-// to finish folds the partial sums itself -- the same cr_fold, hence the same bits as cr_final_kernel -- and writes cr_state; the sums
-// then travel in agent-scope atomic stores / loads, which go to the memory side (a release fence would write back the XCD's whole L2).
-template <int CR_PART_THREADS, bool TICKET>
-__global__ __launch_bounds__(CR_PART_THREADS) void cr_partial_kernel(Layout L, uint32_t N, uint32_t n_cr, uint32_t span, double* part, double* cr_state,
-                                                                     uint32_t* ticket, uint32_t nb) {
-    __shared__ double s_d[CR_PART_THREADS / WAVE][MAX_CR], s_n[CR_PART_THREADS / WAVE][MAX_CR];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lo = blockIdx.x * span;
-    const uint32_t hi = lo + span < N ? lo + span : N;
-    double acc_d[MAX_CR], acc_n[MAX_CR];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) { acc_d[m] = 0.0; acc_n[m] = 0.0; }
-    constexpr int UNR = 4;
-    for (uint32_t base = lo + tid; base < hi; base += CR_PART_THREADS * UNR) {
-        int idx[UNR];
-        double dl[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const uint32_t c = base + (uint32_t)u * CR_PART_THREADS;
-            idx[u] = c < hi ? (int)*cridx_ptr(L, c) : -1;
-            dl[u] = c < hi ? *delta_ptr(L, c) : 0.0;
+// Level 1 from the slots (where the update kernels did not write it themselves): a LANE per position -- the table lookup and the two slot loads of a
+// chunk's G1 positions leave together (a thread per chunk walked them in dependent rounds: 10 us at cfg2) -- then every lane of the chunk adds the
+// chunk's values in position order, read across lanes with DPP broadcasts (quad_perm / row_newbcast / v_readlane for G1 = 4 / 16 / 64: a ds_bpermute
+// per value and position cost 1.7 us), and the chunk's first lane stores.  16, 4 or 1 chunks per wavefront.
+constexpr int CR_L1_THREADS = 256;
+template <int G1, int J>
+__device__ __forceinline__ int cr_bcast_i(int v) {          // lane J of every group of G1 consecutive lanes, to all lanes of the group
+    if (G1 == 4) return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);              // quad_perm [J, J, J, J]
+    if (G1 == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0xF, false);            // row_newbcast:J
+    return __builtin_amdgcn_readlane(v, J);
+}
+// lane k of the chunk sums CR value k (and k + 4 where a chunk has only four lanes): one compare and one conditional add per position and lane
+// (every lane summing all MAX_CR values compiled to 500 selects and 240 f64 adds per lane: 3.7 us)
+template <int G1, int J>
+__device__ __forceinline__ void cr_l1_steps(int idx, double dl, int m0, double& sd0, double& sn0, double& sd1, double& sn1) {
+    const int ij = cr_bcast_i<G1, J>(idx);
+    const double dj = __hiloint2double(cr_bcast_i<G1, J>(__double2hiint(dl)), cr_bcast_i<G1, J>(__double2loint(dl)));
+    cr_chunk_add(sd0, sn0, m0, ij, dj);
+    if (G1 == 4) cr_chunk_add(sd1, sn1, m0 + 4, ij, dj);
+    if constexpr (J + 1 < G1) cr_l1_steps<G1, J + 1>(idx, dl, m0, sd0, sn0, sd1, sn1);             // position order
+}
+template <int G1>
+__global__ __launch_bounds__(CR_L1_THREADS) void cr_level1_kernel(Layout L, PermKey pk, const uint32_t* perm_tab, uint32_t N, uint32_t n_cr, uint32_t n1, double* part1) {
+    const uint32_t t = blockIdx.x * CR_L1_THREADS + threadIdx.x;      // = chunk * G1 + k  (a chunk never straddles wavefronts: G1 divides 64)
+    const uint32_t ch = t / G1, k = t % G1;
+    const uint32_t n_first = (N + 1u) / 2u, c_first = cr_chunks_of(n_first, G1);
+    const bool second = ch >= c_first;
+    const uint32_t pos = second ? n_first + (ch - c_first) * G1 + k : ch * G1 + k;
+    const bool valid = ch < n1 && pos < (second ? N : n_first);
+    int idx = -1;
+    double dl = 0.0;
+    if (valid) {
+        const uint32_t c = perm_tab ? perm_tab[pos] : perm_fwd(pos, pk);
+        idx = (int)*cridx_ptr(L, c);
+        dl = *delta_ptr(L, c);
+    }
+    static_assert(MAX_CR <= 8, "a chunk's lanes cover the CR values: lane k sums value k (and k + 4 when G1 == 4)");
+    double sd0 = 0.0, sn0 = 0.0, sd1 = 0.0, sn1 = 0.0;
+    cr_l1_steps<G1, 0>(idx, dl, (int)k, sd0, sn0, sd1, sn1);
+    if (ch < n1) {
+        if (k < n_cr) {
+            __hip_atomic_store(&part1[(uint64_t)k * n1 + ch], sd0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part1[(uint64_t)(MAX_CR + k) * n1 + ch], sn0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-            for (int m = 0; m < MAX_CR; ++m) {
-                if (m < (int)n_cr && idx[u] == m) { acc_d[m] += dl[u]; acc_n[m] += 1.0; }
-            }
+        if (G1 == 4 && k + 4u < n_cr) {
+            __hip_atomic_store(&part1[(uint64_t)(k + 4u) * n1 + ch], sd1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part1[(uint64_t)(MAX_CR + k + 4u) * n1 + ch], sn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+// Level 2: wavefront g folds level-1 partials [64 g, 64 g + 64) of every array with the DPP tree -> part2[m * n2 + g]
+__global__ __launch_bounds__(WAVE) void cr_mid_kernel(const double* part1, uint32_t n1, uint32_t n_cr, uint32_t n2, double* part2) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x, b = g * WAVE + lane;
 #pragma unroll
     for (int m = 0; m < MAX_CR; ++m) {
         if (m < (int)n_cr) {                       // uniform
-            const double wd = gsum<WAVE>(acc_d[m]), wn = gsum<WAVE>(acc_n[m]);
-            if ((tid & (WAVE - 1)) == 0) { s_d[tid / WAVE][m] = wd; s_n[tid / WAVE][m] = wn; }
+            double d = 0.0, n = 0.0;
+            if (b < n1) {
+                d = __hip_atomic_load(&part1[(uint64_t)m * n1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n = __hip_atomic_load(&part1[(uint64_t)(MAX_CR + m) * n1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            d = gsum<WAVE>(d);
+            n = gsum<WAVE>(n);
+            if (lane == 0) {
+                __hip_atomic_store(&part2[(uint64_t)m * n2 + g], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part2[(uint64_t)(MAX_CR + m) * n2 + g], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    __syncthreads();
-    if (tid < n_cr) {
-        double d = 0.0, n = 0.0;
-        for (int w = 0; w < CR_PART_THREADS / WAVE; ++w) { d += s_d[w][tid]; n += s_n[w][tid]; }
-        // agent-scope stores: read by other workgroups of the SAME launch (ticket form), or by cr_final_kernel behind a packet without a
-        // release fence (the library's own queue: sampler.hip finish_generation)
-        __hip_atomic_store(&part[tid * CR_PARTS + blockIdx.x], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&part[(MAX_CR + tid) * CR_PARTS + blockIdx.x], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (TICKET) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup takes its ticket (gfx942 / gfx950
-                                                                         // only: see the #error at the top of this file)
-    }
-    if (!TICKET) return;
-    __shared__ uint32_t s_last;
-    __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last || tid >= WAVE) return;
-    CrTotals T;
-    cr_fold<true>(cr_state, part, nb, n_cr, T);
-    if (tid == 0) {
-        cr_write_totals(T, n_cr, cr_state);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // armed for the next generation
-    }
 }
-// totals `tot` + the partial sums of one generation -> cr_state (one wavefront; tot may be cr_state itself)
+// totals `tot` + the partial sums of one generation -> cr_state (one wavefront holding ROUNDS partials per lane; tot may be cr_state itself)
+template <int ROUNDS>
 __global__ __launch_bounds__(WAVE) void cr_final_kernel(const double* tot, const double* part, uint32_t nb, uint32_t n_cr, double* cr_state) {
     CrTotals T;
-    cr_fold(tot, part, nb, n_cr, T);
+    cr_fold<ROUNDS>(tot, part, nb, nb, n_cr, T);
     if (threadIdx.x == 0) cr_write_totals(T, n_cr, cr_state);
 }
 

@@ -219,7 +219,8 @@ static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a
 template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
     static hipFunction_t fn = nullptr;
-    launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, grid_for(a.n_items, LPC), (unsigned)block_for(LPC), s);
+    constexpr unsigned blk = (unsigned)block_for_hot(LPC, HOT, DPL), cpw = blk / (unsigned)LPC;      // (burn-in flavours of one wavefront per chain: 16 chains per workgroup)
+    launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, (a.n_items + cpw - 1u) / cpw, blk, s);
 }
 #endif
 template <int ALGO, int T, int NP, int LPC, int DPL>
@@ -402,7 +403,11 @@ struct bpm_sampler {
     int64_t w_rows = 0;        // history rows folded into the Welford moments
     double* tparams = nullptr;
     double* cr_state = nullptr;
-    double* cr_part = nullptr;    // [2 MAX_CR][CR_PARTS] partial sums of a generation's CR statistics (cr_partial_kernel -> cr_final_kernel) + ticket
+    // CR reduction (kernels.h): level-1 partial sums [2 MAX_CR][cr_n1] of a generation (chunks of cr_g1 positions), two buffers for the cr_mid_kernel passes
+    double* cr_p1 = nullptr;
+    double* cr_p2[2] = {nullptr, nullptr};
+    uint32_t cr_g1 = 16, cr_n1 = 0;
+    bool gen_cr_inkernel = false;     // this generation's update kernels write level 1 themselves (both launches are burn-in flavours: HOT 3 / 4)
     unsigned long long* counters = nullptr;  // device: [2] = NaN ratios
     uint32_t* acc_count = nullptr;           // device: accepted updates per local chain, this run
     int64_t gens_this_run_local = 0;
@@ -854,7 +859,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     }
     if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_part, s->counters, s->acc_count,
+    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -1044,9 +1049,15 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     HIPCKD(hipMemsetAsync(s->tparams, 0, ((size_t)np + 2) * sizeof(double), s->stream));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
     CKD(dev_alloc_state(&s->cr_state, 3 * MAX_CR, s->coherent));
-    if (cfg->algo == BPM_ALGO_DREAM) {       // (+ the ticket of the one-dispatch form behind the sums)
-        CKD(dev_alloc_state(&s->cr_part, (size_t)2 * MAX_CR * CR_PARTS + 2, s->coherent));
-        HIPCKD(hipMemsetAsync(s->cr_part, 0, ((size_t)2 * MAX_CR * CR_PARTS + 2) * sizeof(double), s->stream));
+    if (cfg->algo == BPM_ALGO_DREAM) {       // the partial sums of the CR reduction (kernels.h)
+        const uint32_t n_first = (s->N + 1u) / 2u;
+        s->cr_g1 = (uint32_t)cr_g1(s->shape.lpc);
+        s->cr_n1 = cr_chunks_of(n_first, s->cr_g1) + cr_chunks_of(s->N - n_first, s->cr_g1);
+        const size_t n2 = ((size_t)s->cr_n1 + WAVE - 1) / WAVE;
+        CKD(dev_alloc_state(&s->cr_p1, (size_t)2 * MAX_CR * s->cr_n1, s->coherent));
+        HIPCKD(hipMemsetAsync(s->cr_p1, 0, (size_t)2 * MAX_CR * s->cr_n1 * sizeof(double), s->stream));
+        if (s->cr_n1 > CR_FINAL_MAX)
+            for (auto& b : s->cr_p2) { CKD(dev_alloc_state(&b, (size_t)2 * MAX_CR * n2, s->coherent)); HIPCKD(hipMemsetAsync(b, 0, (size_t)2 * MAX_CR * n2 * sizeof(double), s->stream)); }
     }
     {
         double init[3 * MAX_CR] = {0};
@@ -1516,6 +1527,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.pack_nsub = s->xnsub;
             a.pack_stride = s->xstride();
         }
+        a.cr_part1 = nullptr; a.cr_chunk0 = 0u; a.cr_n1 = s->cr_n1;
         if (sync) {      // samplers.py:261-308: one launch, every local chain against all other chains, updates banked
             a.algo = (uint32_t)BPM_ALGO_DEMC;
             a.mode = 2u;
@@ -1525,6 +1537,26 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.x_next = s->x_next;
         }
     }
+    // CR reduction, level 1 (kernels.h): written by the update kernels themselves when BOTH launches of the generation take a burn-in flavour
+    // (HOT 3 / 4: single GPU, work item = position, no trace ...: the predicate launch_fused applies), else computed from the slots in finish_generation
+    s->gen_cr_inkernel = false;
+    if (s->gen_cr_reduce && dream && s->cfg.target_id != BPM_TARGET_HOST_CALLBACK && s->shape.idx != SHAPE_WIDE && crp_shape(s->shape.lpc, s->shape.dpl) &&
+        !test_path("nohot") && !test_path("crslots")) {
+        bool ok = true;
+        for (int ph = 0; ph < 2; ++ph) {
+            const PhaseArgs& a = s->cur_args[ph];
+            ok = ok && (a.n_items == 0 || phase_args_hot(a, true, a.rec_tab != nullptr, true));
+        }
+        if (ok) {
+            const uint32_t n_first = (s->N + 1u) / 2u;
+            for (int ph = 0; ph < 2; ++ph) {
+                PhaseArgs& a = s->cur_args[ph];
+                a.cr_part1 = s->cr_p1;
+                a.cr_chunk0 = a.upd_off == 0u ? 0u : cr_chunks_of(n_first, s->cr_g1);
+            }
+            s->gen_cr_inkernel = true;
+        }
+    }
     return 0;
 }
 
@@ -1532,34 +1564,52 @@ static int finish_generation(bpm_sampler* s) {
     if (s->lean) s->ll_stale = true;
     if (s->gen_adapt_on && !s->gen_cr_reduce) s->w_rows += 1;       // (the update kernels advanced the Welford moments all the same)
     if (s->gen_cr_reduce) {
-        // this generation's (delta, cr) slots -> partial sums -> totals, p_cr (kernels.h: "CR reduction in two dispatches"; beyond
-        // 65536 chains ONE dispatch whose last workgroup folds)
-        const uint32_t span = cr_part_span(s->N), nb = (s->N + span - 1) / span;
-        const bool big = cr_part_threads(s->N) == 1024u;
-        uint32_t* ticket = reinterpret_cast<uint32_t*>(s->cr_part + (size_t)2 * MAX_CR * CR_PARTS);
+        // this generation's CR statistics -> totals, p_cr (kernels.h: "CR reduction"): level 1 came out of the update kernels themselves
+        // (gen_cr_inkernel) or is computed from the slots here, cr_mid_kernel passes bring more than 1024 partial sums down, cr_final_kernel folds
+        const uint32_t n_cr = (uint32_t)s->cfg.n_cr;
+        const int fence = s->dq_fence | bpm::DirectQueue::ACQUIRE;      // (a few hundred bytes, all through agent-scope stores: no release on these packets)
+        if (g_dq) g_dq_need_acquire = false;
+        if (!s->gen_cr_inkernel) {
+            const PhaseArgs& a0 = s->cur_args[0];
+            typedef void (*L1K)(Layout, PermKey, const uint32_t*, uint32_t, uint32_t, uint32_t, double*);
+            const L1K l1 = s->cr_g1 == 4u ? cr_level1_kernel<4> : (s->cr_g1 == 16u ? cr_level1_kernel<16> : cr_level1_kernel<64>);
+            if (g_dq) {
+                struct { Layout L; PermKey pk; const uint32_t* perm; uint32_t N, n_cr, n1, _pad; double* part1; } ka{s->L, a0.pk, a0.perm_tab, s->N, n_cr, s->cr_n1, 0u, s->cr_p1};
+                const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(l1));
+                if (!k || g_dq->launch(*k, (uint32_t)(((uint64_t)s->cr_n1 * s->cr_g1 + CR_L1_THREADS - 1) / CR_L1_THREADS), 1, CR_L1_THREADS, &ka, sizeof(ka), fence) != 0)
+                    return fail("direct AQL queue: cr_level1_kernel: " + g_dq->why());
+            } else {
+                hipLaunchKernelGGL(l1, dim3((unsigned)(((uint64_t)s->cr_n1 * s->cr_g1 + CR_L1_THREADS - 1) / CR_L1_THREADS)), dim3(CR_L1_THREADS), 0, s->stream, s->L, a0.pk, a0.perm_tab, s->N,
+                                   n_cr, s->cr_n1, s->cr_p1);
+                HIPCK(hipGetLastError());
+            }
+        }
+        const double* src = s->cr_p1;
+        uint32_t cnt = s->cr_n1;
+        int flip = 0;
+        while (cnt > CR_FINAL_MAX) {
+            const uint32_t nn = (cnt + WAVE - 1) / WAVE;
+            double* dst = s->cr_p2[flip];
+            if (g_dq) {
+                struct { const double* p1; uint32_t n1, n_cr, n2, _pad; double* p2; } ka{src, cnt, n_cr, nn, 0u, dst};
+                const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(cr_mid_kernel));
+                if (!k || g_dq->launch(*k, nn, 1, WAVE, &ka, sizeof(ka), fence) != 0) return fail("direct AQL queue: cr_mid_kernel: " + g_dq->why());
+            } else {
+                hipLaunchKernelGGL(cr_mid_kernel, dim3(nn), dim3(WAVE), 0, s->stream, src, cnt, n_cr, nn, dst);
+                HIPCK(hipGetLastError());
+            }
+            src = dst; cnt = nn; flip ^= 1;
+        }
+        // (ROUNDS = partials per lane, the next power of two: a partial beyond cnt reads as +0.0, the sums do not depend on the choice)
+        typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
+        const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
+        const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
         if (g_dq) {
-            struct { Layout L; uint32_t N, n_cr, span, _pad; double* part; double* cr_state; uint32_t* ticket; uint32_t nb; } pa{
-                s->L, s->N, (uint32_t)s->cfg.n_cr, span, 0u, s->cr_part, s->cr_state, ticket, nb};
-            static_assert(offsetof(decltype(pa), part) == sizeof(Layout) + 16, "kernarg layout of cr_partial_kernel");
-            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, s->cr_part, nb, (uint32_t)s->cfg.n_cr, s->cr_state};
-            const bpm::DqKernel* kp = g_dq->kernel(big ? reinterpret_cast<const void*>(cr_partial_kernel<1024, true>) : reinterpret_cast<const void*>(cr_partial_kernel<256, false>));
-            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(cr_final_kernel));
-            // the reduction kernels write a few hundred bytes, all with agent-scope stores: no release on their packets (s->dq_fence: the
-            // sampler's steady-state fence) -- the update kernels before them keep theirs
-            const int fence = s->dq_fence | bpm::DirectQueue::ACQUIRE;
-            g_dq_need_acquire = false;
-            if (!kp || !kf || g_dq->launch(*kp, nb, 1, big ? 1024u : 256u, &pa, sizeof(pa), fence) != 0 ||
-                (!big && g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0))
-                return fail("direct AQL queue: CR reduction kernels: " + g_dq->why());
-        } else if (big) {
-            hipLaunchKernelGGL((cr_partial_kernel<1024, true>), dim3(nb), dim3(1024), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr, span, s->cr_part, s->cr_state,
-                               ticket, nb);
-            HIPCK(hipGetLastError());
+            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
+            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
+            if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
         } else {
-            hipLaunchKernelGGL((cr_partial_kernel<256, false>), dim3(nb), dim3(256), 0, s->stream, s->L, s->N, (uint32_t)s->cfg.n_cr, span, s->cr_part, s->cr_state,
-                               ticket, nb);
-            hipLaunchKernelGGL(cr_final_kernel, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, (const double*)s->cr_part, nb, (uint32_t)s->cfg.n_cr,
-                               s->cr_state);
+            hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
             HIPCK(hipGetLastError());
         }
         s->w_rows += 1;

@@ -5,13 +5,17 @@ A callable handed to DeMcMpi/DreamMpi as `ln_like_fn` is evaluated ON THE GPU wh
       bipymc_amd.utils), or
   (2) the bound `ln_like` of one of the REFERENCE's own target objects -- `bipymc.utils.d100_gauss.Gauss_100D`
       (utils/d100_gauss.py:10-35), `dblgauss_rv.BimodeGauss_2D` (utils/dblgauss_rv.py:10-32), `banana_rv.Banana_2D`
-      (utils/banana_rv.py:10-40) -- recognised by class name and the attributes their constructors set.  A user script
+      (utils/banana_rv.py:10-40) -- recognised by class name AND module (`bipymc.utils.<module>`), with `ln_like` the very function the
+      class body defines (no subclass, no override, no instance patch: a user's variant of a reference class -- a prior box that returns
+      -inf, a tempering factor -- is a user likelihood and takes the host callback), and by the attributes their constructors set.  A user script
       that keeps `from bipymc.utils import d100_gauss` and only switches the sampler import is the drop-in case; without
       this it would silently take the host-callback path (samplers.py:36-43), ~10^4 x slower.  The device parameter block is
-      rebuilt from the object's attributes and then VERIFIED: the callable itself is evaluated at a handful of points near
-      the target's mass and compared with the closed form the device evaluates; any mismatch (a subclass that overrides
-      ln_like, edited attributes, a look-alike with other semantics) falls back to the host callback.
+      rebuilt from the object's attributes and then VERIFIED: the callable itself is evaluated at points near the target's
+      mass AND far in its tails (3 ... 9 standard deviations out, single coordinates at +-8 sigma: where a truncation, a prior
+      box or an edited pdf() would show) and compared with the closed form the device evaluates; any mismatch falls back to the
+      host callback.  A promotion to the device path is logged (logger "bipymc_amd", INFO) with the rule that applied.
 Any other callable takes the host-callback path.  `resolve_info()` says which rule applied."""
+import logging
 import math
 
 import numpy as np
@@ -65,6 +69,14 @@ def _like_gauss(o, dim):
     blk = equicorr_block(rho, sg)
     rs = np.random.RandomState(12345)
     pts = [np.zeros(d), 0.5 * sg, -0.25 * sg * (1 + np.arange(d) % 2)] + [sg * 0.7 * rs.standard_normal(d) for _ in range(3)]
+    # far tails: random directions at Mahalanobis-like radii 3, 6, 9 and single coordinates at +-8 sigma (a prior box, a truncation)
+    for r in (3.0, 6.0, 9.0):
+        u = rs.standard_normal(d)
+        pts.append(sg * u * (r / math.sqrt(float(u @ u))) * math.sqrt(d) / max(1.0, math.sqrt(d) / 3.0))
+    for j in (0, d // 2, d - 1):
+        e = np.zeros(d)
+        e[j] = 8.0 * sg[j] * (1 if j % 2 == 0 else -1)
+        pts.append(e)
     return TARGET_GAUSS_EQUICORR, blk, pts, lambda y: equicorr_ln_like(blk, y)
 
 
@@ -91,6 +103,9 @@ def _like_mixture(o, dim):
     s1, s2 = np.array(c1[:2]), np.array(c2[:2])
     pts = [m1, m2, m1 + 0.5 * s1, m2 - 0.7 * s2, 0.5 * (m1 + m2) * np.array([1.0, 0.9]), m1 + np.array([1.5, -1.0]) * s1,
            m2 + np.array([-2.0, 0.5]) * s2]
+    for r, ang in ((4.0, 0.3), (7.0, 2.0), (10.0, 4.1), (14.0, 5.5)):             # far tails around both modes
+        pts.append(m1 + r * s1 * np.array([math.cos(ang), math.sin(ang)]))
+        pts.append(m2 + r * s2 * np.array([math.cos(ang + 1.0), math.sin(ang + 1.0)]))
     return TARGET_MIXTURE_PAIRS, blk, pts, closed
 
 
@@ -109,16 +124,38 @@ def _like_banana(o, dim):
         x2 = (y[1] - b * (x1 * x1 + a * a)) * a
         return log_binormal((x1 - mu1) / s1, (x2 - mu2) / s2, rho, blk[5], blk[6])
     pts = []
-    for x1, x2 in ((mu1, mu2), (mu1 + s1, mu2 + 0.8 * s2), (mu1 - 1.5 * s1, mu2 - s2), (mu1 + 0.3 * s1, mu2 - 1.2 * s2), (mu1 - 0.4 * s1, mu2 + 2 * s2)):
+    for x1, x2 in ((mu1, mu2), (mu1 + s1, mu2 + 0.8 * s2), (mu1 - 1.5 * s1, mu2 - s2), (mu1 + 0.3 * s1, mu2 - 1.2 * s2), (mu1 - 0.4 * s1, mu2 + 2 * s2),
+                   (mu1 + 4 * s1, mu2 + 3 * s2), (mu1 - 6 * s1, mu2 - 7 * s2), (mu1 + 8 * s1, mu2 + 9 * s2), (mu1 - 3 * s1, mu2 + 5 * s2)):      # ... and the tails
         pts.append(np.array([a * x1, x2 / a + b * (x1 * x1 + a * a)]))       # banana_rv.py:42-45 transform
     return TARGET_BANANA_2D, blk, pts, closed
 
 
-_LOOKALIKES = {"Gauss_100D": _like_gauss, "BimodeGauss_2D": _like_mixture, "Banana_2D": _like_banana}
+# class name -> (the module the reference defines it in, builder)
+_LOOKALIKES = {"Gauss_100D": ("bipymc.utils.d100_gauss", _like_gauss), "BimodeGauss_2D": ("bipymc.utils.dblgauss_rv", _like_mixture),
+               "Banana_2D": ("bipymc.utils.banana_rv", _like_banana)}
+LOG_UNDERFLOW = -650.0       # np.log(pdf) of the reference underflows to -inf from here on (d100_gauss.py:35): -inf is then its legitimate answer
+
+
+def _reference_class_builder(ln_like_fn, owner):
+    """the builder when `owner` is an instance of one of the reference's target classes ITSELF and `ln_like_fn` the function that class's
+    body defines -- else None (a subclass or a patched instance keeps the attributes but may change the density anywhere)"""
+    cls = type(owner)
+    mod, build = _LOOKALIKES.get(cls.__name__, (None, None))
+    if build is None or getattr(cls, "__module__", None) != mod:
+        return None
+    if cls.__mro__ != (cls, object):                              # a subclass (of the reference's class or of anything else) is a user's class
+        return None
+    f = vars(cls).get("ln_like")
+    if f is None or getattr(ln_like_fn, "__func__", None) is not f:
+        return None
+    inst = getattr(owner, "__dict__", {})
+    if "ln_like" in inst or "pdf" in inst:                        # patched on the instance
+        return None
+    return build
 
 
 def _resolve_lookalike(ln_like_fn, owner, dim):
-    build = _LOOKALIKES.get(type(owner).__name__)
+    build = _reference_class_builder(ln_like_fn, owner)
     if build is None:
         return None
     try:
@@ -127,10 +164,16 @@ def _resolve_lookalike(ln_like_fn, owner, dim):
             return None
         tid, blk, pts, closed = got
         for y in pts:
-            ref = float(np.asarray(ln_like_fn(np.array(y, dtype=np.float64))).reshape(-1)[0])
+            with np.errstate(divide="ignore"):
+                ref = float(np.asarray(ln_like_fn(np.array(y, dtype=np.float64))).reshape(-1)[0])
             mine = float(closed(np.asarray(y, dtype=np.float64)))
+            if mine < LOG_UNDERFLOW and ref == -np.inf:
+                continue                                          # the reference's own underflow (documented deviation: DESIGN.md section 2)
             if not (np.isfinite(ref) and abs(ref - mine) <= VERIFY_ATOL + VERIFY_RTOL * abs(mine)):
                 return None
+        logging.getLogger("bipymc_amd").info("ln_like_fn is the ln_like of bipymc's own %s: evaluated on the GPU (closed form verified at %d "
+                                             "points; target_rule 'reference-lookalike'; force_host_callback=True keeps the Python callable)",
+                                             type(owner).__name__, len(pts))
         return tid, np.ascontiguousarray(blk, dtype=np.float64)
     except Exception:
         return None                                             # anything unexpected: the host callback is always right

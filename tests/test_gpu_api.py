@@ -256,7 +256,9 @@ def test_alternative_kernel_paths_on_one_gpu():
     instead of read from plan_kernel's records; noperm -- the shuffle bijection walked in the kernel instead of looked up;
     planall -- plan records whatever the number of chains; nohot -- the general instantiation instead of the specialised ones;
     wt8 -- round 2's two 8-byte write-through stores per lane instead of one 16-byte store; histchain -- the history append by chain
-    index instead of in shuffle order (what fewer than 64 lanes per chain use);
+    index instead of in shuffle order (what fewer than 64 lanes per chain use); crslots -- level 1 of the CR reduction computed from the slots by
+    cr_level1_kernel (what a rank of a world and the general kernel use) instead of inside the update kernels; lean -- ln_like of the current state
+    re-evaluated from the own row and accepts counted per wavefront (what >= 49152 chains per GPU use) at any size;
     and the operational switches BPM_DIRECT_QUEUE=0 (HIP stream launches) and BPM_QUEUE_INFLIGHT (a drain every few dispatches)."""
     import subprocess
     import sys
@@ -281,7 +283,8 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     res = []
     for paths, extra in (("", {}), ("nohot", {}), ("mode1", {}), ("noplan", {}), ("noperm", {}), ("mode1,noplan", {}), ("planall", {}),
                          ("planall,mode1", {}), ("", {"BPM_DIRECT_QUEUE": "0"}), ("nohot", {"BPM_DIRECT_QUEUE": "0"}),
-                         ("", {"BPM_QUEUE_INFLIGHT": "3"}), ("wt8", {}), ("histchain", {}), ("wt8,histchain,nohot", {})):
+                         ("", {"BPM_QUEUE_INFLIGHT": "3"}), ("wt8", {}), ("histchain", {}), ("wt8,histchain,nohot", {}), ("crslots", {}), ("lean", {}),
+                         ("crslots,lean,mode1", {})):
         env = dict(os.environ)
         for k in ("BPM_TEST_PATHS", "BPM_DIRECT_QUEUE", "BPM_QUEUE_INFLIGHT"):
             env.pop(k, None)

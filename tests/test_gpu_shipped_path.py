@@ -87,6 +87,25 @@ def test_cfg5_share_on_the_shipped_path_equals_the_oracle():
               dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1), hist_rows=(2, 10))
 
 
+@pytest.mark.parametrize("N,d,tgt", [(40000, 8, "mix"), (70001, 2, "gauss"), (8195, 100, "gauss"), (5000, 20, "gauss"), (4099, 300, "gauss")])
+def test_cr_statistics_summed_inside_the_update_kernels_equal_the_oracle(N, d, tgt):
+    """Round 4: level 1 of the CR reduction (dream.py:119-140) is written by the burn-in flavours of the update kernel themselves -- a wavefront's 16 / 64
+    chains (d = 8 / d = 2) or a workgroup of 16 wavefronts (d = 100) per chunk of positions -- cr_mid_kernel passes fold more than 1024 chunks
+    (N = 40000 at d = 8: 2500; N = 70001 at d = 2: 1095), cr_final_kernel finishes; odd populations (a ragged last chunk in both halves); d = 20
+    (4 chains per wavefront) and d = 300 (one wavefront per chain with 8 coordinates per lane: level 1 from the slots).  Against the oracle over 7
+    burn-in generations, on the shipped path (own queue, no trace)."""
+    if tgt == "mix":
+        params = R.mixture_pairs_params(0.25, 0.75, [0, 0], [2, 2], [0.25, 0.25], [0.25, 0.25], 0.8, -0.8)
+        tid = R.TARGET_MIXTURE_PAIRS
+        rs = np.random.RandomState(9)
+        X0 = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
+    else:
+        params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
+        tid = R.TARGET_GAUSS_EQUICORR
+        X0 = np.random.RandomState(4).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _run_both(R.ALGO_DREAM, N, d, tid, params, 31, X0, 7, dict(del_pairs=3, n_cr=3, burnin_gen=100, n_cr_gen=1), hist_rows=(2, 7))
+
+
 @pytest.mark.parametrize("algo,N,d,shuffle,flip", [("demc", 77, 2, True, 0.5), ("demc", 10, 1, True, 0.3), ("demc", 129, 3, False, 1.0),
                                                     ("dream", 101, 8, True, 0.5), ("dream", 64, 5, False, 0.0), ("dream", 33, 17, True, 0.7),
                                                     ("dream", 12, 32, True, 0.5)])

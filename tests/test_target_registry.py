@@ -67,6 +67,34 @@ def test_verification_rejects_a_lookalike_with_another_density():
     assert T.resolve_info(m.ln_like, {}, 2)[2] == "host-callback"
 
 
+def test_a_users_variant_of_a_reference_class_stays_a_host_callback():
+    """a subclass / a patched instance / a same-named class from another module keeps the attributes the look-alike rule reads and may
+    change ln_like AWAY from the mode (a prior box, a truncation, a tempering factor): its likelihood must never be replaced by the closed form."""
+    import types
+    boxed = LK.Gauss_100D_boxed(dim=6)
+    assert np.isfinite(boxed.ln_like(np.zeros(6))) and boxed.ln_like(np.full(6, 100.0)) == -np.inf
+    assert T.resolve_info(boxed.ln_like, {}, 6)[2] == "host-callback"                 # a subclass under its own name
+    Same = type("Gauss_100D", (LK.Gauss_100D_boxed,), {"__module__": "bipymc.utils.d100_gauss"})
+    assert T.resolve_info(Same(dim=6).ln_like, {}, 6)[2] == "host-callback"           # ... under the reference's name and module: still a subclass
+    Flat = type("Gauss_100D", (object,), dict(vars(LK.Gauss_100D_boxed), __init__=LK.Gauss_100D.__init__,
+                                              __module__="bipymc.utils.d100_gauss"))
+    Flat.ln_like = lambda self, y: (-np.inf if np.any(np.abs(np.asarray(y)) > 5.0 * self.var) else float(np.log(self.rv_100d.pdf(y))))
+    assert T.resolve_info(Flat(dim=6).ln_like, {}, 6)[2] == "host-callback"           # no base class, same name and module: the TAIL probes catch the box
+    g = LK.Gauss_100D(dim=6)
+    g.ln_like = types.MethodType(lambda self, y: -0.5 * float(np.sum(np.asarray(y) ** 2)), g)
+    assert T.resolve_info(g.ln_like, {}, 6)[2] == "host-callback"                     # patched on the instance
+    Elsewhere = type("Gauss_100D", (object,), dict(vars(LK.Gauss_100D), __module__="my_models"))
+    assert T.resolve_info(Elsewhere(dim=6).ln_like, {}, 6)[2] == "host-callback"      # the name alone is not enough any more
+    assert T.resolve_info(LK.Gauss_100D(dim=6).ln_like, {}, 6)[2] == "reference-lookalike"
+
+
+def test_promotion_to_the_device_path_is_logged(caplog):
+    import logging
+    with caplog.at_level(logging.INFO, logger="bipymc_amd"):
+        assert T.resolve_info(LK.Banana_2D().ln_like, {}, 2)[2] == "reference-lookalike"
+    assert any("evaluated on the GPU" in r.getMessage() and "Banana_2D" in r.getMessage() for r in caplog.records)
+
+
 def test_rules_that_keep_the_host_callback():
     g = LK.Gauss_100D(dim=6)
     assert T.resolve_info(g.ln_like, {"extra": 1}, 6)[2] == "host-callback"      # frozen kwargs change the callable
