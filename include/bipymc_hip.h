@@ -64,7 +64,8 @@ typedef struct bpm_config {
     int32_t abi_version; /* BPM_ABI_VERSION */
     int32_t algo;        /* BPM_ALGO_* */
     int32_t n_chains;    /* global number of chains, >= 4 (samplers.py:249), divisible by world_size */
-    int32_t dim;         /* len(theta_0) or kwargs["dim"] (demc.py:20-23); 1 ... 2048 (the reference has no limit) */
+    int32_t dim;         /* len(theta_0) or kwargs["dim"] (demc.py:20-23); 1 ... 131055 and n_chains * (dim + 2) < 2^31 (the reference has no limit;
+                          * rows wider than 512 coordinates run on the looped kernel, bipymc_amd/csrc/kernels_wide.h) */
     int32_t target_id;   /* BPM_TARGET_* */
     int32_t n_target_params;
     const double* target_params; /* copied */
@@ -75,7 +76,7 @@ typedef struct bpm_config {
     const char* nccl_uid;        /* BPM_UID_BYTES from bpm_get_unique_id on rank 0; NULL if world_size==1 */
     /* DREAM kwargs (dream.py:20-27) */
     double gamma_scale; /* 1.0 */
-    int32_t del_pairs;  /* 3 */
+    int32_t del_pairs;  /* 3; 1 ... 10 */
     int32_t burnin_gen; /* 300 */
     int32_t n_cr_gen;   /* 50 */
     int32_t n_cr;       /* 3, <= BPM_MAX_CR */

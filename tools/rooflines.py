@@ -54,7 +54,7 @@ out = [
     entry("cfg2 DREAM d=100 N=8192 steady", "phase_fused_kernel<1,1,64,2,3,1>", T + "_kernel_stats_bench_driver.csv", "64, 2, 3, 1>", 7216, 4096,
           traffic(T + "_pmc_bench_driver.txt"), "kernel-trace duration of the driver's invocation; bench.py reports the back-to-back launch period"),
     entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", T + "_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
-          "Welford moments r/w add 32 d bytes per update; + cr_partial_kernel + cr_final_kernel per generation"),
+          "Welford moments r/w add 32 d bytes per update; level 1 of the CR reduction inside the kernel (round 4), + cr_final_kernel per generation"),
     entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", T + "_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
           traffic(T + "_pmc_cfg3.txt"), "latency bound: launch floor + dependent Infinity-Cache round trips; a 16-byte row is an eighth of a 128-byte line"),
     entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5.csv", "<1, 2, 4, 2, 3, 2>", 592, 131072,
@@ -62,6 +62,6 @@ out = [
     entry("cfg5 one GPU's share N=32768 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5_local.csv", "<1, 2, 4, 2, 3, 2>", 592, 16384, None,
           "latency bound (1024 wavefronts)"),
     entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", T + "_kernel_stats_cfg5_burnin.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
-          "+ cr_partial_kernel (ticket form) per generation, outlier check every 50 generations"),
+          "level 1 of the CR reduction inside the kernel (round 4), + cr_mid_kernel + cr_final_kernel per generation, outlier check every 50 generations"),
 ]
 print(json.dumps(out, indent=1))
