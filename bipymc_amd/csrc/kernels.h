@@ -208,6 +208,8 @@ struct PhaseArgs {
     uint32_t hist_by_pos;       // 1: the history row and its ln-like are appended at the update's POSITION in this generation's shuffle order
                                 // (work items of a wavefront write consecutive rows) instead of at the chain's index; the host remembers the
                                 // generation, and rows are put back into chain order when anything reads them (sampler.hip: normalize_history)
+                                // 2: the row by position, its ln-like by chain (while DREAM's outlier check is due every few generations: it sums
+                                // the ln-like history of every chain, see outlier_omega_kernel)
 #ifndef BPM_LEAN_LAST
     uint32_t lean;              // 1 (several chains per wavefront, device target, many chains): ln_like of the current state is re-evaluated from the own
                                 // row instead of read from `ll`, `ll` is not written, accepted updates are counted per wavefront (kernels.h: lean_scalars)
@@ -421,6 +423,10 @@ struct Target<TARGET_GAUSS, LPC, DPL> {
 template <int LPC, int DPL>
 struct Target<TARGET_MIXTURE, LPC, DPL> {
     struct Consts { double p[16]; };
+    // (the sixteen values are the same for every lane, yet they arrive through the vector memory path and sit in 32 VGPRs for the whole kernel: 98 VGPRs,
+    // 4 wavefronts per SIMD at cfg5.  Round 4 read them through the constant address space instead -- scalar loads, 67 VGPRs, 7 wavefronts per SIMD --
+    // and every small-d workload got SLOWER (cfg5 45.2 -> 46.7, its share 9.4 -> 10.5 us per generation): the kernel is not short of wavefronts, and
+    // the SGPR file was full already.  DESIGN.md section 5.)
     static __device__ __forceinline__ Consts load(int, uint32_t, const double* tp) {
         Consts k;
 #pragma unroll
@@ -1136,7 +1142,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     }
     const uint32_t hi = a.hist_by_pos ? wk.pos_own : li;
     if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(hi * ld), q, ld, nv);
-    if (a.llhist_row && q == 0) a.llhist_row[hi] = new_ll;
+    if (a.llhist_row && q == 0) a.llhist_row[a.hist_by_pos == 1u ? wk.pos_own : li] = new_ll;
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)
@@ -1808,7 +1814,7 @@ __global__ void hist_unpermute_kernel(const PermKey key, uint32_t N, uint32_t ld
     const uint32_t k = (uint32_t)(e / np), p = (uint32_t)(e % np);
     const uint32_t c = perm_fwd(k, key);
     reinterpret_cast<double2*>(dst + (uint64_t)c * ld)[p] = reinterpret_cast<const double2*>(src + (uint64_t)k * ld)[p];
-    if (p == 0) lldst[c] = llsrc[k];
+    if (p == 0 && llsrc) lldst[c] = llsrc[k];      // (llsrc == nullptr: this row's ln-like was appended by chain)
 }
 
 // Records of K consecutive generations in one launch, one thread per (generation, position in shuffle order):
@@ -2007,14 +2013,27 @@ __global__ __launch_bounds__(SLOT_CHUNK) void plan_slot_own_kernel(const uint32_
 // and synchronised the stream three times per check.
 // OM layout: rank r's block at OM + r * 2 * n_local = [omega (n_local) | ln_like (n_local)].
 // ---------------------------------------------------------------------------------
-__global__ void outlier_omega_kernel(const double* llhist, const double* ll, uint32_t n_local, uint32_t r0, uint32_t rows, double* om_block) {
+// ln-like rows appended by POSITION (PhaseArgs::hist_by_pos == 1) are read where they lie: keys[g] is the shuffle of the generation that wrote row g
+// (identity for a row in chain order), chain i's entry sits at position pi_g^-1(i).  That gather is slow -- every XCD pulls nearly the whole row
+// through its L2: 335 us per check at cfg5 with 90 rows in the window -- so while the check is due every few generations the update kernels append
+// the ln-like by chain (hist_by_pos == 2: one scattered 8-byte store per update) and keys is nullptr: coalesced reads.
+__global__ void outlier_omega_kernel(const double* llhist, const double* ll, uint32_t n_local, uint32_t r0, uint32_t rows, const PermKey* keys, double* om_block) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
     double acc = 0.0;
     uint32_t cnt = 0;
-    for (uint32_t g = r0; g < rows; ++g) {          // rows whose ln_like is unknown (NaN: warm start with a host callback) do not count
-        const double v = llhist[(uint64_t)g * n_local + i];
-        if (v == v) { acc += v; ++cnt; }
+    constexpr uint32_t UNR = 4;                     // (the scattered loads of 4 rows in flight; summed in row order all the same)
+    for (uint32_t g0 = r0; g0 < rows; g0 += UNR) {  // rows whose ln_like is unknown (NaN: warm start with a host callback) do not count
+        double v[UNR];
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; ++u) {
+            const uint32_t g = g0 + u < rows ? g0 + u : rows - 1u;
+            const uint32_t p = keys ? perm_inv(i, keys[g]) : i;
+            v[u] = llhist[(uint64_t)g * n_local + p];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; ++u)
+            if (g0 + u < rows && v[u] == v[u]) { acc += v[u]; ++cnt; }
     }
     om_block[i] = cnt ? acc / (double)cnt : acc / 0.0;
     om_block[n_local + i] = ll[i];
@@ -2035,6 +2054,7 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 }
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_UNR = 4;              // elements per thread and pass
+inline uint32_t sel_blocks(uint32_t N) { return (N + SEL_THREADS * SEL_UNR - 1) / (SEL_THREADS * SEL_UNR); }      // workgroups of one pass
 struct SelRanks { uint32_t k[4]; };      // 0-based order statistics: floor / ceil positions of the 25th and 75th percentile
 // Radix-select state in global memory: per target the key prefix fixed so far and the rank left inside it; the histogram of
 // the pass in flight ([4][256], zero between passes) and the launch's ticket follow it.
@@ -2048,7 +2068,8 @@ struct SelState {
 // of N / (1024 * SEL_UNR) workgroups: each histograms its slice in LDS (targets whose prefixes still coincide share one
 // histogram) and adds the non-empty bins to the global histogram; the LAST workgroup to finish (ticket) picks every
 // target's bin, extends its prefix, and clears histogram and ticket for the next pass.  After pass 7 sel[b] is the value.
-// The extra workgroup blockIdx.x == gridDim.x - 1 of pass 0 finds the first maximum (np.argmax) -> sel[4].
+// Pass 0 also finds the first maximum (np.argmax) -> sel[4]: per-workgroup (value, first index) pairs behind the state, folded by the last workgroup
+// (one extra workgroup walking all N values took 65 us at N = 262144).
 // (Round 2's first version ran all eight passes in ONE workgroup per target: 1.26 ms per check at N = 262144, five CUs busy.)
 __global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const double* OM, uint32_t n_local, uint32_t N, int pass, SelRanks R,
                                                                          SelState* st, double* sel) {
@@ -2057,23 +2078,11 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const 
     __shared__ double s_v[SEL_THREADS];
     __shared__ uint32_t s_i[SEL_THREADS];
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_hist_blocks = pass == 0 ? gridDim.x - 1u : gridDim.x;
-    if (pass == 0 && blockIdx.x == gridDim.x - 1u) {
-        double best = 0.0;
-        uint32_t bi = 0xFFFFFFFFu;
-        for (uint32_t e0 = 0; e0 < N; e0 += SEL_THREADS * 8u) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t e = e0 + (uint32_t)u * SEL_THREADS + tid;
-                v[u] = e < N ? om_at(OM, n_local, e) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t e = e0 + (uint32_t)u * SEL_THREADS + tid;
-                if (e < N && (bi == 0xFFFFFFFFu || v[u] > best)) { best = v[u]; bi = e; }      // ascending e per thread: keeps the first maximum
-            }
-        }
+    const uint32_t n_hist_blocks = gridDim.x;
+    // the first maximum (pass 0): every workgroup folds its slice into (value, first index), the last one folds those
+    double* pmax_v = reinterpret_cast<double*>(st + 1);
+    uint32_t* pmax_i = reinterpret_cast<uint32_t*>(pmax_v + gridDim.x);
+    auto fold_first_max = [&](double best, uint32_t bi) {      // -> s_v[0], s_i[0]; ties: the lower index
         s_v[tid] = best; s_i[tid] = bi;
         __syncthreads();
         for (uint32_t o = SEL_THREADS / 2; o > 0; o >>= 1) {
@@ -2087,9 +2096,7 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const 
             }
             __syncthreads();
         }
-        if (tid == 0) sel[4] = (double)s_i[0];
-        return;
-    }
+    };
     const int shift = 56 - 8 * pass;
     const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
     unsigned long long prefix[4];
@@ -2106,10 +2113,24 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const 
     __syncthreads();
     const uint32_t base = blockIdx.x * (SEL_THREADS * SEL_UNR);
     unsigned long long keys[SEL_UNR];
+    {
+        double best = 0.0;
+        uint32_t bi = 0xFFFFFFFFu;
 #pragma unroll
-    for (int u = 0; u < SEL_UNR; ++u) {
-        const uint32_t e = base + (uint32_t)u * SEL_THREADS + tid;
-        keys[u] = e < N ? f64_key(om_at(OM, n_local, e)) : 0ull;
+        for (int u = 0; u < SEL_UNR; ++u) {
+            const uint32_t e = base + (uint32_t)u * SEL_THREADS + tid;
+            const double v = e < N ? om_at(OM, n_local, e) : 0.0;
+            keys[u] = e < N ? f64_key(v) : 0ull;
+            if (pass == 0 && e < N && (bi == 0xFFFFFFFFu || v > best)) { best = v; bi = e; }      // ascending e per thread: keeps the first maximum
+        }
+        if (pass == 0) {
+            fold_first_max(best, bi);
+            if (tid == 0) {
+                __hip_atomic_store(&pmax_v[blockIdx.x], s_v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&pmax_i[blockIdx.x], s_i[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int u = 0; u < SEL_UNR; ++u) {
@@ -2189,6 +2210,18 @@ __global__ __launch_bounds__(SEL_THREADS) void outlier_select_pass_kernel(const 
             if (pass == 7) sel[b] = key_f64(np);
         }
     }
+    if (pass == 0) {
+        __syncthreads();
+        double best = 0.0;
+        uint32_t bi = 0xFFFFFFFFu;
+        for (uint32_t k = tid; k < gridDim.x; k += SEL_THREADS) {      // (ascending slices per thread: a later slice wins only with a larger value)
+            const double v = __hip_atomic_load(&pmax_v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t i = __hip_atomic_load(&pmax_i[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || v > best)) { best = v; bi = i; }
+        }
+        fold_first_max(best, bi);
+        if (tid == 0) sel[4] = (double)s_i[0];
+    }
     if (tid == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -2198,11 +2231,10 @@ __device__ __forceinline__ double np_lerp(double a, double b, double t) {
     return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
 }
 // One wavefront tests 64 chains (lane = chain); for each outlier among them (rare) the whole wavefront copies the best chain's
-// row into the replica -- every rank does, for all N chains -- and the chain's OWNER also fixes the ln_like cache, the last
-// history row (= current state) and the chain's Welford moments, rebuilt over its rows in history order: the very operations
-// the running update applied, so the chains that were not reset keep moments that equal a full rebuild bit for bit.
+// row into the replica -- every rank does, for all N chains -- and the chain's OWNER also fixes the ln_like cache and the ln-like of the last
+// history row, and lists the chain for outlier_rebuild_kernel (list[0] = count, then local chain indices).
 __global__ __launch_bounds__(WAVE) void outlier_reset_kernel(Layout L, uint32_t N, uint32_t lo, const double* OM, const double* sel, double t1, double t3,
-                                                             double* ll, double* hist, double* llhist, uint32_t rows, double* w_mean, double* w_m2,
+                                                             double* ll, double* llhist, uint32_t rows, const PermKey* llkeys, uint32_t* list,
                                                              unsigned long long* n_resets) {
     const uint32_t lane = threadIdx.x;
     const uint32_t c0 = blockIdx.x * WAVE + lane;
@@ -2220,42 +2252,74 @@ __global__ __launch_bounds__(WAVE) void outlier_reset_kernel(Layout L, uint32_t 
         m &= m - 1ull;
         const uint32_t c = blockIdx.x * WAVE + b;
         double* dst = row_ptr(L, c);
-        const bool mine = (c - lo) < L.n_local;
-        const uint32_t li = c - lo;
-        for (uint32_t j = lane; j < L.ld; j += WAVE) {
-            const double v = src[j];
-            dst[j] = v;
-            if (mine && hist) {
-                const uint64_t stride = (uint64_t)L.n_local * L.ld;
-                double* col = hist + (uint64_t)li * L.ld + j;
-                col[(uint64_t)(rows - 1) * stride] = v;
-                if (w_mean) {                                   // this chain's moments over its rows [0, rows), last row = v
-                    double mean = 0.0, m2 = 0.0;
-                    constexpr int UNR = 8;                      // the loads of 8 rows in flight, then their 8 sequential updates
-                    for (uint32_t g0 = 0; g0 < rows; g0 += UNR) {
-                        double x[UNR];
-#pragma unroll
-                        for (int u = 0; u < UNR; ++u) x[u] = (g0 + u + 1 < rows) ? col[(uint64_t)(g0 + u) * stride] : v;
-#pragma unroll
-                        for (int u = 0; u < UNR; ++u) {
-                            if (g0 + u < rows) {
-                                const double d1 = x[u] - mean;
-                                mean = mean + d1 / (double)(g0 + u + 1);
-                                m2 = m2 + d1 * (x[u] - mean);
-                            }
-                        }
-                    }
-                    w_mean[(uint64_t)li * L.ld + j] = mean;
-                    w_m2[(uint64_t)li * L.ld + j] = m2;
-                }
-            }
-        }
+        for (uint32_t j = lane; j < L.ld; j += WAVE) dst[j] = src[j];
         if (lane == 0) {
-            if (mine) {
+            const uint32_t li = c - lo;
+            if (li < L.n_local) {
                 ll[li] = ll_best;
-                if (llhist) llhist[(uint64_t)(rows - 1) * L.n_local + li] = ll_best;
+                if (llhist) llhist[(uint64_t)(rows - 1) * L.n_local + (llkeys ? perm_inv(li, llkeys[rows - 1]) : li)] = ll_best;
+                if (list) list[1u + atomicAdd(&list[0], 1u)] = li;
             }
             atomicAdd(n_resets, 1ull);
+        }
+    }
+}
+// The owner's history of a chain that was reset: its last row (= the current state) becomes the best chain's row, and the chain's Welford
+// moments are rebuilt over its rows in history order -- the very operations the running update applied, so the chains that were not
+// reset keep moments that equal a full rebuild bit for bit.  One wavefront per listed chain (a kernel of its own: inside the reset kernel the
+// rebuilds of a 64-chain block's outliers ran one after the other, 0.2-0.7 ms per check at cfg5).  The loads of 64 / JW rows x JW columns
+// are in flight together (lane = (row, column)); row g holds the chain at position pi_g^-1(li) when it was appended by position (keys, see
+// outlier_omega_kernel); the updates then run in row order on values handed over by lane.
+__global__ __launch_bounds__(WAVE) void outlier_rebuild_kernel(Layout L, const double* sel, const uint32_t* list, double* hist, uint32_t rows,
+                                                               const PermKey* keys, double* w_mean, double* w_m2) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = list[0];
+    const uint32_t ld = L.ld;
+    const uint32_t JW = ld >= (uint32_t)WAVE ? (uint32_t)WAVE : (ld <= 1u ? 1u : 1u << (32 - __clz((int)(ld - 1u))));
+    const uint32_t RW = (uint32_t)WAVE / JW;
+    const uint32_t jj = lane % JW, rsub = lane / JW;
+    const double* src = row_ptr(L, (uint32_t)sel[4]);
+    const uint64_t stride = (uint64_t)L.n_local * ld;
+    constexpr uint32_t UNR = 4;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t li = list[1u + i];
+        const uint32_t p_last = keys ? perm_inv(li, keys[rows - 1]) : li;
+        for (uint32_t jb = 0; jb < ld; jb += JW) {
+            const uint32_t j = jb + jj;
+            const bool valid = j < ld;
+            const double v = valid ? src[j] : 0.0;
+            if (valid && rsub == 0u) hist[(uint64_t)(rows - 1) * stride + (uint64_t)p_last * ld + j] = v;
+            if (!w_mean) continue;
+            double mean = 0.0, m2 = 0.0;                        // this chain's moments over its rows [0, rows), last row = v
+            for (uint32_t g0 = 0; g0 < rows; g0 += RW * UNR) {
+                double x[UNR];
+#pragma unroll
+                for (uint32_t u = 0; u < UNR; ++u) {
+                    const uint32_t g = g0 + u * RW + rsub;
+                    x[u] = v;
+                    if (valid && g + 1u < rows) {
+                        const uint32_t pg = keys ? perm_inv(li, keys[g]) : li;
+                        x[u] = hist[(uint64_t)g * stride + (uint64_t)pg * ld + j];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UNR; ++u) {
+#pragma unroll 1
+                    for (uint32_t r = 0; r < RW; ++r) {
+                        const uint32_t g = g0 + u * RW + r;
+                        const double xx = __shfl(x[u], (int)(r * JW + jj));
+                        if (g < rows) {
+                            const double d1 = xx - mean;
+                            mean = mean + d1 / (double)(g + 1u);
+                            m2 = m2 + d1 * (xx - mean);
+                        }
+                    }
+                }
+            }
+            if (valid && rsub == 0u) {
+                w_mean[(uint64_t)li * ld + j] = mean;
+                w_m2[(uint64_t)li * ld + j] = m2;
+            }
         }
     }
 }

@@ -387,6 +387,11 @@ struct bpm_sampler {
     // reads them by chain (bpm_get_history, the moment rebuild, the outlier check, a partial first generation of bpm_reduce_moments).
     bool hist_by_pos = false;
     std::vector<int64_t> hist_tag;
+    PermKey* okeys = nullptr;               // outlier check: per history row the shuffle key of its state row [0, cap) and of its ln-like [cap, 2 cap)
+    size_t okeys_cap = 0;                   // (outlier_row_keys)
+    std::vector<PermKey> okeys_host;
+    bool okeys_x = false, okeys_ll = false; // any state row / any ln-like row of the history still lies in position order
+    uint32_t* olist = nullptr;              // outlier check: [0] count, then the local chains that were reset (outlier_rebuild_kernel)
     double* hist_tmp = nullptr;    // one row (n_local * ld) + its ln-likes (n_local): staging of normalize_history
     int64_t hist_rows = 0;     // rows stored (0 when keep_history == 0 and nothing stored)
     int64_t rows_logical = 0;  // len(chain.chain) of the reference: 1 + generations since (re)initialisation
@@ -710,14 +715,15 @@ static int normalize_history(bpm_sampler* s, int64_t r0, int64_t r1) {
     for (int64_t r = r0; r < r1; ++r) {
         const int64_t tag = s->hist_tag[(size_t)r];
         if (tag < 0) continue;
-        const PermKey key = make_perm_key(s->cfg.seed, (uint64_t)(tag >> 1), s->N, (tag & 1) != 0);
+        const PermKey key = make_perm_key(s->cfg.seed, (uint64_t)(tag >> 2), s->N, (tag & 1) != 0);
+        const bool ll_by_chain = (tag & 2) != 0;
         double* row = s->hist + (uint64_t)r * row_d;
         double* llrow = s->llhist + (uint64_t)r * s->n_local;
         hipLaunchKernelGGL(hist_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, key, s->N, s->ld, (const double*)row,
-                           (const double*)llrow, s->hist_tmp, s->hist_tmp + row_d);
+                           ll_by_chain ? (const double*)nullptr : (const double*)llrow, s->hist_tmp, s->hist_tmp + row_d);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(row, s->hist_tmp, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-        HIPCK(hipMemcpyAsync(llrow, s->hist_tmp + row_d, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        if (!ll_by_chain) HIPCK(hipMemcpyAsync(llrow, s->hist_tmp + row_d, (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         s->hist_tag[(size_t)r] = -1;
     }
     return 0;
@@ -859,7 +865,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     }
     if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
+    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->okeys, s->olist, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -1086,8 +1092,11 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     if (want_om) {
         if (!s->om) CKD(dev_alloc(&s->om, (size_t)s->world * 2 * s->n_local));
         CKD(dev_alloc(&s->sel, 8));
-        CKD(dev_alloc(&s->sel_state, sizeof(SelState)));
-        HIPCKD(hipMemsetAsync(s->sel_state, 0, sizeof(SelState), s->stream));
+        // (behind the state: one (value, index) pair per workgroup of a pass for the first maximum)
+        const size_t sel_bytes = sizeof(SelState) + (size_t)sel_blocks(s->N) * (sizeof(double) + sizeof(uint32_t));
+        CKD(dev_alloc(&s->sel_state, sel_bytes));
+        HIPCKD(hipMemsetAsync(s->sel_state, 0, sel_bytes, s->stream));
+        CKD(dev_alloc(&s->olist, (size_t)s->n_local + 1));
     }
     // update records drawn ahead (plan_kernel) for the fused device kernels, while a launch is latency bound.  Measured
     // on cfg2's target (one wavefront per chain): 11.4 vs 11.8 us/generation at N=2048, 15.9 vs 16.4 at 8192, 24.9 vs
@@ -1501,11 +1510,10 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.n_items = cnt[s->rank];
             a.mode = 0u;
         }
-        // (while the outlier check is due every few generations -- DREAM burn-in with outlier_every > 0 -- rows are appended by chain: the check
-        // reads the ln-like history by chain and repairs the last row, and de-permuting every row it has not seen yet cost more than the
-        // coalesced append gains: cfg5 burn-in with the check 104 us per generation instead of 82)
+        // (while the outlier check is due every few generations -- DREAM burn-in with outlier_every > 0 -- the ln-like goes by chain: the check sums
+        // every chain's ln-like history, and reads the state rows of the few chains it resets where they lie: outlier_row_keys)
         const bool outlier_phase = dream && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen;
-        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr && !outlier_phase) ? 1u : 0u;
+        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr) ? (outlier_phase ? 2u : 1u) : 0u;
         { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
         a.lean = s->lean ? 1u : 0u;
         a.algo = (uint32_t)s->cfg.algo;
@@ -1616,8 +1624,9 @@ static int finish_generation(bpm_sampler* s) {
     }
     if (s->cfg.running_moments) CK(push_gen_sums(s, s->rows_logical));      // (the row this generation appended: index rows_logical)
     if (s->cfg.keep_history) {
-        if (s->cur_args[0].hist_by_pos || s->cur_args[1].hist_by_pos)      // appended by position: generation t_abs, its shuffle switch
-            s->hist_tag[(size_t)s->hist_rows] = (s->t_abs << 1) | (s->opts.shuffle != 0 ? 1 : 0);
+        if (s->cur_args[0].hist_by_pos || s->cur_args[1].hist_by_pos)      // appended by position: generation t_abs, ln-like by chain?, shuffle switch
+            s->hist_tag[(size_t)s->hist_rows] = (s->t_abs << 2) | ((s->cur_args[0].hist_by_pos | s->cur_args[1].hist_by_pos) == 2u ? 2 : 0) |
+                                                (s->opts.shuffle != 0 ? 1 : 0);
         s->hist_rows += 1;
     }
     s->rows_logical += 1;
@@ -1714,6 +1723,41 @@ static int push_check_error(bpm_sampler* s) {
 // lies below Q1 - 2 IQR (quartiles over all N chains, np.percentile's interpolation) restart from the best chain's state.
 // Everything stays on the device and on the samplers' streams: omega of the local chains, all-gather of the (omega | ln_like)
 // blocks (RCCL, or device copies in a local group), radix select of the four order statistics + first argmax, reset.
+// The shuffle keys of the history rows for the outlier check's kernels (identity for what lies in chain order): state rows and ln-like rows have
+// a key each (hist_tag).  On the sampler's stream, from a host vector that outlives the copy.
+static int outlier_row_keys(bpm_sampler* s) {
+    s->okeys_x = s->okeys_ll = false;
+    if (!s->hist_by_pos) return 0;
+    const size_t rows = (size_t)s->hist_rows;
+    HIPCK(hipStreamSynchronize(s->stream));      // (the previous check's kernels and copy are done with okeys / okeys_host)
+    if (rows > s->okeys_cap) {
+        if (s->okeys) HIPCK(hipFree(s->okeys));
+        s->okeys = nullptr;
+        s->okeys_cap = std::max<size_t>(rows + rows / 2, 256);
+        HIPCK(hipMalloc(&s->okeys, 2 * s->okeys_cap * sizeof(PermKey)));
+    }
+    PermKey id{};
+    id.n = s->N; id.nbits = perm_nbits(s->N); id.on = 0u;
+    s->okeys_host.assign(2 * s->okeys_cap, id);
+    for (size_t r = 0; r < rows; ++r) {
+        const int64_t tag = r < s->hist_tag.size() ? s->hist_tag[r] : -1;
+        if (tag < 0) continue;
+        const PermKey k = make_perm_key(s->cfg.seed, (uint64_t)(tag >> 2), s->N, (tag & 1) != 0);
+        s->okeys_host[r] = k;
+        s->okeys_x = true;
+        if ((tag & 2) == 0) { s->okeys_host[s->okeys_cap + r] = k; s->okeys_ll = true; }
+    }
+    if (s->okeys_x) HIPCK(hipMemcpyAsync(s->okeys, s->okeys_host.data(), 2 * s->okeys_cap * sizeof(PermKey), hipMemcpyHostToDevice, s->stream));
+    return 0;
+}
+// the eight passes of the radix select (+ first maximum) over s->om -> s->sel
+static void launch_outlier_select(bpm_sampler* s, const SelRanks& R) {
+    const uint32_t nblk = sel_blocks(s->N);
+    for (int pass = 0; pass < 8; ++pass)
+        hipLaunchKernelGGL(outlier_select_pass_kernel, dim3(nblk), dim3(SEL_THREADS), 0, s->stream, s->om, s->n_local, s->N, pass, R,
+                           reinterpret_cast<SelState*>(s->sel_state), s->sel);
+}
+
 static int group_outlier_check(const Group& g) {
     bpm_sampler* s0 = g.h[0];
     const uint32_t N = s0->N;
@@ -1721,11 +1765,11 @@ static int group_outlier_check(const Group& g) {
         bpm_sampler* s = g.h[r];
         s->outlier_due = false;
         if (!s->cfg.keep_history || s->hist_rows != s->rows_logical) return fail("outlier detection needs the chain history");
-        CK(normalize_history(s, 0, s->hist_rows));          // (omega and the repair of the last row go by chain)
+        CK(outlier_row_keys(s));                             // (rows appended by position are read where they lie)
         CK(refresh_ll(s));                                   // (the (omega | ln-like) block carries the chains' current ln-like)
         const uint32_t rows = (uint32_t)s->hist_rows, r0 = rows / 2;
         hipLaunchKernelGGL(outlier_omega_kernel, dim3((s->n_local + 255) / 256), dim3(256), 0, s->stream, s->llhist, s->ll, s->n_local, r0, rows,
-                           s->om + (size_t)s->rank * 2 * s->n_local);
+                           s->okeys_ll ? (const PermKey*)(s->okeys + s->okeys_cap) : (const PermKey*)nullptr, s->om + (size_t)s->rank * 2 * s->n_local);
         HIPCK(hipGetLastError());
     }
     if (s0->push_active) {
@@ -1763,13 +1807,14 @@ static int group_outlier_check(const Group& g) {
     }
     for (int r = 0; r < g.R; ++r) {
         bpm_sampler* s = g.h[r];
-        const uint32_t nblk = (N + SEL_THREADS * SEL_UNR - 1) / (SEL_THREADS * SEL_UNR);
-        for (int pass = 0; pass < 8; ++pass)      // (+ 1 workgroup in pass 0: the first maximum)
-            hipLaunchKernelGGL(outlier_select_pass_kernel, dim3(nblk + (pass == 0 ? 1u : 0u)), dim3(SEL_THREADS), 0, s->stream, s->om,
-                               s->n_local, N, pass, R, reinterpret_cast<SelState*>(s->sel_state), s->sel);
+        launch_outlier_select(s, R);
+        HIPCK(hipMemsetAsync(s->olist, 0, sizeof(uint32_t), s->stream));
         hipLaunchKernelGGL(outlier_reset_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, s->stream, s->L, N, s->lo, s->om, s->sel, tq[0], tq[1],
-                           s->ll, s->hist, s->llhist, (uint32_t)s->hist_rows, s->w_rows == s->rows_logical ? s->w_mean : (double*)nullptr,
-                           s->w_m2, s->counters + 4);
+                           s->ll, s->llhist, (uint32_t)s->hist_rows, s->okeys_ll ? (const PermKey*)(s->okeys + s->okeys_cap) : (const PermKey*)nullptr,
+                           s->olist, s->counters + 4);
+        hipLaunchKernelGGL(outlier_rebuild_kernel, dim3(std::min<uint32_t>(s->n_local, 4096u)), dim3(WAVE), 0, s->stream, s->L, (const double*)s->sel,
+                           (const uint32_t*)s->olist, s->hist, (uint32_t)s->hist_rows, s->okeys_x ? (const PermKey*)s->okeys : (const PermKey*)nullptr,
+                           s->w_rows == s->rows_logical ? s->w_mean : (double*)nullptr, s->w_m2);
         HIPCK(hipGetLastError());
         if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
     }
@@ -2947,10 +2992,7 @@ extern "C" int bpm_debug_outlier_select(bpm_handle_t s, const double* omega, dou
         R.k[2 * i + 1] = std::min(lo + 1u, N - 1u);
         tq[i] = pos - (double)lo;
     }
-    const uint32_t nblk = (N + SEL_THREADS * SEL_UNR - 1) / (SEL_THREADS * SEL_UNR);
-    for (int pass = 0; pass < 8; ++pass)
-        hipLaunchKernelGGL(outlier_select_pass_kernel, dim3(nblk + (pass == 0 ? 1u : 0u)), dim3(SEL_THREADS), 0, s->stream, s->om, s->n_local, N, pass, R,
-                           reinterpret_cast<SelState*>(s->sel_state), s->sel);
+    launch_outlier_select(s, R);
     HIPCK(hipGetLastError());
     double h[5];
     HIPCK(hipMemcpyAsync(h, s->sel, sizeof(h), hipMemcpyDeviceToHost, s->stream));
