@@ -261,9 +261,9 @@ def other_configs(device, budget_s=6.0):
         ("cfg5 whole on one GPU: DREAM mixture d=8 N=262144 steady", L.ALGO_DREAM, mix8, 262144, 200, 592.0,
          "phase_fused_kernel<1,2,4,2,3,2> (4 lanes per chain)", dict(burnin_gen=0)),
         ("cfg2 burn-in: DREAM gauss d=100 N=8192, CR adaptation on", L.ALGO_DREAM, gauss, 8192, 300, 10416.0,
-         "phase_fused_kernel<1,1,64,2,3,3> + cr_partial_kernel + cr_final_kernel", dict(burnin_gen=10 ** 6, n_cr_gen=5)),
+         "phase_fused_kernel<1,1,64,2,3,3> (level 1 of the CR reduction inside) + cr_final_kernel", dict(burnin_gen=10 ** 6, n_cr_gen=5)),
         ("cfg5 burn-in: DREAM mixture d=8 N=262144, CR adaptation + outlier check every 50", L.ALGO_DREAM, mix8, 262144, 100,
-         848.0, "phase_fused_kernel<1,2,4,2,3,4> + cr_partial_kernel (ticket) + outlier kernels",
+         848.0, "phase_fused_kernel<1,2,4,2,3,4> (level 1 of the CR reduction inside) + cr_mid_kernel + cr_final_kernel + outlier kernels",
          dict(burnin_gen=10 ** 6, n_cr_gen=5, outlier_every=50)),
     ]
     out = []

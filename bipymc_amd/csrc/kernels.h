@@ -73,6 +73,8 @@ constexpr bool hot_is_adapt(int hot) { return hot == 3 || hot == 4; }
 // (one wavefront per chain: only with 2 coordinates per lane, d <= 128 -- a 1024-thread workgroup caps the kernel at 128 VGPRs, and the burn-in kernels
 // of the wider register-resident shapes need more: those shapes take level 1 from the slots, like every other path)
 constexpr bool crp_shape(int lpc, int dpl) { return lpc < WAVE || dpl == 2; }
+// (several chains per wavefront keep their 256-thread workgroups in burn-in too: with 1024 threads -- 256 chains per level-1 chunk, no cr_mid_kernel pass
+// at cfg5 -- the register budget allows one workgroup per CU: cfg5's share, 64 workgroups, 16.8 -> 28.2 us per generation, cfg5 70.0 -> 71.5)
 constexpr int block_for_hot(int lpc, int hot, int dpl) { return (lpc == WAVE && dpl == 2 && hot_is_adapt(hot)) ? 1024 : block_for(lpc); }
 // chains (positions) per level-1 partial sum of the CR statistics: a function of the kernel SHAPE alone (every rank, every launch path agrees)
 constexpr int cr_g1(int lpc) { return lpc == WAVE ? 16 : WAVE / lpc; }

@@ -300,6 +300,58 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
+def test_outlier_check_reads_position_ordered_history_where_it_lies():
+    """DREAM burn-in with the outlier check on a sampler that appends its history in shuffle order (fewer than 64 lanes per chain, one GPU): the
+    state rows stay in position order and the check's kernels find a chain's rows through the rows' shuffle keys (outlier_row_keys), the ln-like rows
+    are appended by chain while the check is due.  Against the same run with every row appended by chain (test path histchain): state, whole history,
+    ln-like history, CR statistics, reset and accept counts equal bit for bit -- with chains parked far out (resets happen, the moment rebuild of a
+    reset chain walks position-ordered rows), a partial history read in the middle (rows put back into chain order: mixed rows afterwards), the run
+    going on past burn-in (rows appended by position with their ln-like by position again), d = 8 (4 lanes per chain) and d = 2 (one lane per chain)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+from bipymc_amd.utils import mixture_nd
+out = []
+for d, N in ((8, 4099), (2, 3001)):
+    m = mixture_nd.BimodeGauss_ND(d)
+    tid, tp, dd = m._bpm_target_spec()
+    np.random.seed(3)
+    x0 = m.rvs(N)
+    x0[::97] = 25.0                      # parked in the far tail
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=dd, target_id=tid, target_params=tp, seed=9, burnin_gen=40, n_cr_gen=3, outlier_every=7)
+    e.set_state(x0)
+    e.begin_run()
+    e.step(20)
+    mid = e.get_history(0, 10)           # rows 0..9 back into chain order; the later rows stay as appended
+    e.step(33)                           # checks at 21, 28, 35; burn-in ends at 40
+    st = e.stats()
+    assert st["n_outlier_resets"] >= N // 97, st["n_outlier_resets"]
+    out += [mid, e.get_state(), e.get_history(), e.get_loglike_history(), e.get_loglike(), np.asarray(st["p_cr"]), np.asarray(st["delta_m"]),
+            np.array([st["n_outlier_resets"], st["local_n_accepted"], st["local_n_rejected"]], dtype=float)]
+    e.close()
+np.save(sys.argv[1], np.concatenate([np.asarray(o, dtype=float).reshape(-1) for o in out]))
+'''
+    res = []
+    for paths in ("", "histchain", "nohot"):
+        env = dict(os.environ)
+        for k in ("BPM_TEST_PATHS", "BPM_DIRECT_QUEUE", "BPM_QUEUE_INFLIGHT"):
+            env.pop(k, None)
+        if paths:
+            env["BPM_TEST_PATHS"] = paths
+            env["BPM_LIB_PATH"] = _test_lib_path()
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npy")
+            subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
+            res.append(np.load(f))
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)
+
+
 @pytest.mark.parametrize("case,exchange", [("dream_gauss400", "replay"), ("dream_gauss400", "rows"), ("dream_gauss400", "dense"), ("dream_gauss900", "dense"),
                                            ("dream_gauss2500", "dense")])
 def test_multi_rank_equals_single_rank_with_wide_rows(case, exchange):
