@@ -1610,6 +1610,9 @@ __global__ __launch_bounds__(WAVE) void cr_mid_kernel(const double* part1, uint3
         }
     }
 }
+// (Level 2 and the final fold in ONE launch -- the last wavefront of cr_mid_kernel's grid to finish, by an agent-scope ticket, folding the level-2 sums -- was
+// built, bit-identical, and measured SLOWER than the two launches: cfg5 burn-in 71.4 vs 69.5 us per generation, its share 16.8 vs 16.8.  The third in-launch
+// hand-over of this kind with that sign: a ticket's round trip plus the last wavefront's dependent loads cost more than a small dependent dispatch.)
 // totals `tot` + the partial sums of one generation -> cr_state (one wavefront holding ROUNDS partials per lane; tot may be cr_state itself)
 template <int ROUNDS>
 __global__ __launch_bounds__(WAVE) void cr_final_kernel(const double* tot, const double* part, uint32_t nb, uint32_t n_cr, double* cr_state) {

@@ -1609,18 +1609,20 @@ static int finish_generation(bpm_sampler* s) {
             src = dst; cnt = nn; flip ^= 1;
         }
         // (ROUNDS = partials per lane, the next power of two: a partial beyond cnt reads as +0.0, the sums do not depend on the choice)
-        typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
-        const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
-        const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
-        if (g_dq) {
-            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
-            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
-            if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
-        } else {
-            hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
-            HIPCK(hipGetLastError());
+        if (cnt > 0) {
+            typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
+            const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
+            const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
+            if (g_dq) {
+                struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
+                const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
+                if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
+            } else {
+                hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
+                HIPCK(hipGetLastError());
+            }
+            s->w_rows += 1;
         }
-        s->w_rows += 1;
     }
     if (s->cfg.running_moments) CK(push_gen_sums(s, s->rows_logical));      // (the row this generation appended: index rows_logical)
     if (s->cfg.keep_history) {

@@ -271,6 +271,7 @@ from bipymc_amd.utils import d100_gauss, banana_rv, mixture_nd
 out = []
 for spec, algo, N, kw in ((d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 96, dict(burnin_gen=6, n_cr_gen=2)),
                           (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 101, dict(burnin_gen=6, n_cr_gen=2, del_pairs=2)),
+                          (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 9001, dict(burnin_gen=9, n_cr_gen=2)),   # 564 level-1 chunks
                           (banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 77, dict(p_snooker=0.2))):
     tid, tp, d = spec
     e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, **kw)
