@@ -681,6 +681,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         if (LPC == WAVE) wk.acc_prev = a.acc_count[c - a.lo];
     }
     if (DREAM && a.adapt_on) {                 // dream.py:128: requested here, used after the proposal and after the accept test
+        // (as streaming loads -- the moments are read once per launch -- burn-in got slower: cfg5 68.6 -> 75.4 us per generation, cfg2 20.7 -> 21.3)
         load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_mean);
         load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_m2);
     }
@@ -1144,7 +1145,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     }
     const uint32_t hi = a.hist_by_pos ? wk.pos_own : li;
     if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(hi * ld), q, ld, nv);
-    if (a.llhist_row && q == 0) a.llhist_row[a.hist_by_pos == 1u ? wk.pos_own : li] = new_ll;
+    // (a streaming store like the row's: nobody reads the ln-like history inside the generation loop.  As a plain store the by-chain form cost cfg5's burn-in
+    // 3.4 us per generation, this one 1.0; the by-position form gains too: cfg5 45.5 -> 44.5)
+    if (a.llhist_row && q == 0) __builtin_nontemporal_store(new_ll, &a.llhist_row[a.hist_by_pos == 1u ? wk.pos_own : li]);
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)

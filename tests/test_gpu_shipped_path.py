@@ -106,6 +106,16 @@ def test_cr_statistics_summed_inside_the_update_kernels_equal_the_oracle(N, d, t
     _run_both(R.ALGO_DREAM, N, d, tid, params, 31, X0, 7, dict(del_pairs=3, n_cr=3, burnin_gen=100, n_cr_gen=1), hist_rows=(2, 7))
 
 
+@pytest.mark.parametrize("N,d", [(300, 20), (500, 8)])
+def test_general_kernel_on_the_own_queue_equals_the_oracle(N, d):
+    """the GENERAL instantiation of the update kernel (four CR values: no specialised one) of the shapes with 16 / 4 lanes per chain declares a
+    private segment of 36 bytes without executing a scratch instruction (tests/test_abi.py reads the disassembly); the library's own queue dispatches it with
+    that size in the packet.  It has to run there -- own queue, no trace -- and equal the oracle like every other kernel."""
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
+    X0 = np.random.RandomState(8).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 17, X0, 9, dict(del_pairs=2, n_cr=4, burnin_gen=5, n_cr_gen=2), hist_rows=(3, 9))
+
+
 @pytest.mark.parametrize("algo,N,d,shuffle,flip", [("demc", 77, 2, True, 0.5), ("demc", 10, 1, True, 0.3), ("demc", 129, 3, False, 1.0),
                                                     ("dream", 101, 8, True, 0.5), ("dream", 64, 5, False, 0.0), ("dream", 33, 17, True, 0.7),
                                                     ("dream", 12, 32, True, 0.5)])

@@ -1,4 +1,4 @@
-"""Where cfg5's burn-in with the outlier check spends its time: generations with the check never due, due every 50, every 10; one GPU."""
+"""(BPM_LIB_PATH selects another build of the library.)  Where cfg5's burn-in with the outlier check spends its time: generations with the check never due, due every 50, every 10; one GPU."""
 import os
 import sys
 import time
