@@ -383,8 +383,9 @@ struct bpm_sampler {
     // Position-ordered history append (single GPU, fewer than 64 lanes per chain): the update kernels write a generation's history row in
     // that generation's shuffle order -- consecutive work items, consecutive rows: 1.0 us per generation at cfg3, 5.5 us at cfg5 against
     // the scattered append by chain index (profiles/r03_small_d_hops_and_position_order.txt) -- and hist_tag[row] remembers how to read it:
-    // -1 chain order, else (generation << 1) | shuffle.  normalize_history puts rows back into chain order, in place, before anything
-    // reads them by chain (bpm_get_history, the moment rebuild, the outlier check, a partial first generation of bpm_reduce_moments).
+    // -1 chain order, else (generation << 2) | (2: the row's ln-like went by chain all the same) | shuffle.  normalize_history puts rows back into chain
+    // order, in place, before anything reads them by chain (bpm_get_history, the moment rebuild, a partial first generation of bpm_reduce_moments);
+    // the outlier check reads them where they lie (outlier_row_keys).
     bool hist_by_pos = false;
     std::vector<int64_t> hist_tag;
     PermKey* okeys = nullptr;               // outlier check: per history row the shuffle key of its state row [0, cap) and of its ln-like [cap, 2 cap)
@@ -1609,20 +1610,18 @@ static int finish_generation(bpm_sampler* s) {
             src = dst; cnt = nn; flip ^= 1;
         }
         // (ROUNDS = partials per lane, the next power of two: a partial beyond cnt reads as +0.0, the sums do not depend on the choice)
-        if (cnt > 0) {
-            typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
-            const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
-            const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
-            if (g_dq) {
-                struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
-                const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
-                if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
-            } else {
-                hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
-                HIPCK(hipGetLastError());
-            }
-            s->w_rows += 1;
+        typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
+        const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
+        const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
+        if (g_dq) {
+            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
+            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
+            if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
+        } else {
+            hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
+            HIPCK(hipGetLastError());
         }
+        s->w_rows += 1;
     }
     if (s->cfg.running_moments) CK(push_gen_sums(s, s->rows_logical));      // (the row this generation appended: index rows_logical)
     if (s->cfg.keep_history) {
@@ -1721,10 +1720,6 @@ static int push_check_error(bpm_sampler* s) {
     return 0;
 }
 
-// DREAM outlier-chain reset (Vrugt et al. 2009; extension): chains whose mean ln_like over the last half of their history
-// lies below Q1 - 2 IQR (quartiles over all N chains, np.percentile's interpolation) restart from the best chain's state.
-// Everything stays on the device and on the samplers' streams: omega of the local chains, all-gather of the (omega | ln_like)
-// blocks (RCCL, or device copies in a local group), radix select of the four order statistics + first argmax, reset.
 // The shuffle keys of the history rows for the outlier check's kernels (identity for what lies in chain order): state rows and ln-like rows have
 // a key each (hist_tag).  On the sampler's stream, from a host vector that outlives the copy.
 static int outlier_row_keys(bpm_sampler* s) {
@@ -1760,6 +1755,10 @@ static void launch_outlier_select(bpm_sampler* s, const SelRanks& R) {
                            reinterpret_cast<SelState*>(s->sel_state), s->sel);
 }
 
+// DREAM outlier-chain reset (Vrugt et al. 2009; extension): chains whose mean ln_like over the last half of their history
+// lies below Q1 - 2 IQR (quartiles over all N chains, np.percentile's interpolation) restart from the best chain's state.
+// Everything stays on the device and on the samplers' streams: omega of the local chains, all-gather of the (omega | ln_like)
+// blocks (RCCL, or device copies in a local group), radix select of the four order statistics + first argmax, reset.
 static int group_outlier_check(const Group& g) {
     bpm_sampler* s0 = g.h[0];
     const uint32_t N = s0->N;
