@@ -1147,7 +1147,12 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
     if (a.hist_row) store_row_stream<LPC, DPL>(a.hist_row + (uint32_t)(hi * ld), q, ld, nv);
     // (a streaming store like the row's: nobody reads the ln-like history inside the generation loop.  As a plain store the by-chain form cost cfg5's burn-in
     // 3.4 us per generation, this one 1.0; the by-position form gains too: cfg5 45.5 -> 44.5)
-    if (a.llhist_row && q == 0) __builtin_nontemporal_store(new_ll, &a.llhist_row[a.hist_by_pos == 1u ? wk.pos_own : li]);
+    // (one wavefront per chain -- a single 8-byte store per wavefront -- keeps the ordinary store: nothing to gain, and under a kernel trace the streaming
+    // form showed up as +0.25 us of kernel duration at cfg2)
+    if (a.llhist_row && q == 0) {
+        double* dst_ll = &a.llhist_row[a.hist_by_pos == 1u ? wk.pos_own : li];
+        if (LPC < WAVE) __builtin_nontemporal_store(new_ll, dst_ll); else *dst_ll = new_ll;
+    }
     if (ALGO == ALGO_DREAM) {
         if (a.adapt_on) {
             // running moments of this chain's own history (replaces np.std(chain.chain), dream.py:128)

@@ -58,7 +58,7 @@ out = [
     entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", T + "_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
           traffic(T + "_pmc_cfg3.txt"), "latency bound: launch floor + dependent Infinity-Cache round trips; a 16-byte row is an eighth of a 128-byte line"),
     entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5.csv", "<1, 2, 4, 2, 3, 2>", 592, 131072,
-          traffic(T + "_pmc_cfg5.txt"), "bandwidth bound on 128-byte line traffic: a 64-byte row is half a line, 7 of 8 rows per update are random"),
+          traffic(T + "_pmc_cfg5.txt"), "bound by the rate of random 64-byte rows (5.1e10 rows/s out of a 16.8 MB table: the access pattern alone takes 18.0 us per launch, profiles/r04_row_gather_floor.txt); 7 of 8 rows per update are random"),
     entry("cfg5 one GPU's share N=32768 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5_local.csv", "<1, 2, 4, 2, 3, 2>", 592, 16384, None,
           "latency bound (1024 wavefronts)"),
     entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", T + "_kernel_stats_cfg5_burnin.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
