@@ -163,8 +163,8 @@ struct PhaseArgs {
     double* ll;            // [n_local] cached ln_like of the local chains (samplers.py:330 re-evaluates it)
     double* hist_row;      // [n_local * ld] history row being appended (chain.py:51-54) or nullptr
     double* llhist_row;    // [n_local] or nullptr
-    double* w_mean;        // [n_local * ld] Welford mean of each chain's own history (dream.py:128)
-    double* w_m2;          // [n_local * ld]
+    double* w_mean;        // Welford moments of each chain's own history (dream.py:128), ONE record per chain: [mean (ld) | m2 (ld)], chain li at w_mean + li * 2 ld;
+    double* w_m2;          // w_m2 = w_mean + ld (same stride).  (Two arrays until round 4: two scattered reads and writes per burn-in update where one does.)
     const double* tparams; // target parameter block
     const double* cr_state;  // p_cr[MAX_CR] | delta_m[MAX_CR] | n_cr_updates[MAX_CR]
     unsigned long long* counters;  // [2] = NaN Metropolis ratios (rare; the only atomic)
@@ -682,8 +682,8 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     }
     if (DREAM && a.adapt_on) {                 // dream.py:128: requested here, used after the proposal and after the accept test
         // (as streaming loads -- the moments are read once per launch -- burn-in got slower: cfg5 68.6 -> 75.4 us per generation, cfg2 20.7 -> 21.3)
-        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_mean);
-        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * ld), q, ld, wk.w_m2);
+        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * 2u * ld), q, ld, wk.w_mean);
+        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * 2u * ld), q, ld, wk.w_m2);
     }
     double pcr[MAX_CR];                        // p_cr (uniform pointer: one scalar load of the whole block)
     if (DREAM) {
@@ -1167,11 +1167,11 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                 m2[s] = m2[s] + d1 * (nv[s] - mean[s]);
             }
             if (a.wt) {      // release-less packets: the next generation's kernels read these rows
-                store_row_wt16<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
-                store_row_wt16<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+                store_row_wt16<LPC, DPL>(a.w_mean + (uint32_t)(li * 2u * ld), q, ld, mean);
+                store_row_wt16<LPC, DPL>(a.w_m2 + (uint32_t)(li * 2u * ld), q, ld, m2);
             } else {
-                store_row_stream<LPC, DPL>(a.w_mean + (uint32_t)(li * ld), q, ld, mean);
-                store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * ld), q, ld, m2);
+                store_row_stream<LPC, DPL>(a.w_mean + (uint32_t)(li * 2u * ld), q, ld, mean);
+                store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * 2u * ld), q, ld, m2);
             }
         }
         if (q == 0) {
@@ -1527,8 +1527,8 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
     wk.ll_cur = a.ll[c - a.lo];
     wk.acc_prev = a.acc_count[c - a.lo];
     if (ALGO == ALGO_DREAM && a.adapt_on) {
-        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * a.L.ld), q, a.L.ld, wk.w_mean);
-        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * a.L.ld), q, a.L.ld, wk.w_m2);
+        load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * 2u * a.L.ld), q, a.L.ld, wk.w_mean);
+        load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * 2u * a.L.ld), q, a.L.ld, wk.w_m2);
     }
     const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
@@ -2330,8 +2330,8 @@ __global__ __launch_bounds__(WAVE) void outlier_rebuild_kernel(Layout L, const d
                 }
             }
             if (valid && rsub == 0u) {
-                w_mean[(uint64_t)li * ld + j] = mean;
-                w_m2[(uint64_t)li * ld + j] = m2;
+                w_mean[(uint64_t)li * 2u * ld + j] = mean;
+                w_m2[(uint64_t)li * 2u * ld + j] = m2;
             }
         }
     }
@@ -2339,10 +2339,11 @@ __global__ __launch_bounds__(WAVE) void outlier_rebuild_kernel(Layout L, const d
 
 // Welford moments of every local chain's history rows [0, rows) recomputed from the history
 // buffer (only needed when adaptation resumes after generations run without it).
-__global__ void welford_rebuild_kernel(const double* hist, uint64_t row_stride, uint64_t n_elem, uint32_t rows,
+__global__ void welford_rebuild_kernel(const double* hist, uint64_t row_stride, uint64_t n_elem, uint32_t rows, uint32_t ld,
                                        double* w_mean, double* w_m2) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_elem) return;
+    const uint64_t we = (e / ld) * 2u * ld + e % ld;      // (one record per chain: [mean | m2])
     double mean = 0.0, m2 = 0.0;
     for (uint32_t g = 0; g < rows; ++g) {
         const double v = hist[(uint64_t)g * row_stride + e];
@@ -2350,8 +2351,8 @@ __global__ void welford_rebuild_kernel(const double* hist, uint64_t row_stride, 
         mean = mean + d1 / (double)(g + 1);
         m2 = m2 + d1 * (v - mean);
     }
-    w_mean[e] = mean;
-    w_m2[e] = m2;
+    w_mean[we] = mean;
+    w_m2[we] = m2;
 }
 
 // chain.py:25-27: state0 = theta_0 + N(0, diag(varepsilon)) for the local block of the exchange buffer

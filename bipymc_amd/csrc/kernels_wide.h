@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
     WideTarget<TARGET> T;
     double dl = 0.0, n2p = 0.0;
     const bool cr_stat = DREAM && a.adapt_on && a.cr_gate;
-    const double* m2row = a.w_m2 + (uint32_t)(li * U.ld);
+    const double* m2row = a.w_m2 + (uint32_t)(li * 2u * U.ld);
     double* hrow = (FUSED && a.hist_row) ? a.hist_row + (uint32_t)(li * U.ld) : nullptr;
     double* prow = FUSED ? nullptr : a.prop_buf + (uint64_t)w * U.ld;
     const double* zrow_b = U.snk ? row_ptr(a.L, (uint32_t)__builtin_amdgcn_readlane((int)mine, 2)) : xrow;
@@ -399,8 +399,8 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
     if (accepted || welford || a.x_next) {
         double* srow = row_ptr(a.L, c);
         double* nrow = a.x_next ? a.x_next + (uint32_t)(li * U.ld) : nullptr;
-        double* wm = a.w_mean + (uint32_t)(li * U.ld);
-        double* w2 = a.w_m2 + (uint32_t)(li * U.ld);
+        double* wm = a.w_mean + (uint32_t)(li * 2u * U.ld);
+        double* w2 = a.w_m2 + (uint32_t)(li * 2u * U.ld);
         const uint32_t row_off = (uint32_t)(srow - a.L.G);
         const double cntp = (double)(a.hist_len + 1);
 #pragma unroll 1
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_commit_kernel(const
     const double* prow = a.prop_buf + (uint64_t)w * ld;
     double* hrow = a.hist_row ? a.hist_row + (uint32_t)(li * ld) : nullptr;
     double* nrow = a.x_next ? a.x_next + (uint32_t)(li * ld) : nullptr;
-    double* wm = a.w_mean + (uint32_t)(li * ld);
-    double* w2 = a.w_m2 + (uint32_t)(li * ld);
+    double* wm = a.w_mean + (uint32_t)(li * 2u * ld);
+    double* w2 = a.w_m2 + (uint32_t)(li * 2u * ld);
     const double cntp = (double)(a.hist_len + 1);
 #pragma unroll 1
     for (uint32_t k = 0; k < n_chunks; ++k) {

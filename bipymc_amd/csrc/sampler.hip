@@ -787,8 +787,10 @@ static int reset_history(bpm_sampler* s) {
     if (!s->hist_tag.empty()) s->hist_tag[0] = -1;
     s->hist_rows = 1;
     // Welford over the single row: mean = row, m2 = 0
-    HIPCK(hipMemcpyAsync(s->w_mean, s->hist, row_d * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIPCK(hipMemsetAsync(s->w_m2, 0, row_d * sizeof(double), s->stream));
+    // (one record per chain: [mean (ld) | m2 (ld)])
+    HIPCK(hipMemsetAsync(s->w_mean, 0, 2 * row_d * sizeof(double), s->stream));
+    HIPCK(hipMemcpy2DAsync(s->w_mean, (size_t)2 * s->ld * sizeof(double), s->hist, (size_t)s->ld * sizeof(double), (size_t)s->ld * sizeof(double), s->n_local,
+                           hipMemcpyDeviceToDevice, s->stream));
     s->w_rows = 1;
     if (s->cfg.running_moments) {      // shift := chain 0's state; sums of row 0
         HIPCK(hipMemcpyAsync(s->gs_shift, s->G, s->ld * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -866,7 +868,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     }
     if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->okeys, s->olist, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->w_m2, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
+    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->okeys, s->olist, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -1050,8 +1052,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     }
     s->L.G = s->G;
     CKD(dev_alloc_state(&s->ll, s->n_local, s->coherent));
-    CKD(dev_alloc_state(&s->w_mean, row_d, s->coherent));
-    CKD(dev_alloc_state(&s->w_m2, row_d, s->coherent));
+    CKD(dev_alloc_state(&s->w_mean, 2 * row_d, s->coherent));      // one record per chain: [mean (ld) | m2 (ld)]
+    s->w_m2 = s->w_mean + s->ld;
     CKD(dev_alloc(&s->tparams, (size_t)np + 2));       // (+2: the wide-row kernels read the Gaussian's 1/sigma as pairs)
     HIPCKD(hipMemsetAsync(s->tparams, 0, ((size_t)np + 2) * sizeof(double), s->stream));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1430,7 +1432,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         CK(sec.rc);
         CK(normalize_history(s, 0, s->hist_rows));
         hipLaunchKernelGGL(welford_rebuild_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, s->stream,
-                           s->hist, n_elem, n_elem, (uint32_t)s->hist_rows, s->w_mean, s->w_m2);
+                           s->hist, n_elem, n_elem, (uint32_t)s->hist_rows, s->ld, s->w_mean, s->w_m2);
         HIPCK(hipGetLastError());
         CK(sec.end());
         s->w_rows = s->rows_logical;
