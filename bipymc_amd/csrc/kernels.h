@@ -1174,7 +1174,11 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
                 store_row_stream<LPC, DPL>(a.w_m2 + (uint32_t)(li * 2u * ld), q, ld, m2);
             }
         }
-        if (q == 0) {
+        // The chain's CR slots (delta | CR index) are what the reduction kernels read (cr_level1_kernel) -- only while CR adaptation runs, and not when the
+        // update kernels sum level 1 themselves (cr_part1).  Every generation of an adaptation phase rewrites every chain's slots before its reduction
+        // reads them, so nothing has to be written in between: until round 4 every DREAM update stored "no statistic" here -- two scattered 8-byte
+        // write-through stores per update in the steady state (cfg5: 44.5 -> ... us per generation without them).
+        if (q == 0 && a.adapt_on && a.cr_part1 == nullptr) {
             const bool gated = a.adapt_on && a.cr_gate;
             if (a.wt) {
                 __hip_atomic_store(delta_ptr(a.L, c), gated ? wk.delta : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

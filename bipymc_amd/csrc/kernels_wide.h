@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
         }
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
         if (a.llhist_row) a.llhist_row[li] = new_ll;
-        if (DREAM) {
+        if (DREAM && a.adapt_on) {      // (the CR slots are read by the reduction of an adapting generation only: kernels.h finish_update)
             if (a.wt) {
                 __hip_atomic_store(delta_ptr(a.L, c), cr_stat ? delta : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(cridx_ptr(a.L, c), cr_stat ? (double)cr_idx : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
