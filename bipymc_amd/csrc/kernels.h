@@ -704,6 +704,13 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             gtab[u] = gi <= dim ? gl : 0.0;
         }
     }
+    // ... and with several chains per wavefront (at most 32 coordinates): lane l holds entry l, the lookup by d' is a lane read through the LDS crossbar
+    // (ds_bpermute) instead of a dependent load behind the mask count -- the first touch of the table on a CU is an L2 round trip on the critical path
+    double gt_lane = 0.0;
+    if (DREAM && LPC * DPL < WAVE) {
+        const uint32_t wl = (uint32_t)threadIdx.x & (uint32_t)(WAVE - 1);
+        gt_lane = a.gamma_tab[wl <= dim ? wl : dim];
+    }
     const bool snk_possible = !DREAM && a.p_snooker > 0.0 && a.M >= 3;
     const uint32_t npart = 2 * P + (snk_possible ? 3u : 0u);
     // RL: one wavefront per chain and a compile-time pair count: the partner ids are resolved by lanes in
@@ -920,6 +927,8 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
 #pragma unroll
             for (int u = 1; u < DPL; ++u) gsel = ((cnt >> 6) == u) ? gtab[u] : gsel;
             gamma = readlane_f64(gsel, cnt & 63);
+        } else if (LPC * DPL < WAVE) {
+            gamma = __shfl(gt_lane, cnt);
         } else {
             gamma = a.gamma_tab[cnt];
         }
