@@ -1828,7 +1828,10 @@ __global__ void perm_table_kernel(const PermKeys keys, uint32_t n_gens, uint32_t
     if (e >= (uint64_t)n_gens * N) return;
     const uint32_t g = (uint32_t)(e / N), k = (uint32_t)(e % N);
     tab[e] = perm_fwd(k, keys.k[g]);
-    inv[e] = perm_inv(k, keys.k[g]);      // (walking the network backwards costs less than the scattered store inv[g N + c] = k did: 7.5 -> 4.9 us at cfg2)
+    // (walking the network backwards costs less than the scattered store inv[g N + c] = k did: 7.5 -> 4.9 us at cfg2; inv == nullptr: nobody reads the
+    // inverse -- it serves launches with a work item per LOCAL chain, the ranks of a world -- and half of this kernel's time is saved: 70 -> 35 us per
+    // window of 64 generations at cfg5)
+    if (inv) inv[e] = perm_inv(k, keys.k[g]);
 }
 
 // A history row appended by POSITION (PhaseArgs::hist_by_pos) back into chain order: dst row c = src row k with c = pi_t(k), the shuffle of

@@ -1322,10 +1322,14 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     for (int g = 0; g < K; ++g) keys.k[g] = make_perm_key(s->cfg.seed, (uint64_t)(t0 + g), s->N, shuffle != 0);
     for (int g = K; g < PERM_CHUNK; ++g) keys.k[g] = keys.k[0];
     const uint64_t n = (uint64_t)K * s->N;
+    // the inverse tables (chain id -> position) serve launches with one work item per LOCAL chain: the ranks of a world (and the test path that takes
+    // their kernel path on one GPU); a single-GPU sampler's buffer stays allocated (PhaseArgs::inv_tab is never null with tables) but is not filled
+    static const bool force_mode1 = test_path("mode1");
+    uint32_t* const inv_out = (s->world > 1 || force_mode1) ? B.inv : nullptr;
     if (g_dq && !B.sidx) {
         // direct mode, records by position: the same two kernels as packets on the library's queue, in order with
         // the update kernels around them
-        struct { PermKeys keys; uint32_t n_gens, N; uint32_t* tab; uint32_t* inv; } pa{keys, (uint32_t)K, s->N, B.perm, B.inv};
+        struct { PermKeys keys; uint32_t n_gens, N; uint32_t* tab; uint32_t* inv; } pa{keys, (uint32_t)K, s->N, B.perm, inv_out};
         static_assert(offsetof(decltype(pa), tab) == sizeof(PermKeys) + 8, "kernarg layout of perm_table_kernel");
         const bpm::DqKernel* kp = g_dq->kernel(reinterpret_cast<const void*>(perm_table_kernel));
         if (!kp || g_dq->launch(*kp, (uint32_t)((n + 255) / 256), 1, 256, &pa, sizeof(pa), bpm::DirectQueue::FENCED) != 0) return fail("direct AQL queue: perm_table_kernel: " + g_dq->why());
@@ -1349,7 +1353,7 @@ static int build_window(bpm_sampler* s, int b, int64_t W, int shuffle) {
     // before, stream drained after: once per 64 generations.
     StreamSection sec(s);
     CK(sec.rc);
-    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, B.inv);
+    hipLaunchKernelGGL(perm_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, bs, keys, (uint32_t)K, s->N, B.perm, inv_out);
     HIPCK(hipGetLastError());
     if (B.plan) {
         // (push exchange: nobody replays another rank's updates -- only this rank's own run of the owner-sorted records is built;
