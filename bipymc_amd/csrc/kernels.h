@@ -988,8 +988,22 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
         const bool ids_in_regs = REGS && (!snk_possible || SNK_DIRECT);
         const uint32_t ca = ids_in_regs ? part.get(0) : part.lds[0];
         const uint32_t cb = ids_in_regs ? part.get(1) : part.lds[1];
+        // ALL row requests of the update leave together.  With one lane per chain the partner ids come from table lookups (vector loads, which return
+        // in order) and the snooker lookups sit in a divergent branch: left to itself the compiler requested row A as soon as id A was in, then waited
+        // for id B with a count that also covers row A (the conservative merge over the branch), and fetched the three snooker rows only after the pair
+        // proposal was built -- three memory round trips in a row where one does.  The empty asm makes every id an input at ONE point.
+        const bool do_snk = snk_possible && u_sel < a.p_snooker;
+        if (LPC == 1) asm volatile("" ::"v"(ca), "v"(cb), "v"(snk_id[0]), "v"(snk_id[1]), "v"(snk_id[2]));
         load_row<LPC, DPL>(row_ptr(a.L, ca), q, ld, ra);
         load_row<LPC, DPL>(row_ptr(a.L, cb), q, ld, rb);
+        double rz[DPL], r1[DPL], r2[DPL];
+#pragma unroll
+        for (int s = 0; s < DPL; ++s) { rz[s] = 0.0; r1[s] = 0.0; r2[s] = 0.0; }
+        if (do_snk) {
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[0] : part.lds[2]), q, ld, rz);
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[1] : part.lds[3]), q, ld, r1);
+            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[2] : part.lds[4]), q, ld, r2);
+        }
         early(wk);
 #pragma unroll
         for (int s = 0; s < DPL; ++s) {
@@ -998,12 +1012,8 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             pv = pv + eps_n[s];
             wk.p[s] = pv;
         }
-        if (snk_possible && u_sel < a.p_snooker) {
+        if (do_snk) {
             // snooker update (ter Braak & Vrugt 2008) -- extension, absent from the reference
-            double rz[DPL], r1[DPL], r2[DPL];
-            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[0] : part.lds[2]), q, ld, rz);
-            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[1] : part.lds[3]), q, ld, r1);
-            load_row<LPC, DPL>(row_ptr(a.L, SNK_DIRECT ? snk_id[2] : part.lds[4]), q, ld, r2);
             double n2 = 0.0, dot = 0.0;
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
