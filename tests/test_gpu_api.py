@@ -707,6 +707,48 @@ def test_config4_shape_eight_ranks_equal_single_rank():
         e.close()
 
 
+@pytest.mark.parametrize("exchange", ["dense", "replay"])
+def test_cr_slots_are_fresh_when_adaptation_resumes_in_a_world(exchange):
+    """The chains' CR slots (delta | CR index) are written only by generations whose reduction reads them -- adapting, level 1 not summed inside the
+    update kernel (round 4: the steady state had stored "no statistic" with every update).  Burn-in restarts with every run (demc.py:78, dream.py:92):
+    three runs of 4 adapting + 9 steady generations in a world of two emulated ranks (level 1 from the slots, which hold the LAST adapting
+    generation's values all through the steady part and must all be rewritten before the next reduction reads them) against the single-rank run
+    (level 1 inside its update kernels, slots never written): p_cr, delta_m, n_cr_updates and every replica equal bit for bit."""
+    import ctypes as C
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss, mixture_nd
+    for spec, N in ((mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), 96), (d100_gauss.Gauss_100D()._bpm_target_spec(), 64)):
+        tid, tp, d = spec
+        kw = dict(burnin_gen=4, n_cr_gen=1)
+        x0 = np.random.RandomState(5).normal(size=(N, d)) + 0.5
+        one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=13, **kw)
+        one.set_state(x0)
+        uid = b"BPMLOCAL" + bytes(120)
+        ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=13, rank=r, world_size=2, nccl_uid=uid, **kw)
+                 for r in range(2)]
+        arr = (C.c_void_p * 2)(*[e._h for e in ranks])
+        for e in ranks:
+            e.set_state(x0)
+        for run in range(3):
+            one.begin_run()
+            one.step(13)
+            for e in ranks:
+                e.begin_run()
+                e.set_exchange(mode=exchange, cap=0)
+            L.check(ranks[0].lib.bpm_local_group_step(arr, 2, 13))
+            st1 = one.stats()
+            assert np.all(np.asarray(st1["n_cr_updates"]) > 0)
+            for e in ranks:
+                st = e.stats()
+                np.testing.assert_array_equal(st["p_cr"], st1["p_cr"])
+                np.testing.assert_array_equal(st["delta_m"], st1["delta_m"])
+                np.testing.assert_array_equal(st["n_cr_updates"], st1["n_cr_updates"])
+                assert np.array_equal(e.get_state(), one.get_state())
+        for e in ranks + [one]:
+            e.close()
+
+
 @pytest.mark.parametrize("R", [2, 4])
 def test_outlier_reset_multi_rank_equals_single_rank(R):
     """The outlier-chain reset with world_size > 1 -- omega of the local chains, all-gather of the (omega | ln_like) blocks,
