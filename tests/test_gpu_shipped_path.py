@@ -214,3 +214,46 @@ def test_the_one_dimension_limit_is_the_philox_slot():
     e.step(2)
     assert np.all(np.isfinite(e.get_state()))
     e.close()
+
+
+def _random_case(rs):
+    """a small random configuration of the path: algorithm, target, population, dimension, pair count, CR values, burn-in, snooker, outlier check"""
+    dream = rs.rand() < 0.65
+    if dream:
+        kind = rs.choice(["gauss", "mix"])
+        d = int(rs.choice([1, 2, 3, 5, 8, 9, 16, 31, 32, 33, 64, 100, 129, 200, 513])) if kind == "gauss" else int(rs.choice([2, 4, 6, 8, 12, 30]))
+        n_cr = int(rs.choice([1, 2, 3, 3, 3, 4, 8]))
+        pairs = int(rs.choice([1, 2, 3, 3, 3, 4, 7]))
+        N = int(rs.choice([4 * pairs + 4, 24, 50, 97, 256, 1000]))
+        N = max(N, 2 * (2 * pairs + 1) + 2)
+        kw = dict(del_pairs=pairs, n_cr=n_cr, burnin_gen=int(rs.choice([0, 3, 100])), n_cr_gen=int(rs.choice([1, 2])))
+        if kind == "mix" and rs.rand() < 0.4 and kw["burnin_gen"] > 0:
+            kw["outlier_every"] = 3
+        algo = R.ALGO_DREAM
+    else:
+        kind = rs.choice(["banana", "gauss"])
+        d = 2 if kind == "banana" else int(rs.choice([1, 2, 3, 8, 17, 100, 300, 600]))
+        N = int(rs.choice([8, 13, 64, 257, 1000, 4096]))
+        kw = dict(p_snooker=float(rs.choice([0.0, 0.1, 0.5, 1.0])))
+        algo = R.ALGO_DEMC
+    if kind == "gauss":
+        tid, params = R.TARGET_GAUSS_EQUICORR, R.gauss_equicorr_params(float(rs.choice([0.0, 0.5, 0.9])), np.sqrt(np.arange(d) + 1.0))
+        X0 = rs.normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    elif kind == "mix":
+        tid, params = R.TARGET_MIXTURE_PAIRS, R.mixture_pairs_params(0.25, 0.75, [0, 0], [2, 2], [0.25, 0.25], [0.25, 0.25], 0.8, -0.8)
+        X0 = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
+    else:
+        tid, params = R.TARGET_BANANA_2D, R.banana_params()
+        X0 = rs.normal(size=(N, 2)) * 1.1 + np.array([0.0, 1.1])
+    return algo, N, d, tid, params, X0, kw
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_configurations_on_the_shipped_path_equal_the_oracle(seed):
+    """Differential test over random small configurations (algorithm, target, 1 ... 513 dimensions, 1 ... 7 pairs, 1 ... 8 CR values, burn-in on / off /
+    ending inside the run, snooker probabilities 0 ... 1, the outlier check every 3 generations): whatever kernel shape and flavour the library picks
+    -- specialised or general instantiation, one lane / 4 / 16 lanes / one wavefront per chain, the looped wide-row kernel -- on its own queue, without a
+    trace, against the oracle over 8 generations.  Integers exact, floats as in the rest of this file."""
+    rs = np.random.RandomState(1000 + seed)
+    algo, N, d, tid, params, X0, kw = _random_case(rs)
+    _run_both(algo, N, d, tid, params, 77 + seed, X0, 8, kw, hist_rows=(1, 8))
