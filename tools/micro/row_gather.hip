@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef double d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_gather(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pool, double* state, double* hist, uint32_t n_upd,
@@ -37,7 +38,10 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t* __restrict__ per
     __builtin_nontemporal_store(s, reinterpret_cast<d2*>(hist + (uint64_t)w * 8u + 2u * q));
     if ((c * 2654435761u >> 16) < acc_thr) *reinterpret_cast<d2*>(state + (uint64_t)c * stride_d + 2u * q) = s;
 }
-int main() {
+int main(int argc, char** argv) {
+    // row_gather [only_variant [launches]]: one access pattern, few launches -- for a counter pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) on known byte counts
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    const int n_timed = argc > 2 ? atoi(argv[2]) : 500;
     hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     const uint32_t N = 262144, n_upd = N / 2;
     std::vector<uint32_t> perm(N), pool(6 * (size_t)N);
@@ -54,8 +58,10 @@ int main() {
     printf("pattern                          accepted  us per launch   rows read per s   bytes of rows per s\n");
     struct V { const char* name; uint32_t stride; int mode; };
     const V vs[] = {{"random 64 B rows, stride 64 B ", 8, 0}, {"random 64 B rows, stride 128 B", 16, 0}, {"sequential rows, stride 64 B  ", 8, 2}};
+    int vi = -1;
     for (const V& v : vs)
         for (uint32_t acc_pct : {0u, 6u, 100u}) {
+            if (++vi, only >= 0 && vi != only) continue;
             const uint32_t thr = acc_pct * 65536u / 100u;
             int g = 0;
             auto run = [&](int n) {
@@ -63,10 +69,10 @@ int main() {
                     hipLaunchKernelGGL(k_gather, dim3((n_upd * 4 + 255) / 256), dim3(256), 0, st, d_perm + (g & 1) * n_upd, d_pool, d_state, d_hist + (size_t)(g & 63) * n_upd * 8,
                                        n_upd, v.stride, N, v.mode, thr);
             };
-            run(50); hipStreamSynchronize(st);
+            run(only >= 0 ? 5 : 50); hipStreamSynchronize(st);
             auto t0 = std::chrono::high_resolution_clock::now();
-            run(500); hipStreamSynchronize(st);
-            const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / 500.0;
+            run(n_timed); hipStreamSynchronize(st);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / n_timed;
             printf("%s   %3u %%     %8.2f       %.3e        %.2f TB/s\n", v.name, acc_pct, us, 7.0 * n_upd / (us * 1e-6), 7.0 * n_upd * 64 / (us * 1e-6) / 1e12);
         }
     return 0;
