@@ -246,6 +246,9 @@ def measured_copy_bandwidth(torch, dev):
 # ---------------------------------------------------------------------------------------------------------------------
 # The other BASELINE configurations that fit one GPU, under the same clock.  bytes = SURVEY 8(d).
 # ---------------------------------------------------------------------------------------------------------------------
+OTHER_CONFIG_PREHEAT_S = 0.1      # untimed steady-state generations of a scratch sampler (no history) in front of every extra configuration
+
+
 def _counter_traffic(tag):
     """HBM-side bytes per update launch of a configuration from the committed counter passes (profiles/r04_pmc_<tag>.txt: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, separate passes; FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes, see profiles/r04_row_gather_floor.txt for what
@@ -295,6 +298,17 @@ def other_configs(device, budget_s=6.0):
             e.set_state(x0)
             e.reserve_history(gens + 48)
             e.begin_run()
+            # the GPU kept busy right up to the timed generations, as for the headline (--preheat): creating a sampler and reserving its history leaves
+            # the GPU idle for tens of milliseconds, and the first 8 ms block after that ran 8 % slower than the following ones (cfg5: 41.8 against 38.5 us)
+            heat_kw = dict(kw, burnin_gen=0, outlier_every=0) if algo == L.ALGO_DREAM else dict(kw)
+            heat = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=7, device=device, keep_history=False, **heat_kw)
+            heat.set_state(x0)
+            heat.begin_run()
+            th = time.perf_counter()
+            while time.perf_counter() - th < OTHER_CONFIG_PREHEAT_S:
+                heat.step(64)
+                heat.synchronize()
+            heat.close()
             e.step(30)
             e.synchronize()
             t0 = time.perf_counter()
@@ -308,7 +322,7 @@ def other_configs(device, budget_s=6.0):
         gen_us_dev = (ev_ms * 1e3 / ev_n * 2.0) if ev_n > 0 else None     # two update launches per generation; with CR adaptation
         ach = N * bpu / ((gen_us_dev or el / gens * 1e6) * 1e-6) / 1e9      # the reduction dispatches sit inside the period
         out.append(dict(config=name, value=value, unit="chain-updates/s", n_chains=N, dim=d, steps=gens,
-                        ms_per_step=el / gens * 1e3, start="exact draws of the target",
+                        ms_per_step=el / gens * 1e3, start="exact draws of the target", preheat_s=OTHER_CONFIG_PREHEAT_S,
                         acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
                         packet_fence=ls["fence"],
                         roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
