@@ -47,7 +47,103 @@ N_CR_GEN = 50
 BYTES_PER_UPDATE = 8 * DIM * (2 * DEL_PAIRS + 3) + 16          # 7216
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
 POSTERIOR_MIN_GENS = 1200                                      # post-burn-in generations the moment gate is evaluated over
-ALT_WATCHDOG_S = 120                                           # N > 1: wall-clock bound of the alternative-exchange runs behind the headline
+# ---- bench.py cannot die silent ---------------------------------------------------------------------------
+# Every stage of a run has a wall-clock limit, and the whole run an absolute one (BENCH_DEADLINE_S, default 480 s: below the 600 s the driver gives
+# the command).  When a limit is hit the rank's watchdog (StageWatch) writes ONE parseable JSON line -- the headline measured so far, or a line
+# with "value": null -- naming the stage and the collective that was pending, and the process exits with EXIT_WATCHDOG: the line is kept, the
+# return code is not 0.  The launcher of an N > 1 run (launch_ranks) relays that line, ends the other ranks by PID, and -- when the stall was in
+# the push exchange's connection / validation / timed region and time is left -- starts a FRESH set of child processes once under the dense RCCL
+# all-gather (never a re-exec of a process that touched the GPU).
+EXIT_WATCHDOG = 125
+DEADLINE_S = float(os.environ.get("BENCH_DEADLINE_S", "480"))
+STAGE_LIMITS_S = dict(init=150.0, create=60.0, connect=75.0, validation=90.0, headline=120.0, posterior=90.0, alternatives=120.0, extras=150.0,
+                      teardown=45.0)
+METRIC_NAME = "chain-updates/sec"
+
+
+WATCH = None          # the rank's StageWatch (main() sets it): helpers name the collective they are about to block in
+
+
+def _pend(what):
+    if WATCH is not None:
+        WATCH.pending(what)
+
+
+def null_line(n_gpus, steps=None, warmup=None, **why):
+    """the line of a run that measured nothing: same keys as a measurement, value null, and what happened"""
+    d = {"metric": METRIC_NAME, "value": None, "unit": "chain-updates/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": None,
+         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+         "config": {"workload": "DREAM, 100-D equicorrelated Gaussian, %d chains per GPU (BASELINE configs[1] / [3]): NOT MEASURED" % CHAINS_PER_GPU}}
+    d.update(why)
+    return d
+
+
+class StageWatch(object):
+    """One per rank process.  enter(stage) starts the stage's clock (its own limit, cut to the run's absolute deadline); pending(what) names the
+    collective / library call the rank is about to block in; headline(line) hands over rank 0's measured line as soon as it exists.  fire() --
+    from the timer thread, the main thread may be stuck inside a collective with the GIL released -- writes rank 0's ONE line (the headline so far
+    with a "watchdog" entry, or a null line) and ends the process with EXIT_WATCHDOG.  No teardown is attempted: the process is hung."""
+
+    def __init__(self, rank, world, write_line, steps=None, warmup=None, deadline_at=None, limits=None, exit_fn=os._exit, err=None, clock=time.time):
+        import threading
+        self.rank, self.world, self.write_line, self.steps, self.warmup = rank, world, write_line, steps, warmup
+        self.deadline_at = deadline_at if deadline_at is not None else clock() + DEADLINE_S
+        self.limits = dict(STAGE_LIMITS_S, **(limits or {}))
+        self.exit_fn, self.err, self.clock = exit_fn, err or sys.stderr, clock
+        self.stage, self.what, self.line, self.t_stage, self.limit, self.history = "start", None, None, clock(), None, []
+        self._timer, self._lock, self.fired = None, threading.Lock(), False
+
+    def enter(self, stage, limit_s=None):
+        import threading
+        with self._lock:
+            now = self.clock()
+            if self.stage != "start":
+                self.history.append((self.stage, round(now - self.t_stage, 2)))
+            if self._timer is not None:
+                self._timer.cancel()
+            self.stage, self.what, self.t_stage = stage, None, now
+            limit = self.limits.get(stage, 120.0) if limit_s is None else limit_s
+            self.limit = max(0.05, min(limit, self.deadline_at - now))
+            self._timer = threading.Timer(self.limit, self.fire)
+            self._timer.daemon = True
+            self._timer.start()
+        if os.environ.get("BENCH_TEST_STALL") == "%s:%d" % (stage, self.rank):      # rehearsal hook (tests/test_bench_launcher.py): this rank hangs here
+            self.what = "BENCH_TEST_STALL"
+            time.sleep(10 ** 6)
+
+    def pending(self, what):
+        self.what = what
+
+    def headline(self, line):
+        self.line = line
+
+    def info(self):
+        return dict(fired=True, rank=self.rank, stage=self.stage, pending=self.what, stage_limit_s=round(self.limit or 0.0, 1),
+                    seconds_in_stage=round(self.clock() - self.t_stage, 1), stages_done=self.history,
+                    note="a stage of bench.py ran into its wall-clock limit: the process was ended by its own watchdog (exit code %d)" % EXIT_WATCHDOG)
+
+    def fire(self):
+        with self._lock:
+            if self.fired:
+                return
+            self.fired = True
+        info = self.info()
+        try:
+            self.err.write("bench.py: rank %d: watchdog: stage %r exceeded %.0f s (pending: %s)\n" % (self.rank, self.stage, self.limit or 0.0, self.what))
+            if self.rank == 0:
+                line = dict(self.line) if self.line else null_line(self.world, self.steps, self.warmup)
+                line["watchdog"] = info
+                if not self.line:
+                    line["error"] = "stage %r did not finish within %.0f s (pending: %s)" % (self.stage, self.limit or 0.0, self.what)
+                self.write_line(json.dumps(line))
+        finally:
+            self.exit_fn(EXIT_WATCHDOG)
+
+    def done(self):
+        with self._lock:
+            if self._timer is not None:
+                self._timer.cancel()
+                self._timer = None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -78,34 +174,16 @@ def visible_gpu_count(timeout=180.0):
     return -1
 
 
-def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys.stdout, err=sys.stderr, deadline_s=None):
-    """Start n rank processes of this script as children, relay rank 0's last JSON line to `out`, everything else to `err`.
-    Returns the exit code: 0 only when every rank exited 0 and rank 0 printed its line.  Fewer visible GPUs than ranks is an
-    error before anything starts (RCCL refuses two ranks on one device; no silent oversubscription).  When one rank fails
-    the others are given grace_s seconds, then ended (their exact PIDs) -- a rank that died inside a collective would leave
-    its peers waiting for ever -- and when ALL ranks hang without exiting the wall-clock limit deadline_s (default
-    BENCH_LAUNCH_DEADLINE_S or 1500 s) ends them the same way: exit code 124.  worker_cmd / n_visible: test hooks
-    (tests/test_bench_launcher.py)."""
-    if deadline_s is None:
-        deadline_s = float(os.environ.get("BENCH_LAUNCH_DEADLINE_S", "1500"))
-    t_start = time.time()
-    if n_visible is None:
-        n_visible = visible_gpu_count()
-    if n_visible < n:
-        err.write("bench.py: --gpus %d but %s GPU(s) visible to this process: one process per GPU, no oversubscription "
-                  "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the set)\n"
-                  % (n, "no" if n_visible <= 0 else str(n_visible)))
-        return 2
-    cmd = list(worker_cmd) if worker_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+def _launch_once(n, cmd, out_lines, err, grace_s, deadline_at, rank_deadline_at):
+    """one set of n fresh child processes -> (rc, last JSON line of rank 0 or None).  rc 124: ended at the wall-clock limit."""
     port = _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), BPM_BENCH_CHILD="1")
+                   MASTER_PORT=str(port), BPM_BENCH_CHILD="1", BENCH_DEADLINE_AT="%.3f" % rank_deadline_at)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and the IPC-mapped exchange buffers need here
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else err, stderr=err))
-    line = None
     first_fail_t = None
     rc = 0
     # rank 0's stdout is read in a thread so that a full pipe never blocks it
@@ -125,15 +203,14 @@ def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys
                 continue
             live.discard(r)
             if c != 0:
-                err.write("bench.py: rank %d exited with code %d\n" % (r, c))
+                err.write("bench.py: rank %d exited with code %d%s\n" % (r, c, " (its watchdog fired: a stage ran into its wall-clock limit)" if c == EXIT_WATCHDOG else ""))
                 rc = rc or (c if 0 < c < 256 else 1)
                 if first_fail_t is None:
                     first_fail_t = time.time()
-        timed_out = live and time.time() - t_start > deadline_s
+        timed_out = live and time.time() > deadline_at
         if live and ((first_fail_t is not None and time.time() - first_fail_t > grace_s) or timed_out):
             for r in sorted(live):
-                err.write("bench.py: ending rank %d (pid %d): %s\n" % (r, procs[r].pid, "the run exceeded its wall-clock limit of %.0f s" % deadline_s
-                                                                        if timed_out else "another rank failed"))
+                err.write("bench.py: ending rank %d (pid %d): %s\n" % (r, procs[r].pid, "the run exceeded its wall-clock limit" if timed_out else "another rank failed"))
                 procs[r].kill()
             for r in sorted(live):
                 procs[r].wait()
@@ -143,18 +220,86 @@ def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys
         if live:
             time.sleep(0.05)
     th.join(timeout=5.0)
+    line = None
     for text in got:
-        s = text.strip()
-        if s.startswith("{") and s.endswith("}"):
-            line = s
-        elif s:
+        t = text.strip()
+        if t.startswith("{") and t.endswith("}"):
+            line = t
+        elif t:
             err.write(text if text.endswith("\n") else text + "\n")
-    if rc == 0 and line is None:
-        err.write("bench.py: rank 0 exited without printing its JSON line\n")
-        rc = 1
-    if rc == 0:
-        out.write(line + "\n")
+    return rc, line
+
+
+def launch_ranks(n, argv, worker_cmd=None, n_visible=None, grace_s=15.0, out=sys.stdout, err=sys.stderr, deadline_s=None, retry_min_s=150.0):
+    """Start n rank processes of this script as children and relay rank 0's last JSON line to `out`, everything else to `err`.  EXACTLY ONE line
+    reaches `out` whatever happens -- rank 0's, or a line with "value": null written here that says what went wrong (fewer GPUs than ranks, a rank
+    that died, a run that hit the wall-clock limit).  Returns 0 only when every rank exited 0 and rank 0 printed a line with a value.
+    Fewer visible GPUs than ranks is an error before anything starts (RCCL refuses two ranks on one device; no silent oversubscription).  When one
+    rank fails the others are given grace_s seconds, then ended (their exact PIDs) -- a rank that died inside a collective would leave its peers
+    waiting for ever.  The wall-clock limit deadline_s (BENCH_LAUNCH_DEADLINE_S, else BENCH_DEADLINE_S = 480 s: below the driver's own limit)
+    runs from the moment this function is entered, the GPU-count probe included; the ranks get an absolute deadline 25 s earlier
+    (BENCH_DEADLINE_AT), so their own watchdogs -- which can still write the line -- fire first: exit code 125 then, 124 when the parent had to end
+    them.  A run whose ranks stalled in the push exchange's connection, validation or timed region is repeated ONCE, in fresh child processes,
+    under the dense RCCL all-gather (north_star's exchange) when at least retry_min_s seconds are left; the line then lists the first attempt.
+    worker_cmd / n_visible: test hooks (tests/test_bench_launcher.py)."""
+    t_start = time.time()
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("BENCH_LAUNCH_DEADLINE_S", str(DEADLINE_S)))
+    deadline_at = t_start + deadline_s
+
+    def steps_of(a):
+        try:
+            return int(a[a.index("--steps") + 1]), int(a[a.index("--warmup") + 1])
+        except (ValueError, IndexError):
+            return None, None
+
+    def emit(line_dict):
+        out.write(json.dumps(line_dict) + "\n")
         out.flush()
+    if n_visible is None:
+        n_visible = visible_gpu_count(timeout=min(180.0, max(5.0, deadline_s / 3.0)))
+    steps, warmup = steps_of(list(argv))
+    if n_visible < n:
+        msg = ("--gpus %d but %s GPU(s) visible to this process: one process per GPU, no oversubscription (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
+               "narrow the set)" % (n, "no" if n_visible <= 0 else str(n_visible)))
+        err.write("bench.py: " + msg + "\n")
+        emit(null_line(n, steps, warmup, error=msg))
+        return 2
+    attempts = []
+    cur_argv = list(argv)
+    while True:
+        cmd = (list(worker_cmd) if worker_cmd else [sys.executable, os.path.abspath(__file__)]) + cur_argv
+        rc, line = _launch_once(n, cmd, None, err, grace_s, deadline_at, deadline_at - min(25.0, 0.25 * deadline_s))
+        parsed = None
+        if line is not None:
+            try:
+                parsed = json.loads(line)
+            except ValueError:
+                parsed = None
+        wd = (parsed or {}).get("watchdog") or {}
+        has_value = parsed is not None and parsed.get("value") is not None
+        left = deadline_at - time.time()
+        can_retry = (not attempts and not has_value and wd.get("stage") in ("connect", "validation", "headline") and left >= retry_min_s
+                     and "--exchange" not in cur_argv and "--share-gpu" not in cur_argv)
+        if can_retry:
+            attempts.append(dict(argv=cur_argv, rc=rc, watchdog=wd, seconds=round(time.time() - t_start, 1)))
+            err.write("bench.py: the ranks stalled in stage %r of the default (push) exchange: starting %d FRESH rank processes under the dense RCCL "
+                      "all-gather (%.0f s left)\n" % (wd.get("stage"), n, left))
+            cur_argv = cur_argv + ["--exchange", "dense", "--no-exchange-alternatives"]
+            continue
+        break
+    if parsed is None:
+        why = ("rank 0 exited without printing its JSON line" if rc == 0 else
+               ("the run exceeded its wall-clock limit of %.0f s and its ranks were ended" % deadline_s if rc == 124 else "a rank failed (exit code %d)" % rc))
+        err.write("bench.py: %s\n" % why)
+        parsed = null_line(n, steps, warmup, error=why)
+        rc = rc or 1
+    elif not has_value:
+        rc = rc or 1
+    if attempts:
+        parsed["launcher"] = dict(attempts_before_this_one=attempts,
+                                  note="the first set of rank processes stalled; this line comes from a fresh set under --exchange dense")
+    emit(parsed)
     return rc
 
 
@@ -337,7 +482,8 @@ def other_configs(device, budget_s=6.0):
 
 def connect_exchange(eng, dist, rank, world, want):
     """-> dict(mode=..., why=...).  Every decision is taken on all ranks together (all_gather_object of what each rank saw)."""
-    def everyone(v):
+    def everyone(v, what="connect_exchange: all_gather_object"):
+        _pend(what)
         box = [None] * world
         dist.all_gather_object(box, v)
         return box
@@ -349,22 +495,24 @@ def connect_exchange(eng, dist, rank, world, want):
         blob = eng.push_export()
     except Exception as e:                                             # noqa: BLE001 -- reported collectively
         blob, err = None, "export: %s" % e
-    blobs = everyone((blob, err))
+    blobs = everyone((blob, err), "connect_exchange: all_gather_object of the ranks' bpm_push_export blobs")
     ok = all(b[0] is not None for b in blobs)
     if ok:
         try:
             eng.push_connect([b[0] for b in blobs])
         except Exception as e:                                         # noqa: BLE001
             ok, err = False, "connect: %s" % e
-    seen = everyone((ok, err))
+    seen = everyone((ok, err), "connect_exchange: all_gather_object after bpm_push_connect")
     ok = all(o[0] for o in seen)
     if ok:
+        _pend("connect_exchange: dist.barrier before bpm_push_selftest")
         dist.barrier()
         try:
+            _pend("connect_exchange: bpm_push_selftest (cross-rank waits inside)")
             mine = bool(eng.push_selftest())
         except Exception as e:                                         # noqa: BLE001
             mine, err = False, "self-test: %s" % e
-        seen = everyone((mine, err))
+        seen = everyone((mine, err), "connect_exchange: all_gather_object after bpm_push_selftest")
         ok = all(o[0] for o in seen)
     if ok:
         eng.set_exchange(mode="push")
@@ -379,47 +527,83 @@ def connect_exchange(eng, dist, rank, world, want):
     return dict(mode="replay", why="push exchange not available (%s)" % why)
 
 
-def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000, fatal=True):
-    """Which exchange the timed run uses is decided by a RUN, not by what connected: `gens` generations with CR adaptation (so the per-update
+def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000, fatal=True, wall_s=45.0, chunk=250):
+    """Which exchange the timed run uses is decided by a RUN, not by what connected: up to `gens` generations with CR adaptation (so the per-update
     statistics travel too) from the same start, once on a single-rank sampler holding the whole population on this rank's own GPU (what
     the reference computes on one MPI rank, demc.py:63-151) and then under each candidate in order -- push with agent-scope fences (cheapest),
     push with system-scope fences (what the HSA memory model asks for between agents), accept bytes + replay through RCCL, the dense all-gather
     (the reference's own exchange, demc.py:93-94).  The first candidate that leaves EVERY rank's replica bit-identical to the single-rank run
-    wins; a candidate that raises (a cross-rank wait that ran into its limit) is recorded and skipped.  -> dict(mode=..., validation=[...])."""
+    wins; a candidate that raises (a cross-rank wait that ran into its limit) is recorded and skipped.  Bounded by wall time as well as by
+    generations: the runs advance in chunks of `chunk` generations, the single-rank run keeps the state's hash after every chunk, and a candidate
+    stops (all ranks together) after the chunk in which the slowest rank passed wall_s seconds -- it is then compared at that generation.
+    -> dict(mode=..., validation=[...])."""
     import hashlib
 
     def sha(x):
         return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()[:16]
     world = dist.get_world_size()
+    sizes = [min(chunk, gens - g0) for g0 in range(0, gens, chunk)]
+    _pend("validate_exchange: single-rank run (local)")
     single = make_single()
     single.set_state(X0)
     single.begin_run()
-    single.step(gens)
-    single.synchronize()
-    want = sha(single.get_state())
+    want = []                                   # hash of the single-rank state after every chunk
+    t0 = time.perf_counter()
+    for n in sizes:
+        single.step(n)
+        single.synchronize()
+        want.append(sha(single.get_state()))
+        if time.perf_counter() - t0 > wall_s and len(want) < len(sizes):
+            break
     single.close()
+    sizes = sizes[:len(want)]
     log = []
     push_dead = False
     for cand in candidates:
         if push_dead and cand.startswith("push"):
             log.append(dict(exchange=cand, ok=False, why="skipped: a push wait timed out under an earlier candidate"))
             continue
-        mine, err = None, None
+        mine, err, done_chunks = None, None, 0
+        t0 = time.perf_counter()
         try:
             eng.set_exchange(mode=cand)
             eng.set_state(X0)
             eng.set_adapt_state(t_abs=0)
             eng.begin_run()
+            _pend("validate_exchange[%s]: dist.barrier before the run" % cand)
             dist.barrier()
-            eng.step(gens)
-            eng.synchronize()
-            mine = sha(eng.get_state())
         except Exception as e:                                         # noqa: BLE001 -- decided collectively below
             err = "%s: %s" % (type(e).__name__, e)
+        for n in sizes:
+            if err is None:
+                try:
+                    _pend("validate_exchange[%s]: bpm_step + bpm_synchronize (cross-rank hand-overs inside)" % cand)
+                    eng.step(n)
+                    eng.synchronize()
+                except Exception as e:                                 # noqa: BLE001
+                    err = "%s: %s" % (type(e).__name__, e)
+            # every rank enters this collective after every chunk, whatever happened to it: stop together (an error anywhere, or the wall clock)
+            _pend("validate_exchange[%s]: all_gather_object after chunk %d" % (cand, done_chunks))
+            box = [None] * world
+            dist.all_gather_object(box, (err is None, time.perf_counter() - t0))
+            if not all(b[0] for b in box):
+                break
+            done_chunks += 1
+            if max(b[1] for b in box) > wall_s:
+                break
+        if err is None and done_chunks > 0:
+            try:
+                mine = sha(eng.get_state())
+            except Exception as e:                                     # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+        _pend("validate_exchange[%s]: all_gather_object of the state hashes" % cand)
         box = [None] * world
         dist.all_gather_object(box, (mine, err))
-        ok = all(b[0] == want for b in box)
-        entry = dict(exchange=cand, ok=ok, generations=gens, ranks_equal_to_single_rank_run=sum(1 for b in box if b[0] == want))
+        target = want[done_chunks - 1] if done_chunks > 0 else None
+        ok = target is not None and all(b[0] == target for b in box)
+        entry = dict(exchange=cand, ok=ok, generations=int(sum(sizes[:done_chunks])), ranks_equal_to_single_rank_run=sum(1 for b in box if target is not None and b[0] == target))
+        if done_chunks < len(sizes) and ok:
+            entry["stopped_by_wall_clock_s"] = wall_s
         errs = ["rank %d: %s" % (i, b[1]) for i, b in enumerate(box) if b[1]]
         if errs:
             entry["errors"] = errs[:4]
@@ -441,7 +625,8 @@ def validate_exchange(eng, dist, X0, make_single, candidates, gens=1000, fatal=T
     raise SystemExit("bench.py: no exchange reproduced the single-rank run on every rank: " + json.dumps(log))
 
 
-def _everyone(dist, world, v):
+def _everyone(dist, world, v, what="all_gather_object"):
+    _pend(what)
     box = [None] * world
     dist.all_gather_object(box, v)
     return box
@@ -466,13 +651,18 @@ def _timed_generations(eng, dist, world, X0, n_chains, burn, gens, coll_max):
     eng.set_state(X0)
     eng.set_adapt_state(t_abs=0)
     eng.begin_run()
+    _pend("_timed_generations: dist.barrier before burn-in")
     dist.barrier()
+    _pend("_timed_generations: bpm_step(burn-in) + bpm_synchronize")
     eng.step(burn)
     eng.synchronize()
+    _pend("_timed_generations: dist.barrier before the timed generations")
     dist.barrier()
     t0 = time.perf_counter()
+    _pend("_timed_generations: bpm_step + bpm_synchronize (exchange inside)")
     eng.step(gens)
     eng.synchronize()
+    _pend("_timed_generations: dist.barrier / all_reduce(MAX) behind the timed generations")
     dist.barrier()
     el = coll_max(time.perf_counter() - t0)
     sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]
@@ -607,43 +797,167 @@ def host_callback_config(device, budget_s=3.0):
                 note="the host clock includes the callback; not a roofline configuration (PCIe + Python bound by construction)")
 
 
-# the generation after which cfg2 from the REFERENCE'S start passes the moment gate, as measured on MI355X (tools/convergence_from_reference_start.py,
-# profiles/r04_convergence_from_reference_start.txt: seeds 42 and 7); the asserted form is tests/test_gpu_statistics.py
-REFERENCE_START_GATE_GENS = 6000
+# ---------------------------------------------------------------------------------------------------------------------
+# The posterior gate (BASELINE.json north_star: "posterior moments within 1 % of reference"): EVERY coordinate's variance
+# within 1 % of the analytic value and EVERY coordinate's mean within 0.01 sigma, each with a batch-means Monte-Carlo standard error beside it.
+# A sampler with running_moments keeps two 2 d-double sums per generation instead of a history (10^5 generations of cfg2 would be 660 GB), so the
+# gate costs a second of GPU time; bpm_reduce_moments answers for any burn-in of whole generations, batches are differences of two such answers.
+# ---------------------------------------------------------------------------------------------------------------------
+GATE_VAR_TOL = 0.01           # |var_j / var_j(analytic) - 1| for every coordinate j
+GATE_MEAN_TOL = 0.01          # |mean_j - mean_j(analytic)| / sigma_j for every coordinate j
+GATE_BATCHES = 20
 
 
-def posterior_from_reference_start(device, max_gens=REFERENCE_START_GATE_GENS, window=1000, step=250):
-    """posterior.start alternative: config 2 from theta_0 = 0, varepsilon = 1e-6 (bipymc/chain.py:25-27,
-    tests/test_100dgauss.py:67-69) instead of exact draws: the generation at which the trailing 1000 generations first pass the gate of the headline
-    (pooled variance ratio within 1 %, every |mean| < 0.05 sigma).  Population sums per generation, no history.  Untimed."""
-    from bipymc_amd import _lib as L
+def batch_moment_gate(eng, n_chains, g_lo, g_hi, true_mean, true_var, batches=GATE_BATCHES, reduce_all=None):
+    """Per-coordinate posterior moments of the generations [g_lo, g_hi) of a single-rank sampler (rows g * n_chains + i of the interleaved super chain,
+    demc.py:260-270; param_est's mean / std(ddof=0), demc.py:235-248) and their batch-means standard errors over `batches` consecutive blocks of
+    generations.  reduce_all: sums the per-rank (count | s1 | s2) over the ranks of a world (None: one rank).  -> dict for the JSON line."""
+    true_mean, true_var = np.asarray(true_mean, dtype=np.float64), np.asarray(true_var, dtype=np.float64)
+    edges = np.unique(np.linspace(g_lo, g_hi, batches + 1).astype(np.int64))
+    B = len(edges) - 1
+    cum = []
+    for g in edges:                                   # sums over rows >= g * n_chains
+        cnt, s1, s2, sh = eng.reduce_moments(int(g) * n_chains)
+        if reduce_all is not None:
+            cnt, s1, s2 = reduce_all(cnt, s1, s2)
+        cum.append((float(cnt), s1.copy(), s2.copy(), sh.copy()))
+    sh = cum[0][3]
+    n = np.array([cum[k][0] - cum[k + 1][0] for k in range(B)])
+    S1 = np.array([cum[k][1] - cum[k + 1][1] for k in range(B)])
+    S2 = np.array([cum[k][2] - cum[k + 1][2] for k in range(B)])
+    n_tot = n.sum()
+    mu_s = S1.sum(axis=0) / n_tot                                   # mean in shifted coordinates (x - sh)
+    mean = sh + mu_s
+    var = S2.sum(axis=0) / n_tot - mu_s ** 2                        # std(ddof=0)^2 of param_est
+    mean_b = S1 / n[:, None]                                        # batch means (shifted)
+    var_b = S2 / n[:, None] - 2.0 * mu_s * mean_b + mu_s ** 2       # batch second moments about the OVERALL mean
+    sig = np.sqrt(true_var)
+    mcse_mean = mean_b.std(axis=0, ddof=1) / np.sqrt(B) / sig if B > 1 else np.full_like(sig, np.nan)
+    mcse_vr = (var_b / true_var).std(axis=0, ddof=1) / np.sqrt(B) if B > 1 else np.full_like(sig, np.nan)
+    vr = var / true_var
+    mz = (mean - true_mean) / sig
+    jv, jm = int(np.argmax(np.abs(vr - 1.0))), int(np.argmax(np.abs(mz)))
+    ok = bool(np.all(np.abs(vr - 1.0) <= GATE_VAR_TOL) and np.all(np.abs(mz) <= GATE_MEAN_TOL))
+    return dict(generations=int(g_hi - g_lo), first_generation=int(g_lo), rows=int(n_tot), batches=int(B),
+                var_ratio_mean=float(vr.mean()), var_ratio_min=float(vr.min()), var_ratio_max=float(vr.max()),
+                max_abs_mean_over_sigma=float(np.max(np.abs(mz))),
+                mcse_var_ratio_max=float(np.nanmax(mcse_vr)), mcse_mean_over_sigma_max=float(np.nanmax(mcse_mean)),
+                worst_variance=dict(coordinate=jv, var_ratio=float(vr[jv]), mcse=float(mcse_vr[jv])),
+                worst_mean=dict(coordinate=jm, mean_over_sigma=float(mz[jm]), mcse=float(mcse_mean[jm])),
+                gate=dict(var_ratio_every_coordinate_within=GATE_VAR_TOL, abs_mean_every_coordinate_within_sigma=GATE_MEAN_TOL,
+                          standard_errors="batch means over %d consecutive blocks of generations" % B),
+                gate_pass=ok)
+
+
+POSTERIOR_GATE_GENS = 40000      # post-burn-in generations of the per-coordinate gate at cfg2 (tools/posterior_gate_sweep.py, profiles/r05_posterior_gate_sweep.txt)
+REFERENCE_START_TRANSIENT = 3000 # generations dropped from the reference's start (theta_0 = 0, varepsilon = 1e-6): the population needs ~2250 generations to
+                                 # find the stationary scale (profiles/r04_convergence_from_reference_start.txt)
+
+
+def _gate_engine(device, algo, tgt, N, **kw):
     from bipymc_amd.engine import HipEngine
+    tid, tp, d = tgt._bpm_target_spec()
+    return HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=42, device=device, keep_history=False, running_moments=True, **kw), d
+
+
+def posterior_gate(device, gens=POSTERIOR_GATE_GENS, start="exact"):
+    """The per-coordinate posterior gate of config 2 (DREAM, 100-D Gaussian, N = 8192; analytic moments mean 0, var_j = j + 1, d100_gauss.py:14-35) on a
+    sampler that keeps per-generation population sums instead of a history.  start = "exact": exact draws of the target (the stationary regime from the
+    first generation; BURNIN_GEN generations with CR adaptation are dropped); "reference": the reference's own start, theta_0 = 0 with varepsilon = 1e-6
+    (chain.py:25-27, tests/test_100dgauss.py:105-110), REFERENCE_START_TRANSIENT generations dropped.  Untimed."""
+    from bipymc_amd import _lib as L
     from bipymc_amd.utils.d100_gauss import Gauss_100D
-    tid, tp, _ = Gauss_100D(rho=0.5, dim=DIM)._bpm_target_spec()
-    N = CHAINS_PER_GPU
-    sig2 = np.arange(DIM) + 1.0
-    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=DIM, target_id=tid, target_params=tp, seed=42, device=device, del_pairs=DEL_PAIRS,
-                  burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3, keep_history=False, running_moments=True)
-    first, last = None, None
+    tgt = Gauss_100D(rho=0.5, dim=DIM)
+    e, d = _gate_engine(device, L.ALGO_DREAM, tgt, CHAINS_PER_GPU, del_pairs=DEL_PAIRS, burnin_gen=BURNIN_GEN, n_cr_gen=N_CR_GEN, n_cr=3)
+    t0 = time.perf_counter()
     try:
-        e.init_chains(np.zeros(DIM), 1e-6)
+        if start == "exact":
+            rs = np.random.RandomState(4321)
+            e.set_state(np.sqrt(np.arange(DIM) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, 1)) + np.sqrt(0.5) * rs.standard_normal((CHAINS_PER_GPU, DIM))))
+            drop = BURNIN_GEN
+        else:
+            e.init_chains(np.zeros(DIM), 1e-6)
+            drop = REFERENCE_START_TRANSIENT
         e.begin_run()
-        T = 0
-        while T < max_gens and first is None:
-            e.step(step)
-            T += step
-            if T < window:
-                continue
-            cnt, s1, s2, sh = e.reduce_moments((1 + T - window) * N)
-            mean, var = sh + s1 / cnt, s2 / cnt - (s1 / cnt) ** 2
-            vr, mm = float(np.mean(var / sig2)), float(np.max(np.abs(mean) / np.sqrt(sig2)))
-            last = dict(generations_end=T, var_ratio_mean=vr, max_abs_mean_over_sigma=mm)
-            if abs(vr - 1.0) < 0.01 and mm < 0.05:
-                first = T
+        e.step(drop + gens)
+        e.synchronize()
+        g = batch_moment_gate(e, CHAINS_PER_GPU, 1 + drop, 1 + drop + gens, np.zeros(DIM), np.arange(DIM) + 1.0)
+        st = e.stats()
     finally:
         e.close()
-    return dict(start="the reference's: theta_0 = 0, varepsilon = 1e-6 (every chain within 1e-3 of the origin)", window_generations=window,
-                gate_first_passed_at_generation=first, gate_pass=first is not None, limit_generations=max_gens, last_window=last)
+    g.update(start=("exact draws of the target" if start == "exact" else
+                    "the reference's: theta_0 = 0, varepsilon = 1e-6 (every chain within 1e-3 of the origin)"),
+             generations_dropped=int(drop), seconds=round(time.perf_counter() - t0, 2),
+             acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]), p_cr=[float(v) for v in st["p_cr"]],
+             sampler="DREAM N=%d d=%d, keep_history=0, running_moments=1 (two 2 d-double population sums per generation)" % (CHAINS_PER_GPU, DIM))
+    return g
+
+
+def posterior_gates_other_configs(device):
+    """The same gate for cfg3 (DE-MC, banana, N = 65536, snooker 0.1: E = (0, b (1 + a^2)), Var = (a^2, 1 / a^2 + 2 b^2), banana_rv.py:11-40) and for the
+    8-D pairwise mixture of cfg5 (one GPU's share, N = 32768, and the whole population, N = 262144: per axis mean 1.5, var 0.8125 = 0.0625 within a mode +
+    the spread of the two modes, dblgauss_rv.py:11-32 -- moves between the modes included), from exact draws of the targets.  Untimed."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.utils import banana_rv, mixture_nd
+    out = []
+    np.random.seed(20261005)
+    a_, b_ = 1.15, 0.5
+    specs = [("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", L.ALGO_DEMC, banana_rv.Banana_2D(), 65536, 0, 30000,
+              [0.0, b_ * (1 + a_ * a_)], [a_ * a_, 1.0 / (a_ * a_) + 2 * b_ * b_], dict(p_snooker=0.1)),
+             ("cfg5 one GPU's share: DREAM mixture d=8 N=32768", L.ALGO_DREAM, mixture_nd.BimodeGauss_ND(8), 32768, 300, 30000,
+              np.full(8, 1.5), np.full(8, 0.8125), dict(burnin_gen=300, n_cr_gen=50)),
+             ("cfg5 whole: DREAM mixture d=8 N=262144", L.ALGO_DREAM, mixture_nd.BimodeGauss_ND(8), 262144, 300, 10000,
+              np.full(8, 1.5), np.full(8, 0.8125), dict(burnin_gen=300, n_cr_gen=50))]
+    for name, algo, tgt, N, drop, gens, tm, tv, kw in specs:
+        try:
+            e, d = _gate_engine(device, algo, tgt, N, **kw)
+            t0 = time.perf_counter()
+            try:
+                x0 = tgt.rvs(N)
+                if isinstance(x0, tuple):
+                    x0 = np.stack(x0, axis=1)
+                e.set_state(x0)
+                e.begin_run()
+                e.step(drop + gens)
+                e.synchronize()
+                g = batch_moment_gate(e, N, 1 + drop, 1 + drop + gens, tm, tv)
+                st = e.stats()
+            finally:
+                e.close()
+            g.update(config=name, start="exact draws of the target", generations_dropped=drop, seconds=round(time.perf_counter() - t0, 2),
+                     acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]))
+        except Exception as ex:                                        # noqa: BLE001
+            g = dict(config=name, error=str(ex))
+        out.append(g)
+    return out
+
+
+def reference_scenario_on_the_device(device):
+    """The reference's OWN d = 100 scenario (tests/test_100dgauss.py:100-110: DreamMpi n_chains = 100, n_cr_gen = 50, burnin_gen = 2000, run_mcmc(500000),
+    n_burn = 200000; DeMcMpi n_chains = 200) through the drop-in classes on the device, beside the family the genuine reference produced under
+    three np.random seeds (tests/golden/e2e_anchor_gauss100_*.json, recorded by oracle/gen_anchor_families.py).  The asserted form is
+    tests/test_gpu_api.py::test_reference_families_hold_the_device."""
+    from bipymc_amd import DeMcMpi, DreamMpi
+    from bipymc_amd.utils.d100_gauss import Gauss_100D
+    out = []
+    for name, mk in (("gauss100_dream", lambda g: DreamMpi(g.ln_like, np.zeros(100), n_chains=100, n_cr_gen=50, burnin_gen=2000, seed=42, device=device)),
+                     ("gauss100_demc", lambda g: DeMcMpi(g.ln_like, np.zeros(100), n_chains=200, seed=42, device=device))):
+        path = os.path.join(ROOT, "tests", "golden", "e2e_anchor_%s.json" % name)
+        try:
+            fam = json.load(open(path))["family"]
+            g = Gauss_100D()
+            s = mk(g)
+            s.run_mcmc(500000)
+            mean, std, _ = s.param_est(n_burn=200000)
+            vr = std ** 2 / (np.arange(100) + 1.0)
+            mine = dict(acceptance_fraction=float(s.acceptance_fraction), var_ratio_pooled=float(vr.mean()), var_ratio_min=float(vr.min()), var_ratio_max=float(vr.max()))
+            if hasattr(s, "p_cr"):
+                mine["p_cr"] = [float(v) for v in np.asarray(s.p_cr)]
+            ref = {k: fam[k] for k in ("acceptance_fraction", "var_ratio_pooled", "var_ratio_min", "var_ratio_max", "p_cr") if k in fam}
+            out.append(dict(scenario=name, config=json.load(open(path))["config"], device=mine, reference_family=ref))
+        except Exception as ex:                                        # noqa: BLE001
+            out.append(dict(scenario=name, error=str(ex)))
+    return out
 
 
 def main(argv=None):
@@ -682,6 +996,15 @@ def main(argv=None):
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    def write_line(text):
+        json_out.write(text + "\n")
+        json_out.flush()
+    # the rank's watchdog: every stage below has a wall-clock limit, the run an absolute deadline (the launcher's, minus a margin, for its children)
+    global WATCH
+    watch = WATCH = StageWatch(rank, world, write_line, steps=args.steps, warmup=args.warmup,
+                               deadline_at=float(os.environ["BENCH_DEADLINE_AT"]) if os.environ.get("BENCH_DEADLINE_AT") else None)
+    watch.enter("init")
+
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before anything initialises HSA: dmabuf IPC, what hipIpcGetMemHandle and RCCL need on this pool)
     import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
     ndev = torch.cuda.device_count()
@@ -703,6 +1026,7 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        watch.pending("torch.distributed.init_process_group")
         if args.share_gpu:
             dist.init_process_group(backend="gloo")
         else:
@@ -747,17 +1071,24 @@ def main(argv=None):
     # --exchange restricts the candidates (and then failing is fatal).  Ranks sharing one GPU (--share-gpu) have no RCCL at all.
     exchange_info = None
     eng = None
+    rccl_comm_ranks = None                            # ranks of the RCCL communicator the LIBRARY created (ncclCommInitRank inside bpm_create), if any
+    watch.enter("create")
     if not use_dist:
         eng = make_engine(None)
     elif world == 1:                                   # BPM_FORCE_DIST=1: the one-rank rehearsal of the RCCL path
+        watch.pending("bpm_create with a one-rank RCCL communicator")
         eng = make_engine(rccl_uid())
+        rccl_comm_ranks = 1
+        watch.enter("connect")
         exchange_info = connect_exchange(eng, dist, rank, world, args.exchange)
     else:
         tried = []
         if args.exchange in (None, "push"):
             eng = make_engine(HipEngine.push_uid())
+            watch.enter("connect")
             exchange_info = connect_exchange(eng, dist, rank, world, "push-or-nothing")
             if exchange_info["mode"] == "push":
+                watch.enter("validation")
                 eng.reserve_history(1 + total_gens)
                 # the headline runs under what the sampler classes select (DeMcMpi._connect_exchange: set_exchange("push") = system-scope packet
                 # fences, what the HSA memory model asks for between agents); the agent-scope form is timed beside it as an alternative
@@ -769,13 +1100,18 @@ def main(argv=None):
                     exchange_info = dict(mode=None, why="no push candidate reproduced the single-rank run")
             if exchange_info["mode"] != "push":
                 tried.append(dict(exchange="push", ok=False, why=exchange_info.get("why")))
+                watch.pending("dist.barrier before closing the push world's samplers")
                 dist.barrier()                         # (nobody unmaps while a peer may still be inside its last call)
                 eng.close()
                 eng = None
                 if args.exchange == "push" or args.share_gpu:
                     raise SystemExit("bench.py: the push exchange is not available: " + json.dumps(tried))
         if eng is None:
+            watch.enter("create")
+            watch.pending("bpm_create: ncclCommInitRank over %d ranks (RCCL's first contact)" % world)
             eng = make_engine(rccl_uid())
+            rccl_comm_ranks = world
+            watch.enter("validation")
             eng.reserve_history(1 + total_gens)
             cands = [args.exchange] if args.exchange in ("replay", "rows", "dense") else ["replay", "dense"]
             eng.set_exchange(mode=cands[0])
@@ -783,10 +1119,12 @@ def main(argv=None):
             exchange_info.update(validate_exchange(eng, dist, X0, make_single, cands, gens=min(1000, total_gens)))
             exchange_info["validation"] = tried + exchange_info["validation"]
 
-    def fence():
+    def fence(what="fence"):
+        watch.pending(what + ": bpm_synchronize")
         eng.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
+            watch.pending(what + ": dist.barrier")
             dist.barrier()
 
     # The measurement below runs once.  At N > 1 it runs again under the next (more conservative) exchange candidate if the ranks' replicas
@@ -794,6 +1132,7 @@ def main(argv=None):
     # so this is the net under a rare ordering fault of the cheaper fences); with no candidate left the bench fails without a line.
     attempts = []
     while True:
+        watch.enter("headline")
         eng.set_state(X0)
         eng.reserve_history(1 + total_gens)
         eng.begin_run()
@@ -812,10 +1151,10 @@ def main(argv=None):
             preheat["seconds"] = time.perf_counter() - t0
             heat.close()
         # ---- burn-in with CR adaptation: timed separately, never part of `value`
-        fence()
+        fence("before burn-in")
         t0 = time.perf_counter()
         eng.step(BURNIN_GEN)
-        fence()
+        fence("behind burn-in")
         burn_s = time.perf_counter() - t0
         # ---- warm-up: W generations, the last of them through the same timed entry point as the timed region (the first
         # event-bound dispatch of a process sets up profiling signals: 10-30 us of host time, once)
@@ -823,10 +1162,11 @@ def main(argv=None):
             eng.step(args.warmup - 1)
         if args.warmup > 0:
             eng.step_timed(1)          # (reads the events too: every host-side path of the timed call has run once)
-        fence()
+        fence("behind the warm-up")
         # ---- timed region: exactly K generations.  Wall clock for `value`; for the kernel's per-launch duration two time stamps
         # bound to the first and the last update-kernel dispatch of the same K generations (bpm_step_timed; it returns with the
         # sampler's queue / stream drained).
+        watch.pending("the timed region: bpm_step_timed (%d generations) + barrier" % args.steps)
         t0 = time.perf_counter()
         eng.step_timed(args.steps, read=False)
         torch.cuda.synchronize()
@@ -847,23 +1187,49 @@ def main(argv=None):
         k_avg_ms = ev_ms / max(n_launch, 1)
         units_per_launch = CHAINS_PER_GPU / 2.0                       # half the local chains per launch
         achieved = units_per_launch * BYTES_PER_UPDATE / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        # cross-check at N = 1: an event pair around every launch (bpm_step_profiled exchanges with the dense all-gather: not part of an N > 1 run)
-        pair_ms, pair_n = eng.step_profiled(32) if world == 1 and not use_dist else (0.0, 1)
+        # cross-check at N = 1, OUTSIDE the timed region and on a scratch sampler: an event pair around every launch.  bpm_step_profiled is part of the
+        # test surface (include/bipymc_hip_test.h): it runs on the test variant of the library -- the same sources, same kernels (steady-state flavour,
+        # launched on the HIP stream) -- never on the sampler whose generations are the number
+        pair_ms, pair_n = 0.0, 1
+        if world == 1 and not use_dist:
+            try:
+                pe = HipEngine(algo=L.ALGO_DREAM, n_chains=n_chains, dim=DIM, target_id=tid, target_params=tparams, seed=42, device=local_rank,
+                               del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3, lib=L.load_test())
+                try:
+                    pe.set_state(X0)
+                    pe.begin_run()
+                    pe.step(16)
+                    pair_ms, pair_n = pe.step_profiled(32)
+                finally:
+                    pe.close()
+            except Exception as e:                                     # noqa: BLE001 -- a cross-check, never fatal
+                sys.stderr.write("bench.py: event-pair cross-check skipped: %s\n" % e)
         fence()
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # HBM bytes per launch from rocprofv3 --pmc (offline)
+        # HBM bytes per launch from rocprofv3 --pmc (offline, separate passes: tools/profile_bench.sh writes the file) -- tied to the library that is
+        # being timed: the file carries the build id of the library the counters were taken on, and another library's counters are not this one's
+        traffic, traffic_note = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
         if os.path.exists(tfile) and world == 1 and CHAINS_PER_GPU == 8192:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            have = L.build_id(eng.lib)
+            if tj.get("build_id") == have:
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_note = "profiles/traffic_cfg2.json, counters taken on this build (%s)" % have
+            else:
+                traffic_note = ("null: profiles/traffic_cfg2.json holds the counters of build %s, the library being timed is %s (re-collect with tools/profile_bench.sh)"
+                                % (tj.get("build_id"), have))
 
         extra = {"evaluated": False}
         if not args.no_moments:
-            # parity gate reported with the number: posterior moments of the post-burn-in rows vs the
-            # analytic ones (mean 0, var_i = i+1), from the on-device reduction over this rank's rows.  A short timed
-            # region (the driver's 20 generations) is extended by untimed generations: 52 correlated generations say nothing.
+            watch.enter("posterior")
+            # the TIMED sampler's own post-burn-in rows vs the analytic moments (mean 0, var_i = i+1), from the on-device reduction over this rank's
+            # history rows: a pooled cross-check (1200 generations of 8192 chains resolve the pooled variance to 0.1 %, a single coordinate to ~0.6 %);
+            # the per-coordinate 1 % gate needs 30-40 times as many generations and runs on a sampler without history (posterior_gate below).  A short
+            # timed region (the driver's 20 generations) is extended by untimed generations: 52 correlated generations say nothing.
             post = args.warmup + args.steps + 32
             if post < POSTERIOR_MIN_GENS:
                 eng.step(POSTERIOR_MIN_GENS - post)
-                fence()
+                fence("posterior extension")
                 post = POSTERIOR_MIN_GENS
             n_burn = (1 + BURNIN_GEN) * n_chains
             cnt, s1, s2, sh = eng.reduce_moments(n_burn)
@@ -879,12 +1245,16 @@ def main(argv=None):
             acc = st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
             vr = float(np.mean(var / sig2))
             mm = float(np.max(np.abs(mean) / np.sqrt(sig2)))
-            extra = dict(evaluated=True, generations=int(post), rows=int(cnt),
-                         # the gate: pooled variance ratio within 1 % of the analytic value, every mean within 0.05 sigma
-                         # (tests/test_gpu_api.py::test_posterior_moments_at_baseline_sizes is the asserted form)
-                         var_ratio_mean=vr, max_abs_mean_over_sigma=mm, gate_pass=bool(abs(vr - 1.0) < 0.01 and mm < 0.05),
-                         var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)),
-                         acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]])
+            pooled_ok = bool(abs(vr - 1.0) < 0.01 and mm < 0.05)
+            extra = dict(evaluated=True,
+                         # the rows of the sampler that was timed: POOLED variance ratio within 1 %, every mean within 0.05 sigma
+                         timed_sampler=dict(generations=int(post), rows=int(cnt), var_ratio_mean=vr, max_abs_mean_over_sigma=mm,
+                                            var_ratio_min=float(np.min(var / sig2)), var_ratio_max=float(np.max(var / sig2)), pooled_gate_pass=pooled_ok,
+                                            note="per-coordinate spread over %d generations is Monte-Carlo noise (standard error ~0.6 %% per coordinate); "
+                                                 "the per-coordinate gate is `gate` below" % post),
+                         acceptance_fraction=acc, p_cr=[float(v) for v in st["p_cr"]],
+                         # overwritten by the per-coordinate gate at N = 1 (posterior_gate); at N > 1 the pooled form over the sharded sampler's rows stands
+                         gate_pass=pooled_ok, gate_kind="pooled, over the timed sampler's rows")
 
         import hashlib
         state_sha = hashlib.sha256(np.ascontiguousarray(eng.get_state()).tobytes()).hexdigest()[:16]   # (A/B of launch paths: same bits)
@@ -948,7 +1318,7 @@ def main(argv=None):
                                              "packet_fence": lstat["fence"]},
                        "final_state_sha256_16": state_sha},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "bpm::phase_fused_kernel<1, 1, 64, 2, 3, %d> (DREAM, Gauss target, 64 lanes/chain, 3 pairs, steady-state instantiation%s)" % ((5, " of the sharded launch mode") if world > 1 else (1, "")),
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
@@ -962,22 +1332,31 @@ def main(argv=None):
             out["config"]["exchange"]["attempts_discarded"] = attempts
             out["config"]["exchange"]["never_measured"] = ("agent-scope packet fences between GPUs (push-agent) have never run on a multi-GPU node; "
                                                            "the headline uses system scope")
-    # ---- N > 1: the exchanges the headline did not use, outside its timed region; never fatal, bounded by a watchdog (a first contact with RCCL
-    # that hangs must not cost the headline its line: the line is then printed without the alternatives and the ranks leave)
+    # From here on rank 0 HAS its line: whatever stalls below, the watchdog prints it (with a "watchdog" entry) and the process ends with
+    # EXIT_WATCHDOG -- the line is kept, the return code is not 0 (the round-4 watchdog ended hung ranks with exit code 0).
+    if rank == 0:
+        watch.headline(out)
+    # ---- N > 1: the exchanges the headline did not use, outside its timed region; a FAILURE of an alternative is recorded in the line, never fatal;
+    # a HANG ends the run through the watchdog (stage "alternatives": the pending collective is named in the line)
+    if dist is not None:
+        out_x = out["config"]["exchange"] if rank == 0 else {}
+        # what the N > 1 number is a number OF: the default exchange is NOT the RCCL all-gather north_star names (that one is
+        # exchange_alternatives[0], mode "dense", measured beside the headline by default)
+        mode = (exchange_info or {}).get("mode")
+        out_x["rccl_ranks"] = rccl_comm_ranks                      # ranks of the RCCL communicator the library created for THIS sampler (null: none exists)
+        out_x["torch_process_group_backend"] = dist.get_backend()
+        if rank == 0:
+            out["config"]["parallelism"] = ("chains sharded x%d, exchange = %s%s" % (
+                world, mode, {"push": " (owners store accepted rows into the peers' replicas through IPC-mapped buffers, %s-scope packet fences; NOT the RCCL "
+                                      "all-gather of north_star: that is exchange_alternatives[mode=dense])" % (exchange_info or {}).get("fence_scope"),
+                              "dense": " (in-place ncclAllGather of a rank block twice per generation: north_star's exchange, demc.py:93-94,116-117)",
+                              "replay": " (ncclAllGather of one accept byte per chain + recomputation of the accepted proposals)",
+                              "rows": " (ncclAllGather of packed accepted rows)"}.get(mode, "")))
     if dist is not None and not args.no_exchange_alternatives:
-        import threading
-
-        def bail():
-            if rank == 0:
-                out["exchange_alternatives"] = [dict(error="the alternative exchanges did not finish within %d s: line printed without them" % ALT_WATCHDOG_S)]
-                json_out.write(json.dumps(out) + "\n")
-                json_out.flush()
-            os._exit(0)
-        dog = threading.Timer(ALT_WATCHDOG_S, bail)
-        dog.daemon = True
-        dog.start()
+        watch.enter("alternatives")
 
         def coll_max(x):
+            _pend("all_reduce(MAX) of the ranks' elapsed times")
             t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -986,31 +1365,55 @@ def main(argv=None):
                                          coll_max, world if dist.get_backend() == "nccl" else None, share_gpu=args.share_gpu)
         except BaseException as e:                                     # noqa: BLE001 -- never fatal
             alts = [dict(error="%s: %s" % (type(e).__name__, e))]
-        dog.cancel()
         if rank == 0:
             out["exchange_alternatives"] = alts
+    elif dist is not None and rank == 0:
+        out["exchange_alternatives"] = [dict(skipped="--no-exchange-alternatives")]
+    watch.enter("teardown")
     if dist is not None:
+        watch.pending("dist.barrier before bpm_destroy")
         dist.barrier()                                                 # (the library orders the teardown itself; this keeps the ranks' exits together)
+    watch.pending("bpm_destroy")
     eng.close()
     if rank == 0:
+        watch.enter("extras")
         if world == 1 and not use_dist and not args.no_other_configs and CHAINS_PER_GPU == 8192:
+            watch.pending("other_configs")
             out["configs"] = other_configs(local_rank)
             try:
                 out["configs"].append(host_callback_config(local_rank))
             except Exception as e:                                     # noqa: BLE001
                 out["configs"].append(dict(config="cfg2 shape with a host-callback ln_like_fn", error=str(e)))
-            if not args.no_moments:
+        if world == 1 and not use_dist and not args.no_moments and CHAINS_PER_GPU == 8192:
+            # the per-coordinate gate (every variance within 1 %, every mean within 0.01 sigma, batch-means standard errors): cfg2 from exact draws
+            # -- this defines posterior.gate_pass -- and from the reference's start; cfg3 and cfg5; the reference's own scenario beside its family
+            for key, fn in (("gate", lambda: posterior_gate(local_rank, start="exact")),
+                            ("gate_from_reference_start", lambda: posterior_gate(local_rank, start="reference")),
+                            ("gates_other_configs", lambda: posterior_gates_other_configs(local_rank)),
+                            ("reference_scenarios", lambda: reference_scenario_on_the_device(local_rank))):
+                watch.pending("posterior." + key)
                 try:
-                    out["posterior"]["start_alternatives"] = [posterior_from_reference_start(local_rank)]
+                    out["posterior"][key] = fn()
                 except Exception as e:                                 # noqa: BLE001
-                    out["posterior"]["start_alternatives"] = [dict(start="the reference's: theta_0 = 0, varepsilon = 1e-6", error=str(e))]
+                    out["posterior"][key] = dict(error=str(e))
+            g = out["posterior"]["gate"]
+            if isinstance(g, dict) and "gate_pass" in g:
+                out["posterior"]["gate_pass"] = bool(g["gate_pass"])
+                out["posterior"]["gate_kind"] = ("per coordinate: every variance within %g, every |mean| within %g sigma over %d generations "
+                                                 "(posterior.gate); batch-means standard errors beside each" % (GATE_VAR_TOL, GATE_MEAN_TOL, g.get("generations", 0)))
+                for k in ("var_ratio_min", "var_ratio_max", "var_ratio_mean", "max_abs_mean_over_sigma", "mcse_var_ratio_max", "mcse_mean_over_sigma_max"):
+                    out["posterior"][k] = g.get(k)
         if world == 1 and not args.no_cpu_baseline:
+            watch.pending("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline()
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+        out["stage_seconds"] = watch.history + [(watch.stage, round(time.time() - watch.t_stage, 2))]
+        write_line(json.dumps(out))
     if dist is not None:
+        watch.enter("teardown")
+        watch.pending("final dist.barrier / destroy_process_group")
         dist.barrier()
         dist.destroy_process_group()
+    watch.done()
     return 0
 
 

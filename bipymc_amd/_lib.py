@@ -57,6 +57,7 @@ _H = C.c_void_p
 SIGNATURES = {
     "bpm_last_error": (C.c_char_p, []),
     "bpm_abi_version": (C.c_int, []),
+    "bpm_build_id": (C.c_char_p, []),
     "bpm_device_count": (C.c_int, [_ip]),
     "bpm_get_unique_id": (C.c_int, [C.c_char_p]),
     "bpm_create": (C.c_int, [_P(BpmConfig), _P(_H)]),
@@ -70,9 +71,7 @@ SIGNATURES = {
     "bpm_step": (C.c_int, [_H, C.c_int64]),
     "bpm_step_timed": (C.c_int, [_H, C.c_int64, _P(C.c_float), _P(C.c_int64)]),
     "bpm_get_step_time": (C.c_int, [_H, _P(C.c_float), _P(C.c_int64)]),
-    "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
     "bpm_synchronize": (C.c_int, [_H]),
-    "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),
     "bpm_set_exchange": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bpm_get_exchange_stats": (C.c_int, [_H, _P(C.c_int64)]),
     "bpm_push_export": (C.c_int, [_H, C.c_void_p]),
@@ -90,12 +89,14 @@ SIGNATURES = {
     "bpm_get_stats": (C.c_int, [_H, _P(BpmStats)]),
     "bpm_set_adapt_state": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64]),
     "bpm_eval_loglike": (C.c_int, [_H, _dp, C.c_int32, _dp]),
-    "bpm_set_trace": (C.c_int, [_H, C.c_int32]),
-    "bpm_get_trace": (C.c_int, [_H, _ip, _dp, _u8p]),
 }
 
 # include/bipymc_hip_test.h: exported by the test variant only
 TEST_SIGNATURES = {
+    "bpm_local_group_step": (C.c_int, [_P(_H), C.c_int32, C.c_int64]),
+    "bpm_step_profiled": (C.c_int, [_H, C.c_int64, _dp, _P(C.c_int64)]),
+    "bpm_set_trace": (C.c_int, [_H, C.c_int32]),
+    "bpm_get_trace": (C.c_int, [_H, _ip, _dp, _u8p]),
     "bpm_debug_destroy_plan": (C.c_int, [C.c_int32, C.c_int32]),
     "bpm_debug_fail_queue": (C.c_int, [_H, C.c_int32]),
     "bpm_debug_queue_pad": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
@@ -127,6 +128,30 @@ def load():
     return _lib
 
 
+# The files a library's build id is the SHA-256 of, in this order (bipymc_amd/csrc/Makefile: ID_SRCS)
+_ID_SRCS = ("csrc/sampler.hip", "csrc/kernels.h", "csrc/kernels_wide.h", "csrc/philox.h", "csrc/rocrand_check.h", "csrc/aql_queue.h",
+            "../include/bipymc_hip.h", "../include/bipymc_hip_test.h", "csrc/Makefile")
+
+
+def source_id():
+    """The build id of the sources IN THE TREE: first 16 hex digits of the SHA-256 over _ID_SRCS' bytes -- what bpm_build_id() of a library built
+    from them returns (the Makefile bakes it in).  None when a source file is missing (an installation without sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in _ID_SRCS:
+        path = os.path.join(_HERE, rel)
+        if not os.path.exists(path):
+            return None
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_id(lib):
+    v = lib.bpm_build_id()
+    return v.decode("ascii", "replace") if v else ""
+
+
 def _bind(path, hooks):
     """hooks: True = the test surface must be there, None = bind it when it is (BPM_LIB_PATH may name a test / experiment build)"""
     lib = C.CDLL(path)       # RTLD_LOCAL: the product and the test variant define the same symbols and may live in one process
@@ -142,6 +167,11 @@ def _bind(path, hooks):
         fn.argtypes = args
     if lib.bpm_abi_version() != ABI_VERSION:
         raise ImportError("bipymc_amd: %s ABI %d != binding ABI %d" % (os.path.basename(path), lib.bpm_abi_version(), ABI_VERSION))
+    # stale-binary guard: *.so is built in-tree and travels to the GPU box as built; what runs must be what the tree says
+    want, have = source_id(), build_id(lib)
+    if want is not None and have != want and os.environ.get("BPM_ALLOW_STALE_LIB", "0") != "1":
+        raise ImportError("bipymc_amd: %s was built from other sources (its build id %s, the tree's %s): rebuild with `make -C bipymc_amd/csrc` "
+                          "(or __graft_entry__.build(force=True)); BPM_ALLOW_STALE_LIB=1 loads it anyway" % (path, have, want))
     return lib
 
 

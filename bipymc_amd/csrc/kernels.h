@@ -49,6 +49,7 @@
 #endif
 
 namespace bpm {
+inline namespace BPM_VARIANT_NS {      // (philox.h: one kernel-symbol namespace per build variant)
 
 constexpr int ALGO_DEMC = 0, ALGO_DREAM = 1;
 constexpr int TARGET_HOST = 0, TARGET_GAUSS = 1, TARGET_MIXTURE = 2, TARGET_BANANA = 3;
@@ -172,9 +173,11 @@ struct PhaseArgs {
     double* prop_buf;      // host-callback path: [n_local * ld] proposals by work item
     double* aux_buf;       // host-callback path: [n_local * 2] (log_corr, ll_prop)
     int32_t* ids_buf;      // host-callback path: [n_local] global id by work item (-1 = inactive)
-    int32_t* trace_i32;    // optional debug trace [n_local * TRACE_I32]
-    double* trace_f64;     // [n_local * TRACE_F64]
+#ifdef BPM_TEST_HOOKS      // the per-chain decision trace of the parity tests: test variant only (include/bipymc_hip_test.h: bpm_set_trace); the PRODUCT's
+    int32_t* trace_i32;    // argument block has no such fields and its kernels no traced branch (trace_i32_of & co. below are compile-time null there)
+    double* trace_f64;     // [n_local * TRACE_F64]   ([n_local * TRACE_I32] above)
     uint8_t* trace_mask;   // [n_local * dim]
+#endif
     PermKey pk;
     const uint32_t* perm_tab;   // [N] shuffle order of this generation, position -> chain id (nullptr: evaluate the bijection)
     const uint32_t* inv_tab;    // [N] its inverse, chain id -> position
@@ -238,6 +241,20 @@ struct PhaseArgs {
     uint32_t lean, pad_lean;
 #endif
 };
+
+// The trace pointers of an argument block: fields of the test variant only (-DBPM_TEST_HOOKS); in the product library these are compile-time null
+// pointers, so every `if (trace_i32_of(a))` branch folds away and the argument block carries nothing of the test surface.
+#ifdef BPM_TEST_HOOKS
+__host__ __device__ __forceinline__ int32_t* trace_i32_of(const PhaseArgs& a) { return a.trace_i32; }
+__host__ __device__ __forceinline__ double* trace_f64_of(const PhaseArgs& a) { return a.trace_f64; }
+__host__ __device__ __forceinline__ uint8_t* trace_mask_of(const PhaseArgs& a) { return a.trace_mask; }
+__host__ __device__ __forceinline__ void trace_set(PhaseArgs& a, int32_t* i, double* f, uint8_t* m) { a.trace_i32 = i; a.trace_f64 = f; a.trace_mask = m; }
+#else
+__host__ __device__ constexpr int32_t* trace_i32_of(const PhaseArgs&) { return nullptr; }
+__host__ __device__ constexpr double* trace_f64_of(const PhaseArgs&) { return nullptr; }
+__host__ __device__ constexpr uint8_t* trace_mask_of(const PhaseArgs&) { return nullptr; }
+__host__ __device__ __forceinline__ void trace_set(PhaseArgs&, int32_t*, double*, uint8_t*) {}
+#endif
 
 // Sum over the LPC lanes of a chain subgroup, result in every lane of the subgroup.
 // Cross-lane moves are DPP (no LDS traffic, ~8 cycles each instead of a ds_bpermute round trip):
@@ -813,7 +830,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     uint32_t snk_id[3] = {0u, 0u, 0u};
     if (SNK_DIRECT && snk_possible && planned) {
         snk_id[0] = rec[5 + 2 * P]; snk_id[1] = rec[6 + 2 * P]; snk_id[2] = rec[7 + 2 * P];
-    } else if (SNK_DIRECT && snk_possible && (u_sel < a.p_snooker || a.trace_i32 != nullptr)) {
+    } else if (SNK_DIRECT && snk_possible && (u_sel < a.p_snooker || trace_i32_of(a) != nullptr)) {
         // three distinct snooker partners, one Philox block -- only for the lanes whose update IS a snooker update (one in ten at the
         // BASELINE setting): the three table lookups per lane are scattered 4-byte loads (the trace records them for every chain)
         const u32x4 ws = chain_block(a.seed, c, a.t, SLOT_SNK);
@@ -1043,9 +1060,9 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
             }
         }
     }
-    if (a.trace_i32 && active) {
+    if (trace_i32_of(a) && active) {
         if (q == 0) {
-            int32_t* tr = a.trace_i32 + (uint64_t)(c - a.lo) * TRACE_I32;
+            int32_t* tr = trace_i32_of(a) + (uint64_t)(c - a.lo) * TRACE_I32;
             tr[0] = wk.cr_idx; tr[1] = wk.d_prime; tr[2] = wk.jump; tr[4] = wk.snk;
             if (REGS) {
 #pragma unroll
@@ -1060,18 +1077,19 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
                 tr[5 + i] = v;
             }
         }
-        if (a.trace_mask) {
+        if (trace_mask_of(a)) {
 #pragma unroll
             for (int s = 0; s < DPL; ++s) {
                 const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (s & 1);
-                if (j < dim) a.trace_mask[(uint64_t)(c - a.lo) * dim + j] = (uint8_t)((maskbits >> s) & 1u);
+                if (j < dim) trace_mask_of(a)[(uint64_t)(c - a.lo) * dim + j] = (uint8_t)((maskbits >> s) & 1u);
             }
         }
     }
 }
 
 // Metropolis test (samplers.py:328-336), append (chain.py:51-54), Welford moments, CR outputs.
-template <int ALGO, int LPC, int DPL, int LEAN = 0 /* 0 never, 1 when a.lean, 2 always */>
+// CRP_W: this kernel flavour sums level 1 of the CR reduction itself (phase_fused_kernel: CRP) -- the only one that may leave the chains' CR slots unwritten.
+template <int ALGO, int LPC, int DPL, int LEAN = 0 /* 0 never, 1 when a.lean, 2 always */, bool CRP_W = false>
 __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bool active, int q,
                                               const Work<DPL>& wk, double ll_prop) {
     const uint32_t ld = a.L.ld;
@@ -1197,7 +1215,7 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
         // update kernels sum level 1 themselves (cr_part1).  Every generation of an adaptation phase rewrites every chain's slots before its reduction
         // reads them, so nothing has to be written in between: until round 4 every DREAM update stored "no statistic" here -- two scattered 8-byte
         // write-through stores per update in the steady state (cfg5: 44.5 -> ... us per generation without them).
-        if (q == 0 && a.adapt_on && a.cr_part1 == nullptr) {
+        if (q == 0 && a.adapt_on && !(CRP_W && a.cr_part1 != nullptr)) {      // (structural: a flavour that cannot write level 1 ALWAYS writes the slots)
             const bool gated = a.adapt_on && a.cr_gate;
             if (a.wt) {
                 __hip_atomic_store(delta_ptr(a.L, c), gated ? wk.delta : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1208,9 +1226,9 @@ __device__ __forceinline__ void finish_update(const PhaseArgs& a, uint32_t c, bo
             }
         }
     }
-    if (a.trace_i32 && q == 0) {
-        a.trace_i32[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
-        double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
+    if (trace_i32_of(a) && q == 0) {
+        trace_i32_of(a)[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
+        double* tf = trace_f64_of(a) + (uint64_t)li * TRACE_F64;
         tf[0] = alpha; tf[1] = ll_prop; tf[2] = wk.delta; tf[3] = wk.gamma;
     }
     // push exchange: a wavefront ends only when its stores into the peers' replicas have been acknowledged at system scope (gfx942 / gfx950 count
@@ -1234,7 +1252,7 @@ __device__ __forceinline__ void pin_args(const PhaseArgs& a) {
     if (LPC != WAVE) {
         asm volatile("" ::"s"(a.L.G), "s"(a.L.ld), "s"(a.L.dim), "s"(a.ll), "s"(a.hist_row), "s"(a.llhist_row), "s"(a.tparams),
                      "s"(a.cr_state), "s"(a.acc_count), "s"(a.perm_tab), "s"(a.inv_tab), "s"(a.gamma_tab), "s"(a.plan), "s"(a.pack),
-                     "s"(a.trace_i32), "s"(a.thr[0]), "s"(a.thr[1]), "s"(a.thr[2]), "s"(a.seed), "s"(a.t), "s"(a.k), "s"(a.N),
+                     "s"(a.thr[0]), "s"(a.thr[1]), "s"(a.thr[2]), "s"(a.seed), "s"(a.t), "s"(a.k), "s"(a.N),
                      "s"(a.lo), "s"(a.upd_off), "s"(a.n_upd), "s"(a.pool_off), "s"(a.M), "s"(a.mode), "s"(a.n_items), "s"(a.n_cr));
         asm volatile("" ::"s"(a.adapt_on), "s"(a.cr_gate), "s"(a.hist_len), "s"(a.epsilon), "s"(a.u_epsilon), "s"(a.L.n_local),
                      "s"(a.L.world), "s"(a.L.magic), "s"(a.counters), "s"(a.pack_cap), "s"(a.pack_nsub), "s"(a.pack_stride));
@@ -1261,13 +1279,13 @@ __device__ __forceinline__ bool resolve_chain(const PhaseArgs& a, uint32_t w, ui
 // 3 / 4 = the same during DREAM's CR adaptation (burn-in), 5 / 6 = a rank of a multi-GPU world in the steady state
 // with the replay exchange (accept bytes; its compacted records when 5, none when 6); 0 = the general kernel.
 __host__ inline bool phase_args_hot_sharded(const PhaseArgs& a, bool dream, bool with_plan) {
-    return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+    return a.mode == 0 && (a.rec_tab != nullptr) == with_plan && trace_i32_of(a) == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            a.adapt_on == 0 && a.epsilon > 0.0 && a.L.world > 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.stamps == nullptr && (a.accbits != nullptr || a.n_peers > 0) && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
 }
 __host__ inline bool phase_args_hot(const PhaseArgs& a, bool dream, bool with_plan, bool adapting) {
-    return a.n_peers == 0 && a.mode == 0 && (a.rec_tab != nullptr) == with_plan && a.trace_i32 == nullptr && a.pack == nullptr && a.x_next == nullptr &&
+    return a.n_peers == 0 && a.mode == 0 && (a.rec_tab != nullptr) == with_plan && trace_i32_of(a) == nullptr && a.pack == nullptr && a.x_next == nullptr &&
            (a.adapt_on != 0) == adapting && a.epsilon > 0.0 && a.L.world == 1 &&
            a.perm_tab != nullptr && a.inv_tab != nullptr && a.lo == 0 && a.stamps == nullptr && a.accbits == nullptr && a.replay == 0 &&
            (!dream || (a.u_epsilon > 0.0 && a.n_cr == 3));
@@ -1293,7 +1311,7 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     PhaseArgs a_hot;
     if (COPY) {
         a_hot = a_in;
-        a_hot.mode = 0u; a_hot.trace_i32 = nullptr; a_hot.trace_f64 = nullptr; a_hot.trace_mask = nullptr; a_hot.pack = nullptr;
+        a_hot.mode = 0u; trace_set(a_hot, nullptr, nullptr, nullptr); a_hot.pack = nullptr;
         a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
         if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; a_hot.acc_by_item = 0u; a_hot.n_peers = 0u; a_hot.peer_tab = nullptr; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
@@ -1301,7 +1319,10 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     }
     const PhaseArgs& a = COPY ? a_hot : a_in;
     if (HOT) {
-        __builtin_assume(a_in.mode == 0u); __builtin_assume(a_in.trace_i32 == nullptr); __builtin_assume(a_in.pack == nullptr);
+        __builtin_assume(a_in.mode == 0u); __builtin_assume(a_in.pack == nullptr);
+#ifdef BPM_TEST_HOOKS
+        __builtin_assume(a_in.trace_i32 == nullptr);
+#endif
         __builtin_assume(a_in.x_next == nullptr); __builtin_assume(a_in.adapt_on == (ADAPT ? 1u : 0u)); __builtin_assume(a_in.stamps == nullptr);
         if (!SHARD) { __builtin_assume(a_in.lo == 0); __builtin_assume(a_in.L.world == 1); }
         __builtin_assume(a_in.epsilon > 0.0);
@@ -1380,7 +1401,7 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     }
     const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
     BPM_STAMP(5);
-    finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0))>(a, c, active, q, wk, ll_prop);
+    finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0)), CRP>(a, c, active, q, wk, ll_prop);
     if (CRP && active && a.adapt_on && a.cr_gate) { cr_d = wk.delta; cr_i = wk.cr_idx; }      // what finish_update wrote into the chain's slots
     BPM_STAMP(6);
 #ifdef BPM_STAMPS
@@ -1441,7 +1462,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_replay_kernel(const Phas
     PhaseArgs a_rep;
     if (LPC == WAVE) {
         a_rep = a_in;
-        a_rep.replay = 1u; a_rep.adapt_on = 0u; a_rep.trace_i32 = nullptr; a_rep.trace_f64 = nullptr; a_rep.trace_mask = nullptr;
+        a_rep.replay = 1u; a_rep.adapt_on = 0u; trace_set(a_rep, nullptr, nullptr, nullptr);
         a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u; a_rep.n_peers = 0u;
     }
     const PhaseArgs& a = (LPC == WAVE) ? a_rep : a_in;
@@ -1483,7 +1504,7 @@ template <int ALGO, int DPL, int NP>
 __global__ __launch_bounds__(REPLAY_WG) void phase_replay_sorted_kernel(const PhaseArgs a_in) {
     constexpr int LPC = WAVE;
     PhaseArgs a_rep = a_in;
-    a_rep.replay = 1u; a_rep.adapt_on = 0u; a_rep.trace_i32 = nullptr; a_rep.trace_f64 = nullptr; a_rep.trace_mask = nullptr;
+    a_rep.replay = 1u; a_rep.adapt_on = 0u; trace_set(a_rep, nullptr, nullptr, nullptr);
     a_rep.pack = nullptr; a_rep.x_next = nullptr; a_rep.stamps = nullptr; a_rep.mode = 1u; a_rep.accbits = nullptr;
     const PhaseArgs& a = a_rep;
     __shared__ uint32_t s_part[(REPLAY_WG / WAVE) * MAX_PARTNERS];
@@ -2485,4 +2506,5 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_final_kernel(const double
     if (threadIdx.x == 0) { out[j] = s_a[0]; out[ld + j] = s_b[0]; }
 }
 
+}  // inline namespace BPM_VARIANT_NS
 }  // namespace bpm

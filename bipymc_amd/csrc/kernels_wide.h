@@ -31,6 +31,7 @@
 #include "kernels.h"
 
 namespace bpm {
+inline namespace BPM_VARIANT_NS {      // (philox.h: one kernel-symbol namespace per build variant)
 
 constexpr int WIDE_CP = 2;                          // coordinate pairs per lane and chunk: 7 rows x 2 loads of 16 bytes in flight per lane
 constexpr int WIDE_CHUNK_PAIRS = WAVE * WIDE_CP;    // 128 pairs = 256 coordinates per chunk
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
             if (valid) {
                 if (hrow) wide_store2_stream(hrow, pi, x.x, x.y);           // speculative: the update will most likely be rejected
                 if (prow) reinterpret_cast<double2*>(prow)[pi] = make_double2(p0, p1);
-                if (a.trace_mask) {
+                if (trace_mask_of(a)) {
                     const uint32_t j0 = 2u * pi;
-                    a.trace_mask[(uint64_t)li * U.dim + j0] = (uint8_t)(mb & 1u);
-                    if (j0 + 1u < U.dim) a.trace_mask[(uint64_t)li * U.dim + j0 + 1u] = (uint8_t)((mb >> 1) & 1u);
+                    trace_mask_of(a)[(uint64_t)li * U.dim + j0] = (uint8_t)(mb & 1u);
+                    if (j0 + 1u < U.dim) trace_mask_of(a)[(uint64_t)li * U.dim + j0 + 1u] = (uint8_t)((mb >> 1) & 1u);
                 }
             }
         }
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
         n2p = gsum<WAVE>(n2p);
         log_corr = 0.5 * (double)(U.dim - 1u) * (log(n2p) - log(sn_n2));
     }
-    if (a.trace_i32) {
-        int32_t* tr = a.trace_i32 + (uint64_t)li * TRACE_I32;
+    if (trace_i32_of(a)) {
+        int32_t* tr = trace_i32_of(a) + (uint64_t)li * TRACE_I32;
         if (lane == 0) { tr[0] = cr_idx; tr[1] = d_prime; tr[2] = jump; tr[4] = U.snk; }
         if (lane < (uint32_t)MAX_PARTNERS) tr[5 + lane] = lane < npart ? (int32_t)mine : -1;      // (lane i resolved partner i)
     }
@@ -388,9 +389,9 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
                 }
             }
         }
-        if (a.trace_i32) {
-            a.trace_i32[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
-            double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
+        if (trace_i32_of(a)) {
+            trace_i32_of(a)[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
+            double* tf = trace_f64_of(a) + (uint64_t)li * TRACE_F64;
             tf[0] = alpha; tf[1] = ll_prop; tf[2] = delta; tf[3] = U.gamma;
         }
     }
@@ -473,9 +474,9 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_commit_kernel(const
         if (accepted) { a.acc_count[li] = acc_prev + 1u; a.ll[li] = new_ll; }
         if (is_nan) atomicAdd(&a.counters[2], 1ull);
         if (a.llhist_row) a.llhist_row[li] = new_ll;
-        if (a.trace_i32) {
-            a.trace_i32[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
-            double* tf = a.trace_f64 + (uint64_t)li * TRACE_F64;
+        if (trace_i32_of(a)) {
+            trace_i32_of(a)[(uint64_t)li * TRACE_I32 + 3] = accepted ? 1 : 0;
+            double* tf = trace_f64_of(a) + (uint64_t)li * TRACE_F64;
             tf[0] = alpha; tf[1] = ll_prop; tf[2] = DREAM ? *delta_ptr(a.L, c) : 0.0; tf[3] = 0.0;
         }
     }
@@ -533,4 +534,5 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void eval_ll_wide_kernel(const doub
     if (lane == 0) out[w] = ll;
 }
 
+}  // inline namespace BPM_VARIANT_NS
 }  // namespace bpm

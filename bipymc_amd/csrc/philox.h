@@ -20,7 +20,20 @@
 #define BPM_HD inline
 #endif
 
+// Every build variant of the library puts its device code into an inline namespace of its own (bpm::product, bpm::hooks, bpm::v_<name>): source code
+// is unaffected, but the KERNEL SYMBOLS differ.  The library's own AQL queue locates its kernels BY NAME among the code objects the HSA loader holds
+// (aql_queue.h: DirectQueue::kernel), and a process may hold the product and the test variant at once (tests, bench.py's cross-check): with equal names
+// the second library dispatched the FIRST library's kernels -- harmless while both were the same code, a memory fault at address 0 as soon as the test
+// variant's argument block carried trace fields the product's does not (round 5).
+#ifndef BPM_VARIANT_NS
+#ifdef BPM_TEST_HOOKS
+#define BPM_VARIANT_NS hooks
+#else
+#define BPM_VARIANT_NS product
+#endif
+#endif
 namespace bpm {
+inline namespace BPM_VARIANT_NS {
 
 // ---- draw layout (keep equal to oracle/philox_ref.py) ----------------------
 constexpr int SLOT_BITS = 16;
@@ -185,4 +198,5 @@ inline bool flip_draw(uint64_t seed, uint64_t t, double flip_prob) {
     return u01_32(global_block(seed, t, SLOT_G_FLIP).x) < flip_prob;
 }
 
+}  // inline namespace BPM_VARIANT_NS
 }  // namespace bpm

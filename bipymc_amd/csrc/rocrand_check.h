@@ -8,6 +8,7 @@
 #include "philox.h"
 
 namespace bpm {
+inline namespace BPM_VARIANT_NS {      // (philox.h: one kernel-symbol namespace per build variant)
 
 __global__ void rocrand_check_kernel(uint32_t* out, int n, uint64_t seed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,4 +29,5 @@ inline void launch_rocrand_check(uint32_t* out, int n, uint64_t seed) {
     hipLaunchKernelGGL(rocrand_check_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, out, n, seed);
 }
 
+}  // inline namespace BPM_VARIANT_NS
 }  // namespace bpm

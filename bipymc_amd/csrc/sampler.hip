@@ -149,6 +149,9 @@ static inline hipEvent_t take_stop_event() {
 typedef void (*PhaseLaunch)(const PhaseArgs&, hipStream_t);
 typedef void (*EvalLaunch)(const double*, uint32_t, uint32_t, uint32_t, const double*, double*, hipStream_t);
 
+// update launches of the generation being run that took a flavour which writes level 1 of the CR reduction ITSELF (kernels.h: CRP): what
+// finish_generation holds against the host's prediction (gen_cr_inkernel) before it lets cr_final_kernel fold the partial sums
+static thread_local int g_crp_launched = 0;
 static inline uint32_t grid_for(uint32_t n_items, int lpc) {
     const uint32_t cpw = (uint32_t)(block_for(lpc) / lpc);
     return (n_items + cpw - 1) / cpw;
@@ -219,6 +222,7 @@ static inline void launch_packed(K kernel, hipFunction_t& fn, const PhaseArgs& a
 template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
     static hipFunction_t fn = nullptr;
+    if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL)) ++g_crp_launched;
     constexpr unsigned blk = (unsigned)block_for_hot(LPC, HOT, DPL), cpw = blk / (unsigned)LPC;      // (burn-in flavours of one wavefront per chain: 16 chains per workgroup)
     launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, (a.n_items + cpw - 1u) / cpw, blk, s);
 }
@@ -424,7 +428,7 @@ struct bpm_sampler {
     double* h_aux = nullptr;
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
-    int32_t* trace_i32 = nullptr;
+    int32_t* trace_i32 = nullptr;      // per-chain decision trace (bpm_set_trace: test variant only; always null in the product library)
     double* trace_f64 = nullptr;
     uint8_t* trace_mask = nullptr;
     double* scratch = nullptr;   // small device scratch (theta0, var, moments)
@@ -814,6 +818,12 @@ static inline long long now_ns() { return std::chrono::duration_cast<std::chrono
 static int destroy_plan(int queue_failed, int quiesced) { return (queue_failed != 0 && quiesced == 0) ? 0 : 1; }
 extern "C" const char* bpm_last_error(void) { return g_err.c_str(); }
 extern "C" int bpm_abi_version(void) { return BPM_ABI_VERSION; }
+// Which sources is this binary?  The Makefile bakes in the first 16 hex digits of the SHA-256 over sampler.hip, the kernel headers, both C headers and
+// the Makefile itself (ID_SRCS, in that order); bipymc_amd/_lib.py recomputes it from the tree and refuses a library built from other sources.
+#ifndef BPM_BUILD_ID
+#define BPM_BUILD_ID "unknown"
+#endif
+extern "C" const char* bpm_build_id(void) { return BPM_BUILD_ID; }
 extern "C" int bpm_device_count(int32_t* out) {
     if (!out) return fail("bpm_device_count: null argument");
     int n = 0;
@@ -1151,6 +1161,10 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // bpm_local_group_step drives them in lock-step and does the all-gather with device copies.  It runs the
     // very kernels, layouts and host logic of a multi-GPU run (everything but RCCL) where only one GPU exists.
     if (cfg->nccl_uid && std::memcmp(cfg->nccl_uid, "BPMLOCAL", 8) == 0) {
+#ifndef BPM_TEST_HOOKS
+        bpm_destroy(s);
+        return fail("bpm_create: local rank groups (a nccl_uid starting with BPMLOCAL, driven by bpm_local_group_step) exist only in the test variant of the library (include/bipymc_hip_test.h)");
+#endif
         s->local_group = true;
         if (test_path("groupqueues") && s->dq) {
             bpm::DirectQueue* q = bpm::DirectQueue::create_private(cfg->device);
@@ -1259,6 +1273,10 @@ extern "C" int bpm_set_loglike(bpm_handle_t s, const double* ll_local) {
     CK(check_handle(s));
     CK(set_device(s));
     if (!ll_local) return fail("bpm_set_loglike: null argument");
+    // (the lean kernels never read the cache and refresh_ll would overwrite what a caller put there, a history row appended by position
+    // would get its ln-likes by chain -- and nothing needs the call for a device target: the library evaluates the cache itself, reset_history)
+    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK)
+        return fail("bpm_set_loglike: host-callback targets only (a sampler with a device target evaluates ln_like of its chains itself)");
     HIPCK(hipMemcpyAsync(s->ll, ll_local, s->n_local * sizeof(double), hipMemcpyHostToDevice, s->stream));
     // the log-like history row of the current state: row 0 after (re)initialisation, the LAST row after a warm start
     // (bpm_set_history with a host-callback target could only leave NaN there; older rows stay NaN: the reference's
@@ -1466,9 +1484,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         a.prop_buf = s->prop_buf;
         a.aux_buf = s->aux_buf;
         a.ids_buf = s->ids_buf;
-        a.trace_i32 = s->trace_i32;
-        a.trace_f64 = s->trace_f64;
-        a.trace_mask = s->trace_mask;
+        trace_set(a, s->trace_i32, s->trace_f64, s->trace_mask);      // (test variant only: the product's argument block has no trace fields)
         a.pk = pk;
         a.perm_tab = s->perm_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
         a.inv_tab = s->inv_tab + (uint64_t)(s->t_abs - s->tab_t0) * s->N;
@@ -1555,6 +1571,8 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     // CR reduction, level 1 (kernels.h): written by the update kernels themselves when BOTH launches of the generation take a burn-in flavour
     // (HOT 3 / 4: single GPU, work item = position, no trace ...: the predicate launch_fused applies), else computed from the slots in finish_generation
     s->gen_cr_inkernel = false;
+    g_crp_launched = 0;
+#ifdef BPM_PRELOAD      // (the specialised flavours exist only in the preload build: without it every launch ends in the general kernel, which writes the slots)
     if (s->gen_cr_reduce && dream && s->cfg.target_id != BPM_TARGET_HOST_CALLBACK && s->shape.idx != SHAPE_WIDE && crp_shape(s->shape.lpc, s->shape.dpl) &&
         !test_path("nohot") && !test_path("crslots")) {
         bool ok = true;
@@ -1572,6 +1590,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             s->gen_cr_inkernel = true;
         }
     }
+#endif
     return 0;
 }
 
@@ -1584,7 +1603,18 @@ static int finish_generation(bpm_sampler* s) {
         const uint32_t n_cr = (uint32_t)s->cfg.n_cr;
         const int fence = s->dq_fence | bpm::DirectQueue::ACQUIRE;      // (a few hundred bytes, all through agent-scope stores: no release on these packets)
         if (g_dq) g_dq_need_acquire = false;
-        if (!s->gen_cr_inkernel) {
+        // The host PREDICTED (prepare_generation) that both launches take a flavour that writes level 1 itself; what was launched decides.  Every
+        // flavour that does not write level 1 writes the chains' slots (kernels.h: finish_update<..., CRP_W>), so "none did" falls back to
+        // cr_level1_kernel over the slots; a mix of the two would fold stale partial sums into p_cr -- an error, never a silent result.
+        bool level1_from_slots = !s->gen_cr_inkernel;
+        if (s->gen_cr_inkernel) {
+            const int want = (s->cur_args[0].n_items > 0 ? 1 : 0) + (s->cur_args[1].n_items > 0 ? 1 : 0);
+            if (g_crp_launched == 0 && want > 0) level1_from_slots = true;
+            else if (g_crp_launched != want)
+                return fail("CR reduction: " + std::to_string(g_crp_launched) + " of " + std::to_string(want) + " update launches of generation " + std::to_string((long long)s->t_abs) +
+                            " wrote their level-1 partial sums (launch_fused's flavour choice and prepare_generation's prediction disagree)");
+        }
+        if (level1_from_slots) {
             const PhaseArgs& a0 = s->cur_args[0];
             typedef void (*L1K)(Layout, PermKey, const uint32_t*, uint32_t, uint32_t, uint32_t, double*);
             const L1K l1 = s->cr_g1 == 4u ? cr_level1_kernel<4> : (s->cr_g1 == 16u ? cr_level1_kernel<16> : cr_level1_kernel<64>);
@@ -1902,7 +1932,7 @@ static int exchange_replay(const Group& g, int ph) {
         a.replay = 1u;
         a.accbits = nullptr;
         a.accbits_all = s->accbits_all;
-        a.trace_i32 = nullptr; a.trace_f64 = nullptr; a.trace_mask = nullptr;
+        trace_set(a, nullptr, nullptr, nullptr);
         a.pack = nullptr; a.hist_row = nullptr; a.llhist_row = nullptr; a.adapt_on = 0u;
         launch_replay_any(s, a);
         if (local_serial(g)) HIPCK(hipStreamSynchronize(s->stream));
@@ -2124,7 +2154,8 @@ static int run_generations(const Group& g, int64_t n_gens) {
     return 0;
 }
 
-// Lock-step driver of a local group (see bpm_create): handles[r] = rank r of R, all on one GPU.
+#ifdef BPM_TEST_HOOKS
+// Lock-step driver of a local group (see bpm_create): handles[r] = rank r of R, all on one GPU.  Test variant only (include/bipymc_hip_test.h).
 extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens) {
     if (!handles || R < 1) return fail("bpm_local_group_step: bad argument");
     for (int r = 0; r < R; ++r) {
@@ -2141,6 +2172,7 @@ extern "C" int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_
     for (int r = 0; r < R; ++r) CK(leave_direct(handles[r]));      // (ranks with queues of their own: everything is enqueued on all of them by now)
     return group_sync(g);
 }
+#endif   // BPM_TEST_HOOKS
 
 extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     CK(check_handle_keep_direct(s));
@@ -2148,7 +2180,7 @@ extern "C" int bpm_step(bpm_handle_t s, int64_t n_gens) {
     // (a rank of a local group with a queue of its own and the push exchange is as independent as a process of its own: one host
     // thread per rank may drive it through bpm_step, the ranks then meet in the cross-rank barrier kernels like the ranks of a world)
     if (s->local_group && !(s->dq_private && s->push_connected && s->push_enabled))
-        return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step");
+        return fail("bpm_step: ranks of a local test group are driven by bpm_local_group_step (test variant)");
     if (!s->run_open) return fail("bpm_step: call bpm_begin_run first");
     if (n_gens < 0) return fail("bpm_step: n_gens < 0");
     if (s->cfg.keep_history) CK(ensure_history(s, s->hist_rows + n_gens));
@@ -2519,10 +2551,11 @@ extern "C" int bpm_get_step_time(bpm_handle_t s, float* elapsed_ms, int64_t* n_l
 }
 
 
+#ifdef BPM_TEST_HOOKS
 // Same generations as bpm_step, with a HIP event pair on the sampler's stream around every
-// update-kernel launch: returns the summed kernel time and the number of launches, i.e. the
-// per-launch duration bench.py prices the roofline with (rocprofv3 --kernel-trace gives the same
-// figure offline).
+// update-kernel launch: returns the summed kernel time and the number of launches -- a cross-check of
+// the per-launch duration bench.py prices the roofline with (rocprofv3 --kernel-trace gives the same
+// figure offline).  Test variant only (include/bipymc_hip_test.h): bench.py runs it outside its timed region.
 extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -2563,6 +2596,7 @@ extern "C" int bpm_step_profiled(bpm_handle_t s, int64_t n_gens, double* kernel_
     if (n_launches) *n_launches = 2 * n_gens;
     return 0;
 }
+#endif   // BPM_TEST_HOOKS
 
 // Warm start (demc.py:46-51,217-233): install `rows` history rows of this rank's chains
 // (hist_local: rows x n_local x dim) and the full current state X (N x dim, = last row of every chain).
@@ -2915,7 +2949,8 @@ extern "C" int bpm_eval_loglike(bpm_handle_t s, const double* X, int32_t n, doub
     return 0;
 }
 
-// ---- debug / parity hooks -----------------------------------------------------------------
+#ifdef BPM_TEST_HOOKS
+// ---- debug / parity hooks (include/bipymc_hip_test.h; build_variants/libbipymc_test.so only) ------------------------------------------
 extern "C" int bpm_set_trace(bpm_handle_t s, int32_t on) {
     CK(check_handle(s));
     CK(set_device(s));
@@ -2947,7 +2982,6 @@ extern "C" int bpm_get_trace(bpm_handle_t s, int32_t* out_i32, double* out_f64, 
     return 0;
 }
 
-#ifdef BPM_TEST_HOOKS
 // the host-side per-generation decisions, for parity against oracle/philox_ref.py
 extern "C" int bpm_debug_perm(bpm_handle_t s, int64_t t, int32_t shuffle, double flip_prob, int32_t* out_order,
                               int32_t* out_inverse, int32_t* out_flip) {
@@ -3030,7 +3064,7 @@ extern "C" int bpm_debug_time_kernels(bpm_handle_t s, int32_t reps, float* updat
         PhaseArgs r = a;
         if (which == 1) {
             r.replay = 1u; r.accbits = nullptr; r.accbits_all = s->accbits_all;
-            r.trace_i32 = nullptr; r.trace_f64 = nullptr; r.trace_mask = nullptr; r.pack = nullptr; r.hist_row = nullptr; r.llhist_row = nullptr;
+            trace_set(r, nullptr, nullptr, nullptr); r.pack = nullptr; r.hist_row = nullptr; r.llhist_row = nullptr;
             r.adapt_on = 0u;
         }
         for (int i = 0; i < 3; ++i) { if (which == 0) fn(r, s->stream); else launch_replay_any(s, r); }

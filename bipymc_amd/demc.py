@@ -170,9 +170,14 @@ class DeMcMpi(object):
             if self.exchange == "push":
                 raise RuntimeError("the push exchange could not be connected: " + why)
             import warnings
-            warnings.warn("bipymc_amd: push exchange not available (%s); accept bytes travel through RCCL instead" % why)
-            eng.set_exchange("replay")
-            self.exchange_used = "replay"
+            # rows wider than 512 coordinates run on the looped kernel, which has no replay / packed-rows form (bpm_set_exchange refuses both):
+            # they degrade to the dense all-gather -- the reference's own MPI_Allgather (demc.py:93-94,116-117).  The decision depends on dim
+            # alone: the same on every rank.
+            fallback = "dense" if self.dim > 512 else "replay"
+            warnings.warn("bipymc_amd: push exchange not available (%s); %s instead" % (
+                why, "whole blocks travel through the RCCL all-gather" if fallback == "dense" else "accept bytes travel through RCCL"))
+            eng.set_exchange(fallback)
+            self.exchange_used = fallback
             return
         if self.uses_device_target:
             eng.set_exchange(self.exchange)

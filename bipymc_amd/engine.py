@@ -147,8 +147,13 @@ class HipEngine(object):
         self._ck(self.lib.bpm_get_step_time(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def _need_hooks(self, name):
+        if not hasattr(self.lib, name):
+            raise L.BpmError("%s is part of the test surface (include/bipymc_hip_test.h): create the engine with lib=_lib.load_test()" % name)
+
     def step_profiled(self, n_gens):
-        """-> (summed update-kernel time in ms, number of launches)"""
+        """-> (summed update-kernel time in ms, number of launches).  Test variant only."""
+        self._need_hooks("bpm_step_profiled")
         ms = C.c_double(0.0)
         n = C.c_int64(0)
         self._ck(self.lib.bpm_step_profiled(self._h, int(n_gens), C.byref(ms), C.byref(n)))
@@ -276,8 +281,9 @@ class HipEngine(object):
         self._ck(self.lib.bpm_eval_loglike(self._h, _dptr(X), X.shape[0], _dptr(out)))
         return out
 
-    # ---- parity hooks -------------------------------------------------
+    # ---- parity hooks (test variant of the library only: HipEngine(lib=_lib.load_test())) ----------------
     def set_trace(self, on=True):
+        self._need_hooks("bpm_set_trace")
         self._ck(self.lib.bpm_set_trace(self._h, 1 if on else 0))
 
     def get_trace(self):

@@ -117,6 +117,10 @@ typedef struct bpm_stats {
 
 const char* bpm_last_error(void);
 int bpm_abi_version(void);
+/* Provenance: the first 16 hex digits of the SHA-256 over the sources this binary was built from (bipymc_amd/csrc/Makefile: ID_SRCS), baked in at
+ * compile time.  The binding recomputes it from the tree and refuses a stale library; profiles/traffic_*.json carry the id the counters were taken
+ * on.  (No counterpart in the reference: pure Python has no build.) */
+const char* bpm_build_id(void);
 /* GPUs visible to this process (hipGetDeviceCount): what one rank per GPU needs to pick its device where the reference
  * picks nothing (mpi4py ranks share the host's cores, demc.py:15). */
 int bpm_device_count(int32_t* out);
@@ -138,7 +142,8 @@ int bpm_get_state(bpm_handle_t h, double* X);
 /* Warm start with full histories (demc.py:46-51,217-233; chain.py:82-93): hist_local is
  * (rows, n_local, dim) for this rank's chains, X the (N, dim) current state of all chains. */
 int bpm_set_history(bpm_handle_t h, int64_t rows, const double* hist_local, const double* X);
-/* cached ln_like of the current state: all N values (host-callback targets must set the local ones). */
+/* cached ln_like of the current state.  bpm_set_loglike: HOST-CALLBACK targets only (they must set the n_local local values after every
+ * (re)initialisation; a sampler with a device target evaluates them itself and refuses the call). */
 int bpm_set_loglike(bpm_handle_t h, const double* ll_local); /* n_local values */
 int bpm_get_loglike(bpm_handle_t h, double* ll_local);
 
@@ -155,14 +160,7 @@ int bpm_step_timed(bpm_handle_t h, int64_t n_gens, float* elapsed_ms, int64_t* n
 /* the figures of the last bpm_step_timed call (which may be given NULL, NULL: reading the events costs tens of microseconds of
  * host time that a caller timing the call with its own clock does not want inside) */
 int bpm_get_step_time(bpm_handle_t h, float* elapsed_ms, int64_t* n_launches);
-/* same again with a HIP event pair around every update-kernel launch: summed kernel time and launch
- * count (bench.py prices the roofline with it). n_gens <= 4096. */
-int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);
 int bpm_synchronize(bpm_handle_t h);
-/* Test hook for the world_size > 1 path on ONE GPU: create R handles with rank = 0..R-1, world_size = R and a
- * nccl_uid that starts with "BPMLOCAL" (no RCCL involved); this call advances all of them n_gens generations
- * in lock-step, doing the per-half-generation all-gather (demc.py:93-94,116-117) with device copies. */
-int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
 /* Exchange policy for world_size > 1: what the Allgather of demc.py:93-94,116-117 moves.  Outside DREAM's CR
  * adaptation (where delta / cr_idx of every chain travel with the dense block) a half generation only changes the rows
  * that were ACCEPTED, and everything a proposal is made of -- the replicated state matrix, counter-addressed draws,
@@ -252,13 +250,9 @@ int bpm_set_adapt_state(bpm_handle_t h, const double* p_cr, const double* delta_
 /* ln_like of n points (row-major (n, dim)) with the sampler's device target: what `ln_like_fn(theta)` returns for the shipped analytic
  * targets (utils/d100_gauss.py:14-35, dblgauss_rv.py:11-32, banana_rv.py:11-40) */
 int bpm_eval_loglike(bpm_handle_t h, const double* X, int32_t n, double* out);
-/* (the test surface -- bpm_debug_*, bpm_selftest_philox, the BPM_TEST_PATHS kernel-path switches -- is NOT part of this library: it is
- * compiled only into build_variants/libbipymc_test.so and declared in include/bipymc_hip_test.h) */
-/* per-chain integer/float trace of the LAST generation (parity tests):
- * out_i32[n_local*32] = (cr_idx, d_prime, gamma_jump, accepted, snooker, partner ids[23], ...),
- * out_f64[n_local*4] = (alpha, ll_prop, delta, gamma), out_mask[n_local*dim] = CR mask */
-int bpm_set_trace(bpm_handle_t h, int32_t on);
-int bpm_get_trace(bpm_handle_t h, int32_t* out_i32, double* out_f64, uint8_t* out_mask);
+/* (the test surface -- bpm_debug_*, bpm_selftest_philox, bpm_set_trace / bpm_get_trace, bpm_local_group_step, bpm_step_profiled, the
+ * BPM_TEST_PATHS kernel-path switches -- is NOT part of this library: it is compiled only into build_variants/libbipymc_test.so and declared
+ * in include/bipymc_hip_test.h; the product's kernel-argument block has no trace fields) */
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,18 @@
 extern "C" {
 #endif
 
+/* The world_size > 1 path on ONE GPU: create R handles with rank = 0..R-1, world_size = R and a nccl_uid that starts with "BPMLOCAL" (no RCCL
+ * involved; the product library refuses such a uid); this call advances all of them n_gens generations in lock-step, doing the per-half-generation
+ * all-gather (demc.py:93-94,116-117) with device copies -- or, once connected, through the push exchange. */
+int bpm_local_group_step(bpm_handle_t* handles, int32_t R, int64_t n_gens);
+/* bpm_step with a HIP event pair around every update-kernel launch: summed kernel time and launch count (bench.py's cross-check of the
+ * per-launch duration its roofline is priced with, run outside the timed region).  n_gens <= 4096. */
+int bpm_step_profiled(bpm_handle_t h, int64_t n_gens, double* kernel_ms_sum, int64_t* n_launches);
+/* per-chain integer/float trace of the LAST generation (parity tests; the trace fields exist in the test variant's kernel-argument block only):
+ * out_i32[n_local*32] = (cr_idx, d_prime, gamma_jump, accepted, snooker, partner ids[23], ...),
+ * out_f64[n_local*4] = (alpha, ll_prop, delta, gamma), out_mask[n_local*dim] = CR mask.  A tracing sampler launches on the HIP stream. */
+int bpm_set_trace(bpm_handle_t h, int32_t on);
+int bpm_get_trace(bpm_handle_t h, int32_t* out_i32, double* out_f64, uint8_t* out_mask);
 /* bpm_destroy's decision about the device buffers as a pure function (1 free, 0 leak), and the injection of a failed queue (the device's
  * queue is unusable for the rest of the process afterwards: child processes only) */
 int bpm_debug_destroy_plan(int32_t queue_failed, int32_t quiesced);

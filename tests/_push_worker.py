@@ -101,7 +101,7 @@ def local_group_check(case, R):
     tid, tp, d = spec
     ref = single_rank_reference(case)
     uid = b"BPMLOCAL" + bytes(120)
-    ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, **kw)
+    ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, lib=L.load_test(), **kw)
              for r in range(R)]
     ls0 = ranks[0].launch_stats()
     blobs = [e.push_export() for e in ranks]
@@ -116,8 +116,8 @@ def local_group_check(case, R):
         assert e.exchange_stats()["mode"] == "push"
         e.set_state(x0)
         e.begin_run(flip=0.4)
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G // 2))
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G - G // 2))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G // 2), ranks[0].lib)
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G - G // 2), ranks[0].lib)
     n_local = N // R
     H = np.concatenate([e.get_history() for e in ranks], axis=1)
     assert np.array_equal(H, ref["hist"])                                  # every chain's whole history, bit for bit

@@ -58,8 +58,11 @@ def test_product_library_carries_no_test_surface(built, built_test):
     assert not [s for s in exported if "debug" in s or "selftest_philox" in s]
     blob = open(built, "rb").read()
     assert b"BPM_TEST_PATHS" not in blob and b"bpm_debug" not in blob
+    # round 5: the lock-step driver of local rank groups, the per-launch event profile and the decision trace are test surface too
+    assert not [s for s in exported if s in ("bpm_local_group_step", "bpm_step_profiled", "bpm_set_trace", "bpm_get_trace")]
     hooks = _declared_symbols("bipymc_hip_test.h")
-    assert len(hooks) >= 8 and all("debug" in h or "selftest" in h for h in hooks)
+    assert len(hooks) >= 12 and all("debug" in h or "selftest" in h or h in ("bpm_local_group_step", "bpm_step_profiled", "bpm_set_trace", "bpm_get_trace")
+                                    for h in hooks)
     test_exported = _exported(built_test)
     assert test_exported == set(_declared_symbols()) | set(hooks)
     assert b"BPM_TEST_PATHS" in open(built_test, "rb").read()
@@ -70,6 +73,36 @@ def test_library_loads_and_reports_abi(built):
     lib = _lib.load()
     assert lib.bpm_abi_version() == _lib.ABI_VERSION
     assert lib.bpm_last_error() is not None
+
+
+def test_binaries_are_built_from_the_sources_in_the_tree(built, built_test, tmp_path, monkeypatch):
+    """*.so is git-ignored and travels to the GPU box as built -- what proves the tested binary is the tested source?  The
+    Makefile bakes the SHA-256 of the sources (ID_SRCS) into every library; the binding recomputes it from the tree and refuses another."""
+    import ctypes as C
+    import hashlib
+    from bipymc_amd import _lib
+    want = _lib.source_id()
+    assert want is not None and re.fullmatch(r"[0-9a-f]{16}", want)
+    # the Makefile's list and the binding's list are the same files in the same order
+    mk = open(os.path.join(ROOT, "bipymc_amd", "csrc", "Makefile")).read()
+    ids = re.search(r"^ID_SRCS = (.*)$", mk, re.M).group(1).split()
+    norm = lambda rel: os.path.normpath(os.path.join(ROOT, "bipymc_amd", "csrc", rel))
+    assert [norm(x) for x in ids] == [os.path.normpath(os.path.join(ROOT, "bipymc_amd", x)) for x in _lib._ID_SRCS]
+    h = hashlib.sha256()
+    for x in ids:
+        h.update(open(norm(x), "rb").read())
+    assert h.hexdigest()[:16] == want
+    for so in (built, built_test):
+        lib = C.CDLL(so)
+        lib.bpm_build_id.restype = C.c_char_p
+        assert lib.bpm_build_id().decode() == want, (so, "stale binary: run make -C bipymc_amd/csrc")
+    assert _lib.build_id(_lib.load()) == want and _lib.build_id(_lib.load_test()) == want
+    # a library built from OTHER sources is refused, loudly
+    monkeypatch.setattr(_lib, "source_id", lambda: "0123456789abcdef")
+    with pytest.raises(ImportError, match="built from other sources"):
+        _lib._bind(built, hooks=None)
+    monkeypatch.setenv("BPM_ALLOW_STALE_LIB", "1")
+    assert _lib._bind(built, hooks=None) is not None
 
 
 def test_struct_layouts_match_header(built, tmp_path):
@@ -126,6 +159,22 @@ def test_destroy_plan_never_frees_under_a_failed_queue(built_test):
     assert lib.bpm_debug_destroy_plan(0, 0) == 1        # (no failure: nothing can still run)
     assert lib.bpm_debug_destroy_plan(1, 1) == 1        # failed, then inactivated: free
     assert lib.bpm_debug_destroy_plan(1, 0) == 0        # failed and not quiesced: LEAK
+
+
+def test_build_variants_have_disjoint_kernel_symbols(built, built_test):
+    """The library's own AQL queue finds its kernels BY NAME among all code objects the HSA loader holds (aql_queue.h: DirectQueue::kernel).  A process
+    that holds the product and the test variant at once (the GPU tests, bench.py's event-pair cross-check) must never dispatch one library's packet
+    with the other's kernel: the variants' argument blocks differ (the product has no trace fields) -- a GPU memory fault at address 0 when it
+    happened (round 5, gpurun_out/r5a).  Every variant's device code lives in an inline namespace of its own (philox.h: BPM_VARIANT_NS)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    prod = set(k["name"] for k in kernel_resources(built))
+    hooks = set(k["name"] for k in kernel_resources(built_test))
+    assert len(prod) > 150 and len(hooks) >= len(prod)
+    assert not (prod & hooks), sorted(prod & hooks)[:5]
+    assert all("7product" in n for n in prod), [n for n in prod if "7product" not in n][:5]      # (Itanium mangling of bpm::product::)
+    assert all("5hooks" in n for n in hooks), [n for n in hooks if "5hooks" not in n][:5]
 
 
 def test_no_kernel_spills_or_touches_scratch_memory(built):

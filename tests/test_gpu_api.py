@@ -78,6 +78,38 @@ def test_100d_gauss_reference_scenario():
         assert chain.shape[0] == 300000
 
 
+def test_product_and_test_variant_run_side_by_side_in_one_process():
+    """Round 5 regression: the product library and the test variant in ONE process, both samplers on their own AQL queues, alternating.  The queue
+    locates kernels by name; with equal names the library loaded second dispatched the first one's kernels -- a memory fault as soon as the two
+    argument blocks differed (the product's has no trace fields).  Same configuration, same seed: bit-identical states, and the test variant's
+    traced run (HIP stream, general kernel with the trace code) agrees as well."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    tid, tp, d = d100_gauss.Gauss_100D(rho=0.5, dim=100)._bpm_target_spec()
+    X0 = np.random.RandomState(3).normal(size=(512, d)) * np.sqrt(np.arange(d) + 1.0)
+    kw = dict(algo=L.ALGO_DREAM, n_chains=512, dim=d, target_id=tid, target_params=tp, seed=19, burnin_gen=6, n_cr_gen=2)
+    a = HipEngine(**kw)
+    b = HipEngine(lib=L.load_test(), **kw)
+    c = HipEngine(lib=L.load_test(), **kw)
+    for e in (a, b, c):
+        e.set_state(X0)
+    c.set_trace(True)
+    for e in (a, b, c):
+        e.begin_run()
+    for _ in range(4):                    # interleaved: both libraries' queues are live at the same time
+        a.step(5); b.step(5); c.step(5)
+    la, lb = a.launch_stats(), b.launch_stats()
+    assert la["has_queue"] and lb["has_queue"] and la["direct"] >= 40 and lb["direct"] >= 40
+    Xa, Xb, Xc = a.get_state(), b.get_state(), c.get_state()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Xa, Xc)
+    assert np.array_equal(a.get_history(), b.get_history())
+    assert a.stats()["local_n_accepted"] == b.stats()["local_n_accepted"] == c.stats()["local_n_accepted"]
+    np.testing.assert_array_equal(a.stats()["p_cr"], b.stats()["p_cr"])
+    for e in (a, b, c):
+        e.close()
+
+
 def test_host_callback_equals_device_target():
     """An arbitrary Python ln_like_fn (samplers.py:36-43) takes the propose/commit path; with the same
     target it must reproduce the fused device path (same draws, ln_like equal to rounding)."""
@@ -369,7 +401,7 @@ def test_wide_rows_have_no_replay_or_packed_rows_exchange():
     from bipymc_amd.utils import d100_gauss
     tid, tp, d = d100_gauss.Gauss_100D(dim=600)._bpm_target_spec()
     uid = b"BPMLOCAL" + bytes(120)
-    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=16, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid) for r in range(2)]
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=16, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid, lib=L.load_test()) for r in range(2)]
     assert ranks[0].exchange_stats()["mode"] == "dense"
     for mode in ("replay", "rows"):
         with pytest.raises(L.BpmError, match="exchange by push"):
@@ -420,13 +452,13 @@ def _multi_rank_case(case, R, exchange):
 
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run(flip=0.4)
         e.set_exchange(mode=exchange.split("_")[0], cap=2 if exchange == "rows_overflow" else 0)
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     xs = [e.exchange_stats() for e in ranks]
     assert all(x == xs[0] for x in xs)                                 # every rank took the same decisions
     n_sparse_gens = max(0, G - (kw.get("burnin_gen", 0) if algo == L.ALGO_DREAM else 0))     # CR adaptation runs dense
@@ -654,13 +686,13 @@ def test_eight_rank_world_equals_single_rank(exchange):
     one.step(G)
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=21, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run()
         e.set_exchange(mode=exchange)
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     HR = np.concatenate([e.get_history() for e in ranks], axis=1)
     assert np.array_equal(HR, one.get_history())
     for e in ranks:
@@ -692,12 +724,12 @@ def test_config4_shape_eight_ranks_equal_single_rank():
     one.close()
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run()
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     assert ranks[0].exchange_stats()["mode"] == "replay" and ranks[0].exchange_stats()["replay_gens"] == G - 40
     for e in ranks:
         assert np.array_equal(e.get_state(), X1)
@@ -725,7 +757,7 @@ def test_cr_slots_are_fresh_when_adaptation_resumes_in_a_world(exchange):
         one = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=13, **kw)
         one.set_state(x0)
         uid = b"BPMLOCAL" + bytes(120)
-        ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=13, rank=r, world_size=2, nccl_uid=uid, **kw)
+        ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=13, rank=r, world_size=2, nccl_uid=uid, lib=L.load_test(), **kw)
                  for r in range(2)]
         arr = (C.c_void_p * 2)(*[e._h for e in ranks])
         for e in ranks:
@@ -736,7 +768,7 @@ def test_cr_slots_are_fresh_when_adaptation_resumes_in_a_world(exchange):
             for e in ranks:
                 e.begin_run()
                 e.set_exchange(mode=exchange, cap=0)
-            L.check(ranks[0].lib.bpm_local_group_step(arr, 2, 13))
+            L.check(ranks[0].lib.bpm_local_group_step(arr, 2, 13), ranks[0].lib)
             st1 = one.stats()
             assert np.all(np.asarray(st1["n_cr_updates"]) > 0)
             for e in ranks:
@@ -774,12 +806,12 @@ def test_outlier_reset_multi_rank_equals_single_rank(R):
     assert st1["n_outlier_resets"] >= 4
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=6, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run()
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     HR = np.concatenate([e.get_history() for e in ranks], axis=1)
     assert np.array_equal(HR, one.get_history())
     assert np.array_equal(np.concatenate([e.get_loglike_history() for e in ranks], axis=1), one.get_loglike_history())
@@ -827,12 +859,12 @@ def test_config5_as_stated_full_size():
     one.close()
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=31, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run()
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     for e in ranks:
         st = e.stats()
         assert np.array_equal(e.get_state(), X1)
@@ -896,12 +928,12 @@ def test_many_ranks_sorted_records_and_fallback(R):
     one.step(G)
     uid = b"BPMLOCAL" + bytes(120)
     ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=3, rank=r, world_size=R,
-                       nccl_uid=uid, **kw) for r in range(R)]
+                       nccl_uid=uid, lib=L.load_test(), **kw) for r in range(R)]
     for e in ranks:
         e.set_state(x0)
         e.begin_run()
     arr = (C.c_void_p * R)(*[e._h for e in ranks])
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     assert np.array_equal(np.concatenate([e.get_history() for e in ranks], axis=1), one.get_history())
     for e in ranks:
         assert np.array_equal(e.get_state(), one.get_state())

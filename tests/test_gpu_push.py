@@ -155,7 +155,7 @@ from bipymc_amd.engine import HipEngine
 from bipymc_amd.utils import d100_gauss
 tid, tp, d = d100_gauss.Gauss_100D(dim=6)._bpm_target_spec()
 uid = b"BPMLOCAL" + bytes(120)
-ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid, burnin_gen=0)
+ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid, lib=L.load_test(), burnin_gen=0)
          for r in range(2)]
 blobs = [e.push_export() for e in ranks]
 for e in ranks:
@@ -201,8 +201,8 @@ def test_connect_refuses_wrong_blobs_and_can_be_repeated():
     from bipymc_amd.utils import d100_gauss
     tid, tp, d = d100_gauss.Gauss_100D(dim=6)._bpm_target_spec()
     uid = b"BPMLOCAL" + bytes(120)
-    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=32, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid) for r in range(2)]
-    other = HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=1, world_size=2, nccl_uid=uid)
+    ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=32, dim=d, target_id=tid, target_params=tp, seed=1, rank=r, world_size=2, nccl_uid=uid, lib=L.load_test()) for r in range(2)]
+    other = HipEngine(algo=L.ALGO_DREAM, n_chains=64, dim=d, target_id=tid, target_params=tp, seed=1, rank=1, world_size=2, nccl_uid=uid, lib=L.load_test())
     blobs = [e.push_export() for e in ranks]
     with pytest.raises(L.BpmError, match="not the export of rank"):
         ranks[0].push_connect(blobs[::-1])                               # rank order mixed up

@@ -14,10 +14,17 @@ def _engine(**kw):
     return HipEngine(**kw)
 
 
+def _hooks_engine(**kw):
+    """on the test variant of the library: the per-chain decision trace is part of the test surface (include/bipymc_hip_test.h)"""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    return HipEngine(lib=L.load_test(), **kw)
+
+
 def test_dream_decision_frequencies():
     N, d, G = 2048, 20, 40
     params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
-    e = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=123,
+    e = _hooks_engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=123,
                 burnin_gen=0, n_cr=3, del_pairs=3)
     X = np.random.RandomState(0).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
     e.set_state(X)
@@ -66,7 +73,7 @@ def test_dream_decision_frequencies():
 
 def test_demc_decision_frequencies():
     N, G = 4096, 40
-    e = _engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=321,
+    e = _hooks_engine(algo=R.ALGO_DEMC, n_chains=N, dim=2, target_id=R.TARGET_BANANA_2D, target_params=R.banana_params(), seed=321,
                 p_snooker=0.1)
     e.set_state(np.random.RandomState(1).normal(size=(N, 2)) + np.array([0, 1.0]))
     e.set_trace(True)
@@ -104,7 +111,7 @@ def test_jitter_moments_on_device():
     from scipy import stats
     assert stats.kstest((X1 / 0.5).reshape(-1)[:20000], "norm").pvalue > 1e-3
     # uniform multiplicative jitter of DREAM: pairs differ by exactly 1 in every coordinate
-    e = _engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=10,
+    e = _hooks_engine(algo=R.ALGO_DREAM, n_chains=N, dim=d, target_id=R.TARGET_GAUSS_EQUICORR, target_params=params, seed=10,
                 burnin_gen=0, n_cr=1, del_pairs=1)
     X = np.zeros((N, d)); X[::2] = 1.0                                      # a - b in {-1, 0, 1}
     e.set_state(X)

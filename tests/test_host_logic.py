@@ -361,9 +361,9 @@ def test_exchange_is_chosen_collectively(monkeypatch):
         def Barrier(self):
             pass
 
-    def run(eng, other, exchange="auto"):
+    def run(eng, other, exchange="auto", dim=100):
         s = object.__new__(D.DeMcMpi)
-        s._engine, s.comm, s.exchange, s._target_id = eng, Comm(other), exchange, 1      # (a device target)
+        s._engine, s.comm, s.exchange, s._target_id, s.dim = eng, Comm(other), exchange, 1, dim      # (a device target)
         s._connect_exchange()
         return s
 
@@ -386,6 +386,14 @@ def test_exchange_is_chosen_collectively(monkeypatch):
         warnings.simplefilter("always")
         s = run(Eng(fail_at="selftest-raises"), good)
     assert s.exchange_used == "replay" and s.comm.other == [] and any("self-test: hipErrorLaunchFailure" in str(x.message) for x in w)
+    # rows wider than 512 coordinates (the looped kernel has no replay form: bpm_set_exchange refuses it, sampler.hip) fall back to the DENSE
+    # all-gather instead of raising in the constructor; at 512 the replay exchange still serves
+    for dim, want in ((640, "dense"), (513, "dense"), (512, "replay")):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            s = run(Eng(fail_at="selftest"), good, dim=dim)
+        assert s.exchange_used == want and s._engine.mode == want, (dim, s.exchange_used)
+        assert any(("whole blocks" if want == "dense" else "accept bytes") in str(x.message) for x in w)
     # exchange="push" (no RCCL to fall back to): an error on every rank
     with pytest.raises(RuntimeError, match="push exchange could not be connected"):
         run(Eng(fail_at="export"), [(None, "export: no arena"), (False, None)], exchange="push")

@@ -34,7 +34,7 @@ np.random.seed(3)
 x0 = g.rvs(N)
 uid = b"BPMLOCAL" + bytes(120)
 ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R,
-                   nccl_uid=uid, burnin_gen=0) for r in range(R)]
+                   nccl_uid=uid, lib=L.load_test(), burnin_gen=0) for r in range(R)]
 if mode == "push":
     blobs = [e.push_export() for e in ranks]
     for e in ranks:
@@ -44,9 +44,9 @@ for e in ranks:
     e.begin_run()
     e.set_exchange(mode=mode)
 arr = (C.c_void_p * R)(*[e._h for e in ranks])
-L.check(ranks[0].lib.bpm_local_group_step(arr, R, 5))
+L.check(ranks[0].lib.bpm_local_group_step(arr, R, 5), ranks[0].lib)
 t0 = time.perf_counter()
-L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
 dt = time.perf_counter() - t0
 acc = sum(e.stats()["local_n_accepted"] for e in ranks) / float(N * (G + 5))
 print("R=%d mode=%s N=%d: %d generations, %.1f us per generation for ALL ranks serialised on one GPU (acceptance %.3f); %s"

@@ -47,7 +47,11 @@ import json, re
 t = open("$P/${TAG}_pmc_bench_driver.txt").read()
 f = float(re.search(r"FETCH_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
 w = float(re.search(r"WRITE_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
+import sys
+sys.path.insert(0, "$R")
+from bipymc_amd import _lib
 json.dump({"hbm_bytes_per_launch": (2 * f + w) * 1024.0, "fetch_size_kb_uncorrected": f, "write_size_kb": w,
+           "build_id": _lib.build_id(_lib.load()),      # the library the counters were taken on: bench.py nulls roofline.traffic for any other
            "source": "profiles/${TAG}_pmc_bench_driver.txt", "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section)"},
           open("$P/traffic_cfg2.json", "w"), indent=1)
 PY

@@ -46,7 +46,7 @@ one.close()
 N = n_per * R
 x0 = g.rvs(N)
 uid = b"BPMLOCAL" + bytes(120)
-ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, burnin_gen=0)
+ranks = [HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=11, rank=r, world_size=R, nccl_uid=uid, lib=L.load_test(), burnin_gen=0)
          for r in range(R)]
 blobs = [e.push_export() for e in ranks]
 scope = os.environ.get("PUSH_SCOPE", "system")
@@ -57,11 +57,11 @@ for e in ranks:
     e.reserve_history(4 * G + 100)
     e.begin_run()
 arr = (C.c_void_p * R)(*[e._h for e in ranks])
-L.check(ranks[0].lib.bpm_local_group_step(arr, R, 60))
+L.check(ranks[0].lib.bpm_local_group_step(arr, R, 60), ranks[0].lib)
 tw = 1e9
 for _ in range(3):
     t0 = time.perf_counter()
-    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G))
+    L.check(ranks[0].lib.bpm_local_group_step(arr, R, G), ranks[0].lib)
     tw = min(tw, (time.perf_counter() - t0) / G)
 ls = ranks[0].launch_stats()
 # the same world with ONE HOST THREAD PER RANK (bpm_step per rank; ctypes releases the GIL): the ranks' hosts enqueue side by side like
