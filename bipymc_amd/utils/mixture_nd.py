@@ -41,8 +41,15 @@ class BimodeGauss_ND(object):
         m = np.maximum(comp[0], comp[1])
         return m + np.log(np.exp(comp[0] - m) + np.exp(comp[1] - m))
 
-    def rvs(self, n_samples):
-        pick1 = np.random.uniform(size=n_samples) < self.w_g1
+    def rvs(self, n_samples, stratified=False):
+        """exact draws; stratified=True: exactly round(w_g1 n) of them from the first component (the mode occupancy of a finite population then
+        equals the weights instead of fluctuating by sqrt(w (1 - w) / n): what a 1 % gate on the OVERALL variance 0.0625 + 4 w (1 - w) needs)"""
+        if stratified:
+            pick1 = np.zeros(n_samples, dtype=bool)
+            pick1[:int(round(self.w_g1 * n_samples))] = True
+            np.random.shuffle(pick1)
+        else:
+            pick1 = np.random.uniform(size=n_samples) < self.w_g1
         out = np.empty((n_samples, self.dim))
         for k in range(self.dim // 2):
             for sel, mu, sg, rho in ((pick1, self.mu_g1, self.sigma_g1, self.rho_g1),

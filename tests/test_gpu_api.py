@@ -110,6 +110,31 @@ def test_product_and_test_variant_run_side_by_side_in_one_process():
         e.close()
 
 
+@pytest.mark.parametrize("scenario", ["gauss100_dream", "gauss100_demc", "banana_dream", "banana_demc", "bimodal_demc"])
+def test_reference_families_hold_the_device(scenario):
+    """the reference's own scenarios through the drop-in classes ON THE DEVICE, held against the families the genuine
+    reference produced (tests/golden/e2e_anchor_*.json, oracle/gen_anchor_families.py): DreamMpi N = 100 / DeMcMpi N = 200 on the 100-D Gaussian
+    (tests/test_100dgauss.py:100-110: acceptance 0.2094 +- 0.0004, p_cr (0.177, 0.334, 0.491) +- 0.005 for DREAM; the population's variance grows
+    from 1e-6 along the same curve), DreamMpi N = 10 / DeMcMpi N = 20 on the banana with the level fractions within 0.05 (tests/test_banana.py:60-72,
+    118-127), DeMcMpi N = 20 on the bimodal target (tests/test_dblgauss.py:130-133).  Two seeds each; tolerances: tests/_anchors.py."""
+    import _anchors as A
+    from bipymc_amd import DeMcMpi, DreamMpi
+    from bipymc_amd.utils import banana_rv, d100_gauss, dblgauss_rv
+    doc = A.load(scenario)
+    tgt = {"gauss100": d100_gauss.Gauss_100D(), "banana": banana_rv.Banana_2D(sigma1=1.0, sigma2=1.0), "bimodal": dblgauss_rv.BimodeGauss_2D()}[doc["target"]]
+    d = 100 if doc["target"] == "gauss100" else 2
+    N = doc["n_chains"]
+    for seed in (42, 7):
+        cls = DreamMpi if doc["algo"] == "dream" else DeMcMpi
+        s = cls(tgt.ln_like, np.zeros(d), n_chains=N, seed=seed, **doc["kwargs"])
+        assert s.uses_device_target
+        s.run_mcmc(doc["n"])
+        _, _, full = s.param_est(n_burn=0)
+        T = full.shape[0] // N
+        got = A.summarize(doc, full.reshape(T, N, d), s.acceptance_fraction, s.p_cr if doc["algo"] == "dream" else None)
+        A.check(scenario, got, "device, seed %d" % seed)
+
+
 def test_host_callback_equals_device_target():
     """An arbitrary Python ln_like_fn (samplers.py:36-43) takes the propose/commit path; with the same
     target it must reproduce the fused device path (same draws, ln_like equal to rounding)."""
