@@ -741,10 +741,14 @@ def exchange_alternatives(eng, dist, world, X0, n_chains, make_single, make_rccl
     return out
 
 
-def host_callback_config(device, budget_s=3.0):
-    """f1 under the driver's clock: cfg2's shape -- DREAM, 100-D Gaussian, 8192 chains -- with the likelihood as a HOST CALLBACK:
-    every half generation the proposals come back (bpm_propose), a vectorised NumPy ln_like evaluates the block, the values go in (bpm_commit).
-    The path every user-written likelihood takes (samplers.py:36-43; examples/ex_para_fit.py:39-72 calls it row by row)."""
+def host_callback_config(device, budget_s=4.5):
+    """f1 under the driver's clock: cfg2's shape -- DREAM, 100-D Gaussian, 8192 chains -- with the likelihood
+    as a CALLBACK of the caller, the path every user-written likelihood takes (samplers.py:36-43; examples/ex_para_fit.py:39-72 calls it row by row):
+      (a) a vectorised NumPy ln_like on the host: every half generation the proposals come back in `chunks` pieces into pinned staging
+          (bpm_propose_begin / _chunk), the DMA of piece k + 1 under the evaluation of piece k, the values go in piece by piece (bpm_commit_chunk / _end);
+          beside it the one-piece form of rounds 1-4 (bpm_propose / bpm_commit through caller-owned buffers);
+      (b) the same likelihood as a torch function ON THE DEVICE (bpm_propose_device / bpm_commit_device: nothing crosses PCIe).
+    -> list of config entries"""
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
     N, d = CHAINS_PER_GPU, DIM
@@ -760,41 +764,122 @@ def host_callback_config(device, budget_s=3.0):
         return c0 - 0.5 * (a * np.einsum("ij,ij->i", z, z) - b * s1 * s1)
     rs = np.random.RandomState(1234)
     X0 = sig * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
-    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, device=device,
-                  del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3)
-    try:
-        e.set_state(X0)
-        e.set_loglike(ln_like(X0))
-        e.reserve_history(4000)
-        e.begin_run()
-        for _ in range(3):                                            # warm-up
-            for _h in range(2):
-                props, _ids = e.propose()
-                e.commit(ln_like(props))
-        gens, t_py, t0 = 0, 0.0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s * 0.8 and gens < 3000:
-            for _h in range(2):
-                props, _ids = e.propose()
-                tp0 = time.perf_counter()
-                ll = ln_like(props)
-                t_py += time.perf_counter() - tp0
-                e.commit(ll)
-            gens += 1
-        e.synchronize()
-        el = time.perf_counter() - t0
-        st = e.stats()
-    finally:
-        e.close()
     half = N // 2
-    d2h = N * 4 + half * d * 8 + 2 * N * 8                            # work-item ids, proposals of the half's chains, (log_corr, .) pairs
-    h2d = 2 * N * 8                                                   # the pairs with the ln_like values filled in
-    return dict(config="cfg2 shape with a host-callback ln_like_fn (vectorised NumPy): DREAM gauss d=100 N=8192 steady, bpm_propose / bpm_commit",
-                value=N * gens / el, unit="chain-updates/s", n_chains=N, dim=d, steps=gens, ms_per_step=el / gens * 1e3,
-                start="exact draws of the target",
-                acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
-                pcie=dict(d2h_bytes_per_half_generation=d2h, h2d_bytes_per_half_generation=h2d, staging="pinned host buffers, one read-back per propose"),
-                share_of_time_in_the_python_call=t_py / el,
-                note="the host clock includes the callback; not a roofline configuration (PCIe + Python bound by construction)")
+    out = []
+
+    def run(name, one_generation, init, seconds, extra):
+        e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, device=device,
+                      del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3)
+        try:
+            e.set_state(X0)
+            init(e)
+            e.reserve_history(6000)
+            e.begin_run()
+            t_py = [0.0]
+            for _ in range(3):                                        # warm-up
+                one_generation(e, t_py)
+            gens, t_py[0], t0 = 0, 0.0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds and gens < 5000:
+                one_generation(e, t_py)
+                gens += 1
+            e.synchronize()
+            el = time.perf_counter() - t0
+            st = e.stats()
+        finally:
+            e.close()
+        ent = dict(config=name, value=N * gens / el, unit="chain-updates/s", n_chains=N, dim=d, steps=gens, ms_per_step=el / gens * 1e3,
+                   start="exact draws of the target",
+                   acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
+                   share_of_time_in_the_callback=t_py[0] / el,
+                   note="the host clock includes the callback; not a roofline configuration")
+        ent.update(extra)
+        out.append(ent)
+
+    def gen_one_piece(e, t_py):
+        for _h in range(2):
+            props, _ids = e.propose()
+            tp0 = time.perf_counter()
+            ll = ln_like(props)
+            t_py[0] += time.perf_counter() - tp0
+            e.commit(ll)
+
+    def gen_chunked(chunks):
+        def g(e, t_py):
+            for _h in range(2):
+                for k, rows, _ids in e.propose_chunks(chunks):
+                    tp0 = time.perf_counter()
+                    ll = ln_like(rows)
+                    t_py[0] += time.perf_counter() - tp0
+                    e.commit_chunk(k, ll)
+                e.commit_end()
+        return g
+    def gen_threaded(chunks, threads):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=threads)
+
+        def work(e, k):
+            rows, _ids = e.propose_chunk(k)                           # (waits for the DMA of piece k only)
+            t = time.perf_counter()
+            ll = ln_like(rows)
+            return ll, time.perf_counter() - t
+
+        def g(e, t_py):
+            for _h in range(2):
+                e.propose_begin(chunks)
+                futs = [pool.submit(work, e, k) for k in range(chunks)]
+                for k, f in enumerate(futs):
+                    ll, dt = f.result()
+                    t_py[0] += dt / threads                           # (thread-seconds / threads: the callback's share of the wall clock)
+                    e.commit_chunk(k, ll)
+                e.commit_end()
+        return g
+    d2h = N * 4 + half * d * 8                                        # work-item ids + the proposals of the half's chains
+    h2d = half * 8                                                    # their ln-likes
+    pcie = dict(d2h_bytes_per_half_generation=d2h, h2d_bytes_per_half_generation=h2d)
+    host_init = lambda e: e.set_loglike(ln_like(X0))                  # noqa: E731
+    CH, TH = 4, 2
+    try:
+        run("cfg2 shape with a host-callback ln_like_fn (vectorised NumPy), read-back in %d overlapped pieces evaluated by %d host threads "
+            "(DreamMpi(..., vectorized=True, callback_threads=%d)): DREAM gauss d=100 N=8192 steady" % (TH, TH, TH), gen_threaded(TH, TH), host_init, budget_s * 0.2,
+            dict(pcie=dict(pcie, staging="pinned staging of the library, %d pieces per half generation" % TH), host_threads=TH))
+    except Exception as ex:                                           # noqa: BLE001
+        out.append(dict(config="cfg2 shape with a host-callback ln_like_fn, overlapped read-back, threaded evaluation", error=str(ex)))
+    try:
+        run("cfg2 shape with a host-callback ln_like_fn (vectorised NumPy), read-back in %d overlapped pieces: DREAM gauss d=100 N=8192 steady, "
+            "bpm_propose_begin / _chunk + bpm_commit_chunk / _end, ONE host thread" % CH, gen_chunked(CH), host_init, budget_s * 0.25,
+            dict(pcie=dict(pcie, staging="pinned staging of the library, %d pieces per half generation, the DMA of piece k + 1 under the evaluation of piece k" % CH)))
+    except Exception as ex:                                           # noqa: BLE001
+        out.append(dict(config="cfg2 shape with a host-callback ln_like_fn, overlapped read-back", error=str(ex)))
+    try:
+        run("cfg2 shape with a host-callback ln_like_fn (vectorised NumPy), ONE call per half generation through caller-owned buffers (what DreamMpi does by "
+            "default; bpm_propose / bpm_commit, the read-back in 4 pieces under the library's own compaction copy)",
+            gen_one_piece, host_init, budget_s * 0.3, dict(pcie=dict(pcie, staging="pinned staging, the DMA of piece k + 1 under the compaction copy of piece k")))
+    except Exception as ex:                                           # noqa: BLE001
+        out.append(dict(config="cfg2 shape with a host-callback ln_like_fn, one piece", error=str(ex)))
+    try:
+        import torch
+        dev = "cuda:%d" % device
+        isig_t = torch.tensor(isig, dtype=torch.float64, device=dev)
+
+        def ln_like_dev(rows):
+            X = torch.as_tensor(rows, device=dev)                     # the library's buffer, no copy
+            z = X * isig_t
+            s1 = z.sum(dim=1)
+            return c0 - 0.5 * (a * (z * z).sum(dim=1) - b * s1 * s1)
+
+        def gen_dev(e, t_py):
+            for _h in range(2):
+                rows = e.propose_device()
+                tp0 = time.perf_counter()
+                ll = ln_like_dev(rows)
+                t_py[0] += time.perf_counter() - tp0                  # (launch time of the torch kernels: they run asynchronously)
+                e.commit_device(ll)
+        run("cfg2 shape with a DEVICE-RESIDENT callback (the same likelihood as a torch function on the GPU, vectorized=\"device\"): "
+            "bpm_propose_device / bpm_commit_device, no PCIe", gen_dev, lambda e: e.set_loglike_device(ln_like_dev(e.state_device())), budget_s * 0.25,
+            dict(pcie=dict(d2h_bytes_per_half_generation=N * 4, h2d_bytes_per_half_generation=0, staging="none: proposals and ln-likes stay in device memory")))
+    except Exception as ex:                                           # noqa: BLE001
+        out.append(dict(config="cfg2 shape with a device-resident (torch) callback", error=str(ex)))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1383,7 +1468,7 @@ def main(argv=None):
             watch.pending("other_configs")
             out["configs"] = other_configs(local_rank)
             try:
-                out["configs"].append(host_callback_config(local_rank))
+                out["configs"] += host_callback_config(local_rank)
             except Exception as e:                                     # noqa: BLE001
                 out["configs"].append(dict(config="cfg2 shape with a host-callback ln_like_fn", error=str(e)))
         if world == 1 and not use_dist and not args.no_moments and CHAINS_PER_GPU == 8192:

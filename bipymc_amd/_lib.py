@@ -83,6 +83,14 @@ SIGNATURES = {
     "bpm_reduce_moments": (C.c_int, [_H, C.c_int64, _dp, _dp, _dp, _P(C.c_int64)]),
     "bpm_propose": (C.c_int, [_H, _dp, _ip, _ip]),
     "bpm_commit": (C.c_int, [_H, _dp]),
+    "bpm_propose_begin": (C.c_int, [_H, C.c_int32]),
+    "bpm_propose_chunk": (C.c_int, [_H, C.c_int32, _P(_dp), _P(_ip), _ip, _ip]),
+    "bpm_commit_chunk": (C.c_int, [_H, C.c_int32, _dp]),
+    "bpm_commit_end": (C.c_int, [_H]),
+    "bpm_propose_device": (C.c_int, [_H, _P(C.c_void_p), _P(C.c_void_p), _ip, _ip]),
+    "bpm_commit_device": (C.c_int, [_H, C.c_void_p]),
+    "bpm_state_device": (C.c_int, [_H, _P(C.c_void_p), _ip, _ip]),
+    "bpm_set_loglike_device": (C.c_int, [_H, C.c_void_p]),
     "bpm_get_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_get_loglike_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_reserve_history": (C.c_int, [_H, C.c_int64]),

@@ -171,7 +171,8 @@ struct PhaseArgs {
     unsigned long long* counters;  // [2] = NaN Metropolis ratios (rare; the only atomic)
     uint32_t* acc_count;   // [n_local] accepted updates of each local chain in this run (one writer per chain)
     double* prop_buf;      // host-callback path: [n_local * ld] proposals by work item
-    double* aux_buf;       // host-callback path: [n_local * 2] (log_corr, ll_prop)
+    double* aux_buf;       // host-callback path: [log_corr (n_local) | ll_prop (n_local)] by work item (two dense arrays: the ln-likes arrive as ONE dense copy,
+                           // host -> device or device -> device; the snooker correction never leaves the device)
     int32_t* ids_buf;      // host-callback path: [n_local] global id by work item (-1 = inactive)
 #ifdef BPM_TEST_HOOKS      // the per-chain decision trace of the parity tests: test variant only (include/bipymc_hip_test.h: bpm_set_trace); the PRODUCT's
     int32_t* trace_i32;    // argument block has no such fields and its kernels no traced branch (trace_i32_of & co. below are compile-time null there)
@@ -1451,6 +1452,131 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     }
 }
 
+#ifdef BPM_EXPERIMENT_XCD
+// ---- EXPERIMENT (round 5; `make variant NAME=xcd DEFS=-DBPM_EXPERIMENT_XCD`; never the product) ---------------------------------
+// A generation loop RESIDENT ON ONE XCD for populations whose state fits one XCD's 4 MB L2 (cfg3: 1 MB, cfg5's share: 2 MB).  The shipped path
+// pays two whole-GPU dependent dispatches per generation (2 x ~2.5 us of launch floor) and gathers partner rows through the Infinity Cache
+// (every packet's acquire invalidates the L2s).  Here ONE launch runs n_phases half generations: 256 workgroups of 1024 threads are launched, the
+// `want` (32) that find themselves on XCC `xcc_want` become workers (one per CU of that XCD), everybody else exits; a worker updates the work items
+// worker, worker + want, ... of every half generation with THE SAME device code as phase_fused_kernel (make_proposal / Target::eval /
+// finish_update: bits identical), rows written with plain stores -- they land in THAT XCD's L2, the only L2 any reader of this launch uses --
+// and between two half generations the workers meet at an XCD-local barrier: every wave waits for its stores (s_waitcnt vmcnt(0): at workgroup
+// scope in threadgroup-split terms, i.e. "visible in the L2", that is all a release needs on gfx942 / gfx950), one lane per workgroup adds to a
+// counter WITHOUT sc1 -- the atomic executes in this XCD's L2 -- and polls it, then every wave drops its CU's vector L1 (buffer_inv sc0).
+// Every wait is bounded (100 MHz clock): a worker that runs into the limit sets ctl[3] and every worker leaves at the next check.
+//   ctl[0] registration ticket, ctl[1] barrier counter, ctl[2] workers registered (diagnostic), ctl[3] error, ctl[4..5] XCC ids seen (diagnostic)
+__device__ __forceinline__ unsigned long long xcd_now() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ uint32_t xcd_l2_add(uint32_t* p, uint32_t v) {      // returns the old value; performed in the XCD's own L2 (no sc1: not agent scope)
+    uint32_t old;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+    return old;
+}
+// -> false when a wait ran into its limit (or another worker reported one)
+__device__ __forceinline__ bool xcd_barrier(uint32_t* ctl, uint32_t target, unsigned long long deadline) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's rows are in the L2
+    __syncthreads();
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        uint32_t ok = 1u;
+        (void)xcd_l2_add(&ctl[1], 1u);
+        while (xcd_l2_add(&ctl[1], 0u) < target) {
+            if (xcd_l2_add(&ctl[3], 0u) != 0u) { ok = 0u; break; }
+            if (xcd_now() > deadline) { (void)xcd_l2_add(&ctl[3], 1u); ok = 0u; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = s_ok != 0u;
+#ifdef BPM_XCD_INV_SC1
+    asm volatile("buffer_inv sc1" ::: "memory");                           // (agent-scope invalidate: the L1 and the L2's non-local lines)
+#else
+    asm volatile("buffer_inv sc0" ::: "memory");                           // the other CUs' rows are in the L2, not in this CU's L1
+#endif
+    return ok;
+}
+template <int ALGO, int TARGET, int LPC, int DPL, int NP>
+__global__ __launch_bounds__(1024) void xcd_resident_kernel(const PhaseArgs* args_g, uint32_t n_phases, uint32_t* ctl, uint32_t want, uint32_t xcc_want,
+                                                            unsigned long long timeout_ticks) {
+    static_assert(LPC < WAVE, "several chains per wavefront: the shapes whose populations fit an L2");
+    constexpr int BLK = 1024, CPW = BLK / LPC;
+    __shared__ uint32_t s_part[1];            // (these shapes keep partner ids in registers: FAST / QUAD paths of make_proposal)
+    __shared__ uint32_t s_worker;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    if (threadIdx.x == 0) {
+        s_worker = 0xFFFFFFFFu;
+        if (xcc == xcc_want) s_worker = atomicAdd(&ctl[0], 1u);
+        atomicOr(&ctl[4 + (xcc >> 5)], 1u << (xcc & 31u));
+    }
+    __syncthreads();
+    const uint32_t worker = s_worker;
+    if (worker >= want) return;
+    const unsigned long long deadline = xcd_now() + timeout_ticks;
+    const int lane = threadIdx.x;
+    const int cw = lane / LPC, q = lane % LPC;
+    // the argument blocks through the constant address space: uniform addresses -> scalar loads, the fields live in SGPRs like kernel arguments
+    typedef const uint32_t __attribute__((address_space(4)))* CWords;
+    auto load_args = [args_g](uint32_t i, PhaseArgs& a) {
+        static_assert(sizeof(PhaseArgs) % 4 == 0, "argument block in words");
+        const CWords src = (CWords)(args_g + i);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&a);
+#pragma unroll
+        for (uint32_t j = 0; j < sizeof(PhaseArgs) / 4u; ++j) dst[j] = src[j];
+    };
+
+    if (!xcd_barrier(ctl, want, deadline)) return;                         // registration: all `want` workers are here (or nobody goes on)
+    if (threadIdx.x == 0 && worker == 0) atomicAdd(&ctl[2], want);
+    constexpr bool LEAN = lean_scalars<TARGET, LPC>();
+    constexpr bool LEAN_CT = LEAN && lean_always<TARGET>();
+    for (uint32_t i = 0; i < n_phases; ++i) {
+        PhaseArgs a;
+        load_args(i, a);
+        // what the host fixes for every batch of this experiment, as constants (the HOT copies of phase_fused_kernel): single GPU, steady state
+        a.mode = 0u; trace_set(a, nullptr, nullptr, nullptr); a.pack = nullptr; a.replay = 0u; a.x_next = nullptr; a.adapt_on = 0u; a.stamps = nullptr;
+        a.accbits = nullptr; a.lo = 0; a.L.world = 1; a.acc_by_item = 0u; a.n_peers = 0u; a.peer_tab = nullptr; a.plan = nullptr; a.rec_tab = nullptr;
+        a.wt = 0u; a.cr_part1 = nullptr; a.accbits_all = nullptr; a.rec_sorted = nullptr;
+        if (ALGO == ALGO_DREAM) a.n_cr = 3;
+        for (uint32_t base = worker * (uint32_t)CPW; base < a.n_items; base += want * (uint32_t)CPW) {        // (uniform per workgroup)
+            const uint32_t w = base + (uint32_t)cw;
+            uint32_t c;
+            const bool active = resolve_chain(a, w, c);
+            // (the target's constants are fetched per sweep, like a launch of the shipped kernel does: held across the barrier code they cost the
+            // 4-lanes-per-chain shape 66 spilled registers under the 128-VGPR cap of a 1024-thread workgroup)
+            const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
+            Work<DPL> wk;
+            wk.item = w;
+            wk.pos_own = a.upd_off + (active ? w : 0u);
+            const uint32_t dim_early = a.L.dim;
+            if constexpr (LEAN) {
+                const bool lean_early = LEAN_CT || a.lean != 0u;
+                auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
+                make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : 2)>(a, c, active, q, cw % 1, s_part, wk, nullptr, nullptr, early);
+            } else {
+                make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw % 1, s_part, wk, nullptr, nullptr);
+            }
+            const double ll_prop = Target<TARGET, LPC, DPL>::eval(wk.p, q, a.L.dim, tc);
+            finish_update<ALGO, LPC, DPL, (LEAN_CT ? 2 : (LEAN ? 1 : 0))>(a, c, active, q, wk, ll_prop);
+        }
+        if (!xcd_barrier(ctl, want * (i + 2u), deadline)) return;
+    }
+}
+// the same launch shape with NO work: what the barriers alone cost
+__global__ __launch_bounds__(1024) void xcd_barrier_only_kernel(uint32_t n_phases, uint32_t* ctl, uint32_t want, uint32_t xcc_want, unsigned long long timeout_ticks) {
+    __shared__ uint32_t s_worker;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    if (threadIdx.x == 0) { s_worker = 0xFFFFFFFFu; if (xcc == xcc_want) s_worker = atomicAdd(&ctl[0], 1u); }
+    __syncthreads();
+    if (s_worker >= want) return;
+    const unsigned long long deadline = xcd_now() + timeout_ticks;
+    for (uint32_t i = 0; i <= n_phases; ++i)
+        if (!xcd_barrier(ctl, want * (i + 1u), deadline)) return;
+}
+#endif   // BPM_EXPERIMENT_XCD
+
 // Replay exchange, receiving side: one work item per position of the half generation's update group; the item of a
 // chain that lives on ANOTHER rank and whose owner accepted its update (accbits_all) rebuilds that proposal -- same
 // records / draws / arithmetic as the owner's update kernel, hence the same bits -- and writes it into this rank's
@@ -1543,7 +1669,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const Pha
     if (!active) return;
     store_row<LPC, DPL>(a.prop_buf + (uint64_t)w * a.L.ld, q, a.L.ld, wk.p);
     if (q == 0) {
-        a.aux_buf[2 * (uint64_t)w] = wk.log_corr;
+        a.aux_buf[w] = wk.log_corr;
         // CR statistic travels through the exchange slots directly
         if (ALGO == ALGO_DREAM) {
             const bool gated = a.adapt_on && a.cr_gate;
@@ -1553,7 +1679,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const Pha
     }
 }
 
-// ... and ln_like values back in (aux_buf[2w+1]).
+// ... and ln_like values back in (aux_buf[n_local + w]).
 template <int ALGO, int LPC, int DPL>
 __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const PhaseArgs a) {
     const int lane = threadIdx.x;
@@ -1567,14 +1693,14 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_commit_kernel(const Phas
     Work<DPL> wk;
     load_row<LPC, DPL>(row_ptr(a.L, c), q, a.L.ld, wk.x);
     load_row<LPC, DPL>(a.prop_buf + (uint64_t)(active ? w : 0u) * a.L.ld, q, a.L.ld, wk.p);
-    wk.log_corr = active ? a.aux_buf[2 * (uint64_t)w] : 0.0;
+    wk.log_corr = active ? a.aux_buf[w] : 0.0;
     wk.ll_cur = a.ll[c - a.lo];
     wk.acc_prev = a.acc_count[c - a.lo];
     if (ALGO == ALGO_DREAM && a.adapt_on) {
         load_row<LPC, DPL>(a.w_mean + (uint32_t)((c - a.lo) * 2u * a.L.ld), q, a.L.ld, wk.w_mean);
         load_row<LPC, DPL>(a.w_m2 + (uint32_t)((c - a.lo) * 2u * a.L.ld), q, a.L.ld, wk.w_m2);
     }
-    const double ll_prop = active ? a.aux_buf[2 * (uint64_t)w + 1] : 0.0;
+    const double ll_prop = active ? a.aux_buf[a.L.n_local + w] : 0.0;
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     wk.acc_hi = h0.z; wk.acc_lo = h0.w;
     wk.delta = 0.0; wk.gamma = 0.0; wk.cr_idx = -1; wk.d_prime = 0; wk.jump = 0; wk.snk = 0; wk.maskbits = 0; wk.item = w; wk.pos_own = 0u;

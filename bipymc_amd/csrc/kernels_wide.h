@@ -346,7 +346,7 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
     }
     if (!FUSED) {
         if (lane == 0) {
-            a.aux_buf[2 * (uint64_t)w] = log_corr;
+            a.aux_buf[w] = log_corr;
             if (DREAM) {
                 *delta_ptr(a.L, c) = cr_stat ? delta : 0.0;
                 *cridx_ptr(a.L, c) = cr_stat ? (double)cr_idx : -1.0;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_kernel(
     if (a.n_peers) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // pushes acknowledged before the wavefront ends (finish_update)
 }
 
-// ... and the ln_like values of the host callback back in (aux_buf[2 w + 1]): Metropolis, state, history, Welford moments.
+// ... and the ln_like values of the host callback back in (aux_buf[n_local + w]): Metropolis, state, history, Welford moments.
 template <int ALGO>
 __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_commit_kernel(const PhaseArgs a) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BPM_BLOCK_WAVE) void phase_wide_commit_kernel(const
     const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(id), li = c - a.lo;
     const uint32_t dim = a.L.dim, ld = a.L.ld, npairs = (dim + 1u) >> 1;
     const uint32_t n_chunks = (npairs + WIDE_CHUNK_PAIRS - 1u) / WIDE_CHUNK_PAIRS;
-    const double ll_cur = a.ll[li], ll_prop = a.aux_buf[2 * (uint64_t)w + 1], log_corr = a.aux_buf[2 * (uint64_t)w];
+    const double ll_cur = a.ll[li], ll_prop = a.aux_buf[a.L.n_local + w], log_corr = a.aux_buf[w];
     const uint32_t acc_prev = a.acc_count[li];
     const u32x4 h0 = chain_block(a.seed, c, a.t, SLOT_HDR0);
     double alpha = exp((ll_prop + log_corr) - ll_cur);

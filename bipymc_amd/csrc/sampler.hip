@@ -425,7 +425,12 @@ struct bpm_sampler {
     // host-callback path: pinned staging of what bpm_propose reads back and bpm_commit sends (work-item order)
     int32_t* h_ids = nullptr;
     double* h_props = nullptr;
-    double* h_aux = nullptr;
+    double* h_ll = nullptr;                  // [n_local] ln-likes by work item on their way in (bpm_commit_chunk)
+    std::vector<hipEvent_t> chunk_ev;        // one event behind every chunk of the proposals' read-back (bpm_propose_begin)
+    int32_t prop_chunks = 0, prop_given = 0; // chunks of the open half generation / chunks whose ln-likes have been handed in
+    int prop_mode = 0;                       // how the open half generation was proposed: 1 host staging (chunks), 2 device-resident
+    int64_t prop_active = 0;                 // its active work items
+    bool prop_whole = false;                 // it was proposed through bpm_propose (caller-owned buffers): bpm_commit finishes it
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
     int32_t* trace_i32 = nullptr;      // per-chain decision trace (bpm_set_trace: test variant only; always null in the product library)
@@ -541,6 +546,11 @@ struct bpm_sampler {
     // (they re-evaluate it from the own row); ll_stale says that generations have run since it was last evaluated -- refresh_ll brings it up
     // to date for whoever reads it (bpm_get_loglike, the outlier check)
     bool lean = false, ll_stale = false;
+#ifdef BPM_EXPERIMENT_XCD      // (round 5 experiment: a generation loop resident on one XCD, kernels.h: xcd_resident_kernel)
+    PhaseArgs* xcd_args = nullptr;           // device: the argument blocks of one batch of half generations
+    uint32_t* xcd_ctl = nullptr;             // device: ticket | barrier counter | workers | error | XCC ids seen
+    int64_t xcd_gens = 0;                    // generations run this way
+#endif
     bool gen_adapt_on = false;
     bool gen_cr_reduce = false;       // this generation's (delta, cr) slots are reduced (adaptation on AND the gate of dream.py:123 open)
 };
@@ -886,7 +896,8 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
             if (p) (void)hipFree(p);
     if (s->h_ids) (void)hipHostFree(s->h_ids);
     if (s->h_props) (void)hipHostFree(s->h_props);
-    if (s->h_aux) (void)hipHostFree(s->h_aux);
+    if (s->h_ll) (void)hipHostFree(s->h_ll);
+    for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -1154,7 +1165,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         CKD(dev_alloc(&s->ids_buf, s->n_local));
         HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_ids), s->n_local * sizeof(int32_t), hipHostMallocDefault));
         HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_props), row_d * sizeof(double), hipHostMallocDefault));
-        HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_aux), 2 * (size_t)s->n_local * sizeof(double), hipHostMallocDefault));
+        HIPCKD(hipHostMalloc(reinterpret_cast<void**>(&s->h_ll), (size_t)s->n_local * sizeof(double), hipHostMallocDefault));
     }
     if (s->world > 1 && !cfg->nccl_uid) { bpm_destroy(s); return fail("bpm_create: nccl_uid required when world_size > 1"); }
     // Test mode: a uid starting with "BPMLOCAL" makes the ranks of a world handles of ONE process on one GPU;
@@ -2013,6 +2024,70 @@ struct HostCkpt {
     int64_t k_gen, t_abs, hist_rows, rows_logical, w_rows;
 };
 
+#ifdef BPM_EXPERIMENT_XCD
+// EXPERIMENT (never the product): up to `want_gens` steady-state generations of a single-GPU sampler as ONE launch of xcd_resident_kernel -- the
+// host walks prepare_generation / finish_generation for every generation of the batch (a batch never crosses a table window), collects the two
+// argument blocks of each, copies them to the device and launches on the HIP stream (acquire + release around the one kernel).
+static int xcd_mode() { static const int m = getenv("BPM_XCD") ? atoi(getenv("BPM_XCD")) : 0; return m; }
+static bool xcd_eligible(const Group& g) {
+    bpm_sampler* s = g.h[0];
+    if (xcd_mode() == 0 || g.R != 1 || s->world != 1 || s->comm || s->trace_i32 || s->cfg.running_moments || s->cfg.outlier_every > 0) return false;
+    if (s->cfg.algo == BPM_ALGO_DREAM && s->cfg.burnin_gen > s->k_gen) return false;
+    if (s->cfg.algo == BPM_ALGO_DEMC && s->cfg.target_id == BPM_TARGET_BANANA_2D && s->shape.idx == 0) return true;
+    if (s->cfg.algo == BPM_ALGO_DREAM && s->cfg.target_id == BPM_TARGET_MIXTURE_PAIRS && s->shape.idx == 1 && s->cfg.del_pairs == 3 && s->cfg.n_cr == 3) return true;
+    return false;
+}
+static int xcd_batch(bpm_sampler* s, int64_t want_gens, int64_t* did) {
+    CK(leave_direct(s));
+    constexpr int MAX_PH = 2 * PERM_CHUNK;
+    if (!s->xcd_args) {
+        CK(dev_alloc(&s->xcd_args, (size_t)MAX_PH));
+        CK(dev_alloc(&s->xcd_ctl, 16));
+        HIPCK(hipMemsetAsync(s->xcd_ctl, 0, 16 * sizeof(uint32_t), s->stream));
+    }
+    bpm::DirectQueue* const dq_saved = g_dq;
+    g_dq = nullptr; g_wt_stores = false;
+    std::vector<PhaseArgs> host;
+    int64_t n = 0;
+    while (n < want_gens) {
+        CK(prepare_generation(s, want_gens - n));
+        for (int ph = 0; ph < 2; ++ph) if (s->cur_args[ph].n_items > 0) host.push_back(s->cur_args[ph]);
+        CK(finish_generation(s));
+        ++n;
+        if (s->t_abs >= s->tab_t0 + s->tab_K) break;          // the next generation belongs to the next window of the tables
+    }
+    g_dq = dq_saved;
+    const uint32_t want = 32u, xcc = (uint32_t)(xcd_mode() >> 4) & 7u;
+    const unsigned long long timeout = 50000000ull;          // 0.5 s of the 100 MHz clock
+    HIPCK(hipMemcpyAsync(s->xcd_args, host.data(), host.size() * sizeof(PhaseArgs), hipMemcpyHostToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));                   // (host is a local vector)
+    HIPCK(hipMemsetAsync(s->xcd_ctl, 0, 3 * sizeof(uint32_t), s->stream));
+    if ((xcd_mode() & 15) == 2) {
+        hipLaunchKernelGGL(xcd_barrier_only_kernel, dim3(256), dim3(1024), 0, s->stream, (uint32_t)host.size(), s->xcd_ctl, want, xcc, timeout);
+    } else if (s->cfg.algo == BPM_ALGO_DEMC) {
+        hipLaunchKernelGGL((xcd_resident_kernel<ALGO_DEMC, TARGET_BANANA, 1, 2, 1>), dim3(256), dim3(1024), 0, s->stream, (const PhaseArgs*)s->xcd_args, (uint32_t)host.size(),
+                           s->xcd_ctl, want, xcc, timeout);
+    } else {
+        hipLaunchKernelGGL((xcd_resident_kernel<ALGO_DREAM, TARGET_MIXTURE, 4, 2, 3>), dim3(256), dim3(1024), 0, s->stream, (const PhaseArgs*)s->xcd_args, (uint32_t)host.size(),
+                           s->xcd_ctl, want, xcc, timeout);
+    }
+    HIPCK(hipGetLastError());
+    s->xcd_gens += n;
+    *did = n;
+    return 0;
+}
+static int xcd_check(bpm_sampler* s) {
+    if (!s->xcd_ctl) return 0;
+    uint32_t c[6];
+    HIPCK(hipMemcpyAsync(c, s->xcd_ctl, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    if (c[3] != 0 || (c[2] != 32u && (xcd_mode() & 15) != 2))
+        return fail("XCD-resident experiment: the workers did not meet (registered " + std::to_string(c[0]) + " workgroups on the chosen XCD, workers " + std::to_string(c[2]) +
+                    ", error " + std::to_string(c[3]) + ", XCC ids seen mask " + std::to_string(c[4]) + "): results of this call are invalid");
+    return 0;
+}
+#endif
+
 // Does this group's generation loop go through the library's own AQL queue(s)?  A single GPU's sampler, or -- with the push exchange, where
 // nothing of the loop is a collective call -- a rank of a world; group_direct: the R ranks of a local group, each on a queue of its own.
 // (run_generations and the arena self-test of bpm_push_selftest ask the same question: the probe must take the path the updates take.)
@@ -2037,6 +2112,15 @@ static int run_generations(const Group& g, int64_t n_gens) {
     bool push_entered = false;
     while (done < n_gens) {
         const bool adapting = dream && s0->cfg.burnin_gen > s0->k_gen;          // dream.py:92: CR statistics travel in the dense block
+#ifdef BPM_EXPERIMENT_XCD
+        if (xcd_eligible(g)) {
+            int64_t did = 0;
+            CK(xcd_batch(s0, n_gens - done, &did));
+            done += did;
+            if (done >= n_gens) CK(xcd_check(s0));
+            continue;
+        }
+#endif
         if (push || !(s0->sparse_enabled && !adapting)) {
             // (HIP-graph replay of steady-state chunks was built and measured in round 1 -- 13.1 vs 12.5 us per generation at cfg2 -- and
             // removed in round 3: DESIGN.md section 5 item 6)
@@ -2711,52 +2795,26 @@ extern "C" int bpm_synchronize(bpm_handle_t s) {
     return push_check_error(s);
 }
 
-extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, int32_t* n_out) {
-    CK(check_handle(s));
-    CK(set_device(s));
-    if (!s->run_open) return fail("bpm_propose: call bpm_begin_run first");
-    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail("bpm_propose: sampler has a device target; use bpm_step");
-    if (s->proposed) return fail("bpm_propose: previous proposals not committed");
-    if (!out_prop || !out_ids || !n_out) return fail("bpm_propose: null argument");
+// ---- host-callback ln_like_fn (samplers.py:36-43): one half generation = proposals out, ln-likes in ------------------------------------------------
+// Round 5: ONE core in three transports.  The proposal kernel writes the half generation's proposals (work-item order) into prop_buf and the
+// snooker corrections into aux_buf[0 .. n_local); the ln-likes arrive in aux_buf[n_local ..) -- from pinned host memory chunk by chunk while the
+// caller evaluates (bpm_propose_begin / _chunk, bpm_commit_chunk / _end), through the caller-owned buffers of rounds 1-4 (bpm_propose / bpm_commit:
+// the same calls with one chunk and a compaction copy), or from DEVICE memory the caller's own framework computed them in (bpm_propose_device /
+// bpm_commit_device: no PCIe).  Then the commit kernel: Metropolis (samplers.py:328-336), append (chain.py:51-54), CR statistics.
+static int propose_launch(bpm_sampler* s, const char* who) {
+    if (!s->run_open) return fail(std::string(who) + ": call bpm_begin_run first");
+    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail(std::string(who) + ": sampler has a device target; use bpm_step");
+    if (s->proposed) return fail(std::string(who) + ": previous proposals not committed");
     if (s->phase == 0) CK(prepare_generation(s, 1));
     const PhaseArgs& a = s->cur_args[s->phase];
     HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
     if (a.n_items > 0) g_propose[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
-    // ids, proposals and the (log_corr, .) pairs come back into pinned buffers in one go; bpm_commit fills in the ln-likes and sends the pairs back
-    const int32_t* ids = s->h_ids;
-    const double* props = s->h_props;
-    HIPCK(hipMemcpyAsync(s->h_ids, s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipMemcpyAsync(s->h_props, s->prop_buf, (size_t)a.n_items * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipMemcpyAsync(s->h_aux, s->aux_buf, 2 * (size_t)s->n_local * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIPCK(hipStreamSynchronize(s->stream));
-    // compact the active work items (work-item order is kept; commit uses the same order)
-    int32_t n = 0;
-    for (uint32_t w = 0; w < a.n_items; ++w) {
-        if (ids[w] < 0) continue;
-        std::memcpy(out_prop + (size_t)n * s->dim, props + (size_t)w * s->ld, s->dim * sizeof(double));
-        out_ids[n++] = ids[w];
-    }
-    *n_out = n;
-    s->proposed = true;
     return 0;
 }
-
-extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
-    CK(check_handle(s));
-    CK(set_device(s));
-    if (!s->proposed) return fail("bpm_commit: nothing proposed");
+// the commit kernel + the bookkeeping of the half generation (the ln-likes of every active work item are in aux_buf[n_local ..) on the stream by now)
+static int commit_finish(bpm_sampler* s, int64_t n_active) {
     const PhaseArgs& a = s->cur_args[s->phase];
-    // scatter the values back to work-item order (ids and the pairs are still in the pinned buffers bpm_propose filled)
-    const int32_t* ids = s->h_ids;
-    double* aux = s->h_aux;
-    size_t n = 0;
-    for (uint32_t w = 0; w < a.n_items; ++w) {
-        if (ids[w] < 0) continue;
-        if (!ll_prop) return fail("bpm_commit: null ll_prop");
-        aux[2 * (size_t)w + 1] = ll_prop[n++];
-    }
-    HIPCK(hipMemcpyAsync(s->aux_buf, aux, 2 * (size_t)s->n_local * sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (a.n_items > 0) g_commit[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
     if (s->cfg.algo == BPM_ALGO_DEMC_SYNC) {       // one propose/commit per generation: apply the banked updates
@@ -2764,20 +2822,211 @@ extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
                              hipMemcpyDeviceToDevice, s->stream));
         CK(allgather_state(s));
         HIPCK(hipStreamSynchronize(s->stream));
-        s->proposed = false;
+        s->proposed = false; s->prop_mode = 0;
         return finish_generation(s);       // (synchronous DE-MC: never DREAM, no outlier check)
     }
     CK(allgather_state(s));
     HIPCK(hipStreamSynchronize(s->stream));
-    s->proposed = false;
+    s->proposed = false; s->prop_mode = 0;
     if (s->phase == 0) {
         s->phase = 1;
-        s->phase_a_updates = (int64_t)n;
+        s->phase_a_updates = n_active;
     } else {
         s->phase = 0;
         CK(finish_generation(s));
         if (s->outlier_due) { bpm_sampler* one[1] = {s}; CK(group_outlier_check(Group{one, 1, s->comm != nullptr})); }
     }
+    return 0;
+}
+static inline uint32_t chunk_lo(uint32_t n_items, int32_t n_chunks, int32_t k) { return (uint32_t)(((uint64_t)n_items * (uint64_t)k) / (uint64_t)n_chunks); }
+
+extern "C" int bpm_propose_begin(bpm_handle_t s, int32_t n_chunks) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (n_chunks < 1 || n_chunks > 256) return fail("bpm_propose_begin: 1 <= n_chunks <= 256");
+    CK(propose_launch(s, "bpm_propose_begin"));
+    const PhaseArgs& a = s->cur_args[s->phase];
+    while ((int32_t)s->chunk_ev.size() < n_chunks) {
+        hipEvent_t e = nullptr;
+        HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->chunk_ev.push_back(e);
+    }
+    // the ids first (32 KB), then the proposals chunk by chunk, an event behind each: the DMA of chunk k + 1 runs while the caller evaluates chunk k
+    HIPCK(hipMemcpyAsync(s->h_ids, s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    for (int32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t w0 = chunk_lo(a.n_items, n_chunks, k), w1 = chunk_lo(a.n_items, n_chunks, k + 1);
+        if (w1 > w0)
+            HIPCK(hipMemcpyAsync(s->h_props + (size_t)w0 * s->ld, s->prop_buf + (size_t)w0 * s->ld, (size_t)(w1 - w0) * s->ld * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIPCK(hipEventRecord(s->chunk_ev[(size_t)k], s->stream));
+    }
+    s->prop_chunks = n_chunks; s->prop_mode = 1; s->prop_given = 0; s->prop_active = 0; s->prop_whole = false;
+    s->proposed = true;
+    return 0;
+}
+
+extern "C" int bpm_propose_chunk(bpm_handle_t s, int32_t k, const double** rows, const int32_t** ids, int32_t* n_rows, int32_t* ld) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed || s->prop_mode != 1) return fail("bpm_propose_chunk: call bpm_propose_begin first");
+    if (k < 0 || k >= s->prop_chunks || !rows || !ids || !n_rows || !ld) return fail("bpm_propose_chunk: bad argument");
+    const PhaseArgs& a = s->cur_args[s->phase];
+    HIPCK(hipEventSynchronize(s->chunk_ev[(size_t)k]));
+    const uint32_t w0 = chunk_lo(a.n_items, s->prop_chunks, k), w1 = chunk_lo(a.n_items, s->prop_chunks, k + 1);
+    *rows = s->h_props + (size_t)w0 * s->ld;
+    *ids = s->h_ids + w0;
+    *n_rows = (int32_t)(w1 - w0);
+    *ld = (int32_t)s->ld;
+    return 0;
+}
+
+extern "C" int bpm_commit_chunk(bpm_handle_t s, int32_t k, const double* ll) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed || s->prop_mode != 1) return fail("bpm_commit_chunk: call bpm_propose_begin first");
+    if (k < 0 || k >= s->prop_chunks) return fail("bpm_commit_chunk: bad chunk");
+    const PhaseArgs& a = s->cur_args[s->phase];
+    const uint32_t w0 = chunk_lo(a.n_items, s->prop_chunks, k), w1 = chunk_lo(a.n_items, s->prop_chunks, k + 1);
+    if (w1 > w0) {
+        if (!ll) return fail("bpm_commit_chunk: null ll");
+        // (into pinned staging first: the caller's array may be gone before the copy runs)
+        std::memcpy(s->h_ll + w0, ll, (size_t)(w1 - w0) * sizeof(double));
+        for (uint32_t w = w0; w < w1; ++w) s->prop_active += s->h_ids[w] >= 0 ? 1 : 0;
+        HIPCK(hipMemcpyAsync(s->aux_buf + s->n_local + w0, s->h_ll + w0, (size_t)(w1 - w0) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    s->prop_given += 1;
+    return 0;
+}
+
+extern "C" int bpm_commit_end(bpm_handle_t s) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed || s->prop_mode != 1) return fail("bpm_commit_end: nothing proposed with bpm_propose_begin");
+    s->prop_whole = false;
+    if (s->prop_given != s->prop_chunks) return fail("bpm_commit_end: " + std::to_string(s->prop_given) + " of " + std::to_string(s->prop_chunks) + " chunks were given their ln-likes (bpm_commit_chunk)");
+    return commit_finish(s, s->prop_active);
+}
+
+// the caller-owned-buffer form of rounds 1-4, compacted to the active work items.  Since round 5 the read-back runs in pieces INSIDE the call: the
+// compaction copy of piece k (one host core reading freshly DMA'd memory: ~100 us for cfg2's 3.3 MB) runs under the DMA of piece k + 1 (~130 us); four
+// pieces from 1 MB per half generation.
+extern "C" int bpm_propose(bpm_handle_t s, double* out_prop, int32_t* out_ids, int32_t* n_out) {
+    CK(check_handle(s));
+    if (!out_prop || !out_ids || !n_out) return fail("bpm_propose: null argument");
+    if (s->proposed) return fail("bpm_propose: previous proposals not committed");
+    const size_t bytes = (size_t)(s->n_local / 2u + 1u) * s->ld * sizeof(double);
+    static const int forced = getenv("BPM_PROPOSE_PIECES") ? atoi(getenv("BPM_PROPOSE_PIECES")) : 0;      // (A/B switch: tools/host_callback_ab.py)
+    const int32_t pieces = forced > 0 ? std::min(forced, 256) : (bytes >= ((size_t)1 << 20) ? 4 : 1);
+    // (cfg2's shape, 3.3 MB per half generation, two runs each: 1 piece 6.5 / 6.5e6 chain-updates/s, 2 pieces 6.9 / 5.7, 4 pieces 8.3 / 7.0, 8 pieces 5.7 / 5.5 --
+    // every piece costs an event wait and a DMA submission: profiles/r05_host_callback.txt)
+    CK(bpm_propose_begin(s, pieces));
+    int32_t n = 0;
+    for (int32_t k = 0; k < pieces; ++k) {
+        const double* props = nullptr; const int32_t* ids = nullptr; int32_t nr = 0, ld = 0;
+        CK(bpm_propose_chunk(s, k, &props, &ids, &nr, &ld));
+        // compact the active work items (work-item order is kept; commit uses the same order)
+        if (s->ld == s->dim && nr > 0) {                                  // (runs of active rows in one copy)
+            int32_t w = 0;
+            while (w < nr) {
+                if (ids[w] < 0) { ++w; continue; }
+                int32_t e = w;
+                while (e < nr && ids[e] >= 0) ++e;
+                std::memcpy(out_prop + (size_t)n * s->dim, props + (size_t)w * s->ld, (size_t)(e - w) * s->dim * sizeof(double));
+                std::memcpy(out_ids + n, ids + w, (size_t)(e - w) * sizeof(int32_t));
+                n += e - w; w = e;
+            }
+        } else {
+            for (int32_t w = 0; w < nr; ++w) {
+                if (ids[w] < 0) continue;
+                std::memcpy(out_prop + (size_t)n * s->dim, props + (size_t)w * s->ld, s->dim * sizeof(double));
+                out_ids[n++] = ids[w];
+            }
+        }
+    }
+    *n_out = n;
+    s->prop_whole = true;
+    return 0;
+}
+
+extern "C" int bpm_commit(bpm_handle_t s, const double* ll_prop) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed) return fail("bpm_commit: nothing proposed");
+    if (s->prop_mode != 1 || !s->prop_whole) return fail("bpm_commit: the open half generation was proposed with another entry point (bpm_propose_begin / bpm_propose_device)");
+    const PhaseArgs& a = s->cur_args[s->phase];
+    // scatter the values back to work-item order (the ids are still in the pinned buffer bpm_propose filled)
+    std::vector<double> full(a.n_items, 0.0);
+    size_t n = 0;
+    for (uint32_t w = 0; w < a.n_items; ++w) {
+        if (s->h_ids[w] < 0) continue;
+        if (!ll_prop) return fail("bpm_commit: null ll_prop");
+        full[w] = ll_prop[n++];
+    }
+    for (int32_t k = 0; k < s->prop_chunks; ++k) CK(bpm_commit_chunk(s, k, full.data() + chunk_lo(a.n_items, s->prop_chunks, k)));
+    return bpm_commit_end(s);
+}
+
+// ---- the likelihood evaluated ON THE DEVICE by the caller's own framework (torch, cupy ...): nothing crosses PCIe --------------------------
+extern "C" int bpm_propose_device(bpm_handle_t s, const double** rows_dev, const int32_t** ids_dev, int32_t* n_rows, int32_t* ld) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!rows_dev || !ids_dev || !n_rows || !ld) return fail("bpm_propose_device: null argument");
+    CK(propose_launch(s, "bpm_propose_device"));
+    const PhaseArgs& a = s->cur_args[s->phase];
+    // (the active-row count for the accept bookkeeping: the ids come back, 32 KB; with one rank every work item is active)
+    HIPCK(hipMemcpyAsync(s->h_ids, s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));                  // the proposals are complete: the caller's framework reads them on ITS stream
+    int64_t act = 0;
+    for (uint32_t w = 0; w < a.n_items; ++w) act += s->h_ids[w] >= 0 ? 1 : 0;
+    s->prop_active = act;
+    *rows_dev = s->prop_buf; *ids_dev = s->ids_buf; *n_rows = (int32_t)a.n_items; *ld = (int32_t)s->ld;
+    s->prop_mode = 2; s->prop_chunks = 0;
+    s->proposed = true;
+    return 0;
+}
+
+extern "C" int bpm_commit_device(bpm_handle_t s, const double* ll_dev) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->proposed || s->prop_mode != 2) return fail("bpm_commit_device: nothing proposed with bpm_propose_device");
+    const PhaseArgs& a = s->cur_args[s->phase];
+    if (a.n_items > 0) {
+        if (!ll_dev) return fail("bpm_commit_device: null ll_dev");
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ll_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != s->cfg.device) {
+            (void)hipGetLastError();
+            return fail("bpm_commit_device: ll_dev must be device memory of this sampler's GPU (float64, one value per proposal row, contiguous)");
+        }
+        // the caller's framework may have computed the values on any stream of this device: wait for the device, then copy on ours
+        HIPCK(hipDeviceSynchronize());
+        HIPCK(hipMemcpyAsync(s->aux_buf + s->n_local, ll_dev, (size_t)a.n_items * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    }
+    return commit_finish(s, s->prop_active);
+}
+
+// the local chains' CURRENT states where they lie in device memory (n_local rows of *ld doubles), and their ln-likes from device memory: what a
+// device-resident likelihood needs once per (re)initialisation (the host form: bpm_get_state + bpm_set_loglike)
+extern "C" int bpm_state_device(bpm_handle_t s, const double** rows_dev, int32_t* n_rows, int32_t* ld) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!rows_dev || !n_rows || !ld) return fail("bpm_state_device: null argument");
+    HIPCK(hipStreamSynchronize(s->stream));
+    *rows_dev = s->G + (uint64_t)s->rank * s->L.blk; *n_rows = (int32_t)s->n_local; *ld = (int32_t)s->ld;
+    return 0;
+}
+extern "C" int bpm_set_loglike_device(bpm_handle_t s, const double* ll_dev) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail("bpm_set_loglike_device: host-callback targets only");
+    hipPointerAttribute_t at;
+    if (!ll_dev || hipPointerGetAttributes(&at, ll_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != s->cfg.device) {
+        (void)hipGetLastError();
+        return fail("bpm_set_loglike_device: ll_dev must be device memory of this sampler's GPU (float64, n_local values)");
+    }
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpyAsync(s->ll, ll_dev, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (s->hist_rows >= 1 && s->hist_rows == s->rows_logical)
+        HIPCK(hipMemcpyAsync(s->llhist + (size_t)(s->hist_rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
     return 0;
 }
 

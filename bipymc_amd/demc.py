@@ -73,7 +73,25 @@ class DeMcMpi(object):
         self.warm_start = kwargs.get("warm_start", False)
         self.checkpoint = kwargs.get("checkpoint", 0)
         self.log_like_fn = ln_like_fn
-        self._vectorized = bool(kwargs.get("vectorized", False))
+        # how ln_like_fn is called when it is NOT one of the shipped device targets (samplers.py:36-43 calls it row by row):
+        #   vectorized=False   one Python call per proposal row, like the reference
+        #   vectorized=True    one call per block of rows: ln_like_fn((n, dim) float64 ndarray, **ln_kwargs) -> n values
+        #   vectorized="device"  the block stays on the GPU: ln_like_fn is handed an object with `__cuda_array_interface__` (engine.DeviceRows:
+        #                      `torch.as_tensor(rows, device="cuda")` wraps it without a copy) and returns n float64 values in device memory
+        #                      (a torch / cupy array) -- nothing crosses PCIe (include/bipymc_hip.h: bpm_propose_device / bpm_commit_device)
+        # callback_chunks > 1: the half generation's proposals are handed to ln_like_fn in that many pieces, the DMA of piece k + 1 under the evaluation
+        # of piece k (vectorized=True: one call per piece); default: one call per half generation
+        vec = kwargs.get("vectorized", False)
+        self._device_callback = isinstance(vec, str) and vec == "device"
+        if isinstance(vec, str) and not self._device_callback:
+            raise ValueError("vectorized must be False, True or \"device\"")
+        self._vectorized = bool(vec)
+        self._callback_chunks = kwargs.get("callback_chunks", None)
+        # callback_threads > 1 (vectorized=True only; ln_like_fn must then be thread-safe): the pieces of a half generation are evaluated by a pool of
+        # host threads -- NumPy releases the interpreter lock inside its loops, and ONE core reading 3 MB of freshly DMA'd proposals is what bounds
+        # the host path at cfg2's shape (bench.py: host_callback_config)
+        self._callback_threads = int(kwargs.get("callback_threads", 1))
+        self._pool = None
         self._ln_kwargs = dict(ln_kwargs)
         self._freeze_ln_like_fn(**self._ln_kwargs)
         if self.n_chains % self.comm.size != 0:
@@ -254,6 +272,9 @@ class DeMcMpi(object):
         self._hist_cache = None
         self._hist_cache_rows = -1
         if not self.uses_device_target:
+            if self._device_callback:
+                self._engine.set_loglike_device(self.log_like_fn(self._engine.state_device(), **self._ln_kwargs))
+                return
             X = self._engine.get_state()
             lo = self.comm.rank * self.n_local
             self._engine.set_loglike(self._eval_ln_like(X[lo:lo + self.n_local]))
@@ -324,16 +345,55 @@ class DeMcMpi(object):
         self.comm.Barrier()
 
     def _host_generation(self):
-        """One generation with a Python ln_like_fn: two propose/commit half generations."""
+        """One generation with a Python ln_like_fn: two propose/commit half generations (demc.py:103-109,126-132 call ln_like through
+        _mut_prop_ratio, samplers.py:328-332).  The proposals come back in pieces, the DMA of the next piece under the evaluation of this one;
+        with vectorized="device" they never leave the GPU."""
+        eng = self._engine
+        if self._device_callback:
+            for _ in range(2):
+                eng.commit_device(self.log_like_fn(eng.propose_device(), **self._ln_kwargs))
+            return
+        # Default: the one-call form (bpm_propose / bpm_commit; the library overlaps the read-back with its own compaction copy).  The piecewise form
+        # pays off when the callback is expensive per row; with a cheap vectorised NumPy likelihood it measured no gain at cfg2's shape (the evaluation
+        # then reads freshly DMA'd memory itself, and every piece costs a few Python calls: profiles/r05_host_callback.txt)
+        chunks = self._callback_chunks
+        if (chunks is None or chunks <= 1) and self._callback_threads <= 1 and hasattr(eng, "propose"):
+            for _ in range(2):
+                props, _ids = eng.propose()
+                eng.commit(self._eval_ln_like(props))
+            return
+        chunks = 1 if chunks is None else chunks
+        def piece(rows, ids):
+            if len(ids) and ids.min() < 0:                           # idle work items of a rank of a world: no call, any value
+                act = ids >= 0
+                ll = np.zeros(len(ids))
+                ll[act] = self._eval_ln_like(rows[act])
+                return ll
+            return self._eval_ln_like(rows)
+        if self._vectorized and self._callback_threads > 1 and hasattr(eng, "propose_begin"):
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self._callback_threads)
+            chunks = max(chunks, self._callback_threads)
+            for _ in range(2):
+                eng.propose_begin(chunks)
+                futs = [self._pool.submit(lambda k=k: piece(*eng.propose_chunk(k))) for k in range(chunks)]
+                for k, f in enumerate(futs):
+                    eng.commit_chunk(k, f.result())                  # (the library is called from this thread only once the values exist)
+                eng.commit_end()
+            return
         for _ in range(2):
-            props, _ids = self._engine.propose()
-            self._engine.commit(self._eval_ln_like(props))
+            for k, rows, ids in eng.propose_chunks(chunks):
+                eng.commit_chunk(k, piece(rows, ids))
+            eng.commit_end()
 
     def _eval_ln_like(self, thetas):
         """ln_like_fn on a block of rows: one Python call per row like the reference (samplers.py:36-43), or
         -- opt-in `vectorized=True` -- one call on the whole (n, dim) block returning n values."""
         if self._vectorized and len(thetas):
-            v = np.asarray(self.log_like_fn(np.array(thetas, dtype=np.float64), **self._ln_kwargs), dtype=np.float64)
+            # (the block is handed over as it lies in the library's pinned staging when it is contiguous -- even dim --: a view, valid during the call)
+            block = thetas if isinstance(thetas, np.ndarray) and thetas.dtype == np.float64 and thetas.flags["C_CONTIGUOUS"] else np.array(thetas, dtype=np.float64)
+            v = np.asarray(self.log_like_fn(block, **self._ln_kwargs), dtype=np.float64)
             return v.reshape(len(thetas))
         return np.array([self._call_ln_like(p) for p in thetas], dtype=np.float64)
 

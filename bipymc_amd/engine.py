@@ -19,6 +19,60 @@ def _iptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+_dp_type = C.POINTER(C.c_double)
+_ip_type = C.POINTER(C.c_int32)
+
+
+class DeviceRows(object):
+    """n rows of dim float64 coordinates in DEVICE memory (row stride ld doubles), read-only: what a device-resident likelihood is handed.  Exposes
+    the CUDA array interface, which PyTorch-ROCm and CuPy-ROCm consume without a copy: `torch.as_tensor(rows, device="cuda")`."""
+
+    def __init__(self, ptr, n, dim, ld, ids_ptr):
+        self.ptr, self.n, self.dim, self.ld, self._ids_ptr = int(ptr), int(n), int(dim), int(ld), int(ids_ptr)
+        self.shape = (self.n, self.dim)
+
+    @property
+    def __cuda_array_interface__(self):
+        # (read-only by contract; PyTorch refuses the interface's read-only flag, so it is not set)
+        return dict(shape=(self.n, self.dim), typestr="<f8", data=(self.ptr, False), strides=(self.ld * 8, 8), version=3)
+
+    @property
+    def ids(self):
+        return _DeviceVector(self._ids_ptr, self.n, "<i4")
+
+    def __len__(self):
+        return self.n
+
+
+class _DeviceVector(object):
+    def __init__(self, ptr, n, typestr):
+        self.ptr, self.n, self.typestr = int(ptr), int(n), typestr
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=(self.n,), typestr=self.typestr, data=(self.ptr, False), strides=None, version=3)
+
+
+def _device_pointer(obj, n, what):
+    """device address of a contiguous float64 vector of n values: anything with `__cuda_array_interface__` (torch / cupy arrays) or data_ptr()"""
+    cai = getattr(obj, "__cuda_array_interface__", None)
+    if cai is not None:
+        shape = tuple(cai["shape"])
+        size = int(np.prod(shape)) if shape else 1
+        if cai["typestr"] not in ("<f8", "=f8", "|f8"):
+            raise TypeError("%s must be float64 on the device (got %s)" % (what, cai["typestr"]))
+        if cai.get("strides") is not None and len(shape) == 1 and tuple(cai["strides"]) != (8,):
+            raise ValueError("%s must be contiguous" % what)
+        if len(shape) > 1 and size != max(shape):
+            raise ValueError("%s must be one value per row (got shape %s)" % (what, shape))
+        if n is not None and size != n:
+            raise ValueError("%s: %d values for %d rows" % (what, size, n))
+        return int(cai["data"][0])
+    if hasattr(obj, "data_ptr"):
+        return int(obj.data_ptr())
+    raise TypeError("%s must live in device memory: an object with __cuda_array_interface__ (torch.Tensor on the GPU, cupy.ndarray)" % what)
+
+
 class HipEngine(object):
     def __init__(self, algo, n_chains, dim, target_id, target_params, seed, device=0, rank=0, world_size=1,
                  nccl_uid=None, gamma_scale=1.0, del_pairs=3, burnin_gen=300, n_cr_gen=50, n_cr=3,
@@ -172,6 +226,66 @@ class HipEngine(object):
     def commit(self, ll_prop):
         ll = np.ascontiguousarray(ll_prop, dtype=np.float64)
         self._ck(self.lib.bpm_commit(self._h, _dptr(ll) if ll.size else None))
+
+    # ---- the same half generation, read-back overlapped with the caller's evaluation (bpm_propose_begin / _chunk, bpm_commit_chunk / _end) --------
+    def propose_chunks(self, n_chunks):
+        """Generator over the half generation's proposals in n_chunks pieces: yields (k, rows, ids) with rows an (n, dim) float64 VIEW into the
+        library's pinned staging (valid until commit_end) and ids the global chain ids (-1 = idle work item); while the caller evaluates piece k
+        the DMA of the following pieces proceeds.  Hand the values in with commit_chunk(k, ll) and finish with commit_end()."""
+        self._ck(self.lib.bpm_propose_begin(self._h, int(n_chunks)))
+        for k in range(int(n_chunks)):
+            rows, ids = _dp_type(), _ip_type()
+            n, ld = C.c_int32(0), C.c_int32(0)
+            self._ck(self.lib.bpm_propose_chunk(self._h, k, C.byref(rows), C.byref(ids), C.byref(n), C.byref(ld)))
+            if n.value == 0:
+                yield k, np.empty((0, self.dim)), np.empty(0, dtype=np.int32)
+                continue
+            a = np.ctypeslib.as_array(rows, shape=(n.value, ld.value))[:, :self.dim]
+            yield k, a, np.ctypeslib.as_array(ids, shape=(n.value,))
+
+    def propose_begin(self, n_chunks):
+        self._ck(self.lib.bpm_propose_begin(self._h, int(n_chunks)))
+
+    def propose_chunk(self, k):
+        """piece k of the open half generation (waits for its DMA only; callable from a worker thread) -> (rows view, ids view)"""
+        rows, ids = _dp_type(), _ip_type()
+        n, ld = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.bpm_propose_chunk(self._h, int(k), C.byref(rows), C.byref(ids), C.byref(n), C.byref(ld)))
+        if n.value == 0:
+            return np.empty((0, self.dim)), np.empty(0, dtype=np.int32)
+        return np.ctypeslib.as_array(rows, shape=(n.value, ld.value))[:, :self.dim], np.ctypeslib.as_array(ids, shape=(n.value,))
+
+    def commit_chunk(self, k, ll):
+        ll = np.ascontiguousarray(ll, dtype=np.float64)
+        self._ck(self.lib.bpm_commit_chunk(self._h, int(k), _dptr(ll) if ll.size else None))
+
+    def commit_end(self):
+        self._ck(self.lib.bpm_commit_end(self._h))
+
+    # ---- ... and with the likelihood evaluated on the device by the caller's framework (bpm_propose_device / bpm_commit_device) --------------------
+    def propose_device(self):
+        """-> DeviceRows: the half generation's proposals where they lie in device memory (`__cuda_array_interface__`: torch.as_tensor / cupy.asarray
+        take it without a copy), work-item order; .ids is the same for the global chain ids (-1 = idle work item)"""
+        rows, ids = C.c_void_p(), C.c_void_p()
+        n, ld = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.bpm_propose_device(self._h, C.byref(rows), C.byref(ids), C.byref(n), C.byref(ld)))
+        return DeviceRows(rows.value or 0, n.value, self.dim, ld.value, ids.value or 0)
+
+    def commit_device(self, ll):
+        """ll: n float64 values in device memory, in the order of the rows (anything with `__cuda_array_interface__` or data_ptr())"""
+        self._ck(self.lib.bpm_commit_device(self._h, C.c_void_p(_device_pointer(ll, self._pending_rows(), "ln_like values"))))
+
+    def _pending_rows(self):
+        return None
+
+    def state_device(self):
+        rows = C.c_void_p()
+        n, ld = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.bpm_state_device(self._h, C.byref(rows), C.byref(n), C.byref(ld)))
+        return DeviceRows(rows.value or 0, n.value, self.dim, ld.value, 0)
+
+    def set_loglike_device(self, ll):
+        self._ck(self.lib.bpm_set_loglike_device(self._h, C.c_void_p(_device_pointer(ll, self.n_local, "ln_like values"))))
 
     def reserve_history(self, rows):
         self._ck(self.lib.bpm_reserve_history(self._h, int(rows)))

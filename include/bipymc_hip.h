@@ -231,6 +231,27 @@ int bpm_set_launch_path(bpm_handle_t h, int32_t direct, int32_t fence);
  * (samplers.py:328-336), the append (chain.py:51-54) and, after the second phase, k_gen += 1. */
 int bpm_propose(bpm_handle_t h, double* out_prop, int32_t* out_ids, int32_t* n_out);
 int bpm_commit(bpm_handle_t h, const double* ll_prop);
+/* The same half generation with the read-back OVERLAPPED with the caller's evaluation (round 5).  bpm_propose_begin launches the proposal kernel and
+ * queues the device-to-host copies of the proposals in n_chunks pieces (1 ... 256) into pinned staging OF THE LIBRARY, then returns at once;
+ * bpm_propose_chunk(k) waits for piece k only and returns pointers INTO that staging -- *n_rows rows of *ld doubles (the first dim are the proposal;
+ * ld = dim rounded up to even) in work-item order and their global chain ids (-1: an idle work item of a rank of a world; its value is ignored) --
+ * valid until bpm_commit_end: while the caller evaluates ln_like_fn on piece k (samplers.py:36-43) the DMA of the following pieces proceeds.
+ * bpm_commit_chunk(k, ll) hands in the *n_rows values of piece k (any order of k; the library copies), bpm_commit_end does what bpm_commit does.
+ * bpm_propose_chunk -- and only it -- may be called from several host threads at once (a pool evaluating the pieces in parallel). */
+int bpm_propose_begin(bpm_handle_t h, int32_t n_chunks);
+int bpm_propose_chunk(bpm_handle_t h, int32_t k, const double** rows, const int32_t** ids, int32_t* n_rows, int32_t* ld);
+int bpm_commit_chunk(bpm_handle_t h, int32_t k, const double* ll);
+int bpm_commit_end(bpm_handle_t h);
+/* ... and with the likelihood evaluated ON THE DEVICE by the caller's own framework (a vectorised torch / cupy likelihood): nothing crosses PCIe.
+ * bpm_propose_device returns, complete, *rows_dev = DEVICE pointer to the half generation's *n_rows proposal rows of *ld doubles (work-item order)
+ * and *ids_dev = device pointer to their global chain ids (-1: idle work item); bpm_commit_device takes a DEVICE pointer to *n_rows float64 values
+ * in the same order (memory of this sampler's GPU; the library waits for the whole device first -- the values may come from any stream -- and
+ * copies them).  bpm_state_device / bpm_set_loglike_device are the device-resident forms of bpm_get_state (local chains only: n_local rows where
+ * they lie, read-only) + bpm_set_loglike, needed once per (re)initialisation. */
+int bpm_propose_device(bpm_handle_t h, const double** rows_dev, const int32_t** ids_dev, int32_t* n_rows, int32_t* ld);
+int bpm_commit_device(bpm_handle_t h, const double* ll_dev);
+int bpm_state_device(bpm_handle_t h, const double** rows_dev, int32_t* n_rows, int32_t* ld);
+int bpm_set_loglike_device(bpm_handle_t h, const double* ll_dev);
 
 /* history of this rank's chains: out[(g - g_lo) * n_local * dim + i * dim + j], g in [g_lo, g_hi) */
 int bpm_get_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);

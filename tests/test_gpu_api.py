@@ -172,6 +172,17 @@ def test_host_callback_equals_device_target():
     assert np.all(np.abs(ch) <= 1.0) and abs(ch.std() - 1 / np.sqrt(3)) < 0.05
 
 
+def test_callback_transports_agree():
+    """One likelihood, five ways to call it (samplers.py:36-43 calls ln_like_fn row by row): per row, vectorised in one piece, vectorised with the
+    read-back in overlapped pieces, the pieces evaluated by a pool of host threads, and as a torch function on the device (vectorized="device").
+    Body: tests/_torch_worker.py::transports, in a child process that imports torch first (one HIP runtime per process)."""
+    pytest.importorskip("torch")
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_torch_worker.py"), "transports"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"transports ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
 def test_nan_ratio_raises_like_numpy():
     """both ln_like values -inf -> alpha NaN -> the reference's np.random.choice raises ValueError (samplers.py:336)"""
     from bipymc_amd import DeMcMpi

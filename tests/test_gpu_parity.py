@@ -313,6 +313,81 @@ def test_demc_gauss_with_options():
         _check_generation(eng, ora, N, d, False, 2)
 
 
+@pytest.mark.parametrize("algo,d,N,n_chunks,kw", [
+    (R.ALGO_DREAM, 10, 24, 1, dict(del_pairs=3, burnin_gen=5, n_cr_gen=2)),
+    (R.ALGO_DREAM, 10, 24, 3, dict(del_pairs=3, burnin_gen=5, n_cr_gen=2)),
+    (R.ALGO_DREAM, 7, 50, 7, dict(del_pairs=2, burnin_gen=100, n_cr_gen=1)),           # odd d: padded rows in the staging
+    (R.ALGO_DREAM, 100, 64, 4, dict(del_pairs=3, burnin_gen=4, n_cr_gen=2)),
+    (R.ALGO_DREAM, 600, 12, 5, dict(del_pairs=3, burnin_gen=4, n_cr_gen=2)),          # the looped wide-row kernels
+    (R.ALGO_DEMC, 3, 33, 4, dict(p_snooker=0.3)),
+    (R.ALGO_DEMC, 2, 9, 9, dict(p_snooker=0.0)),                                       # more chunks than some halves have rows: empty pieces
+])
+def test_chunked_read_back_of_the_host_callback_path_against_oracle(algo, d, N, n_chunks, kw):
+    """Round 5: the half generation's proposals come back in pieces (bpm_propose_begin / bpm_propose_chunk: the DMA of piece
+    k + 1 under the caller's evaluation of piece k), the ln-likes go in piece by piece IN ANY ORDER (bpm_commit_chunk), bpm_commit_end finishes --
+    against OracleSampler(ll_fn=...) like the one-piece form above: every accept decision exact, states / history to 1e-11."""
+    params = _gauss_params(d, rho=0.4)
+
+    def py_ll(theta):
+        return float(R.ll_gauss_equicorr(theta, params))
+
+    eng = _engine(algo=algo, n_chains=N, dim=d, target_id=R.TARGET_HOST, target_params=None, seed=78, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("del_pairs", "burnin_gen", "n_cr_gen", "p_snooker")}
+    ora = R.OracleSampler(algo, N, d, R.TARGET_HOST, None, 78, ll_fn=py_ll, **okw)
+    X0 = np.random.RandomState(4).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    eng.set_state(X0)
+    eng.set_loglike(np.array([py_ll(x) for x in X0]))
+    ora.set_state(X0)
+    eng.begin_run()
+    seen_rows = 0
+    for g in range(9):
+        for ph in range(2):
+            pieces = [(k, rows.copy(), ids.copy()) for k, rows, ids in eng.propose_chunks(n_chunks)]
+            assert [p[0] for p in pieces] == list(range(n_chunks)) and all(p[1].shape == (len(p[2]), d) for p in pieces)
+            assert all(np.all(p[2] >= 0) for p in pieces)                 # one rank: every work item is active
+            seen_rows += sum(len(p[2]) for p in pieces)
+            for k, rows, ids in reversed(pieces):                        # (the values may be handed in in any order)
+                eng.commit_chunk(k, np.array([py_ll(r) for r in rows]))
+            eng.commit_end()
+        ora._generation(g, 0.5, True, 1e-12 if algo == R.ALGO_DREAM else 1e-15, 1e-2, None)
+        np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-11, atol=1e-13)
+    assert seen_rows == 9 * N
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+    if algo == R.ALGO_DREAM:
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-7 if d > 512 else 1e-9)
+    np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-11, atol=1e-13)
+    # misuse is an error, not a hang or a silent half generation
+    from bipymc_amd._lib import BpmError
+    it = eng.propose_chunks(2)
+    next(it)
+    with pytest.raises(BpmError, match="chunks were given"):
+        eng.commit_end()
+    with pytest.raises(BpmError, match="another entry point"):
+        eng.commit(np.zeros(N))
+
+
+@pytest.mark.parametrize("algo,d,N,kw", [
+    (R.ALGO_DREAM, 10, 24, dict(del_pairs=3, burnin_gen=5, n_cr_gen=2)),
+    (R.ALGO_DREAM, 101, 40, dict(del_pairs=3, burnin_gen=4, n_cr_gen=2)),              # odd d: a row stride of 102 doubles in device memory
+    (R.ALGO_DEMC, 4, 30, dict(p_snooker=0.2)),
+])
+def test_device_resident_likelihood_against_oracle(algo, d, N, kw):
+    """Round 5: the likelihood evaluated ON THE DEVICE by the caller's framework -- the proposals are handed over where they lie
+    (engine.DeviceRows: `__cuda_array_interface__`, wrapped by torch without a copy), the ln-likes come back as a device tensor
+    (bpm_propose_device / bpm_commit_device): no PCIe.  Against OracleSampler(ll_fn=...) with the same formula in NumPy: accept counts equal, state
+    and history to 1e-10 (torch's and NumPy's row sums differ in the last bits).  In a child process that imports torch FIRST: the torch wheel carries
+    a HIP runtime of its own, and a process can initialise only one (the library then binds to the one already loaded) -- the order a user's script has."""
+    pytest.importorskip("torch")
+    import json as _json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_torch_worker.py"), "device_parity", str(algo), str(d), str(N), _json.dumps(kw)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"device_parity ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
 # ------------------------------------------------------------------ history, results
 def test_history_rows_and_super_chain_order():
     N, d, G = 12, 6, 9
