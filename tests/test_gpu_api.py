@@ -132,6 +132,7 @@ def test_reference_families_hold_the_device(scenario):
         _, _, full = s.param_est(n_burn=0)
         T = full.shape[0] // N
         got = A.summarize(doc, full.reshape(T, N, d), s.acceptance_fraction, s.p_cr if doc["algo"] == "dream" else None)
+        s._engine.close()
         A.check(scenario, got, "device, seed %d" % seed)
 
 
@@ -176,7 +177,9 @@ def test_callback_transports_agree():
     """One likelihood, five ways to call it (samplers.py:36-43 calls ln_like_fn row by row): per row, vectorised in one piece, vectorised with the
     read-back in overlapped pieces, the pieces evaluated by a pool of host threads, and as a torch function on the device (vectorized="device").
     Body: tests/_torch_worker.py::transports, in a child process that imports torch first (one HIP runtime per process)."""
-    pytest.importorskip("torch")
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:      # (NOT imported here: torch brings HIP / HSA / RCCL copies of its own, and importing it into a process
+        pytest.skip("PyTorch is not installed")       #  whose library is already loaded breaks RCCL's first contact for every later test)
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "_torch_worker.py"), "transports"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -568,45 +571,36 @@ def test_serial_api_demc_class():
 
 
 def test_posterior_moments_at_baseline_sizes():
-    """'Posterior moments within 1 % of reference / analytic values'  at the BASELINE sizes,
-    from the on-device moment reduction; starts are exact draws of the targets (stationary regime)."""
+    """'Posterior moments within 1 % of reference' (BASELINE.json north_star) at the BASELINE sizes, PER COORDINATE (the pooled form
+    hid a per-coordinate spread of 0.988 ... 1.016 over 1200 generations, and 3.5 % was what this test allowed): every coordinate's variance within 1 %
+    of the analytic value and every coordinate's mean within 0.01 sigma, with the batch-means standard error of the worst coordinate at most a third of
+    the tolerance -- over 40 000 post-burn-in generations of cfg2 (one second with per-generation population sums instead of a history), from exact
+    draws of the target AND from the reference's own start (theta_0 = 0, varepsilon = 1e-6; chain.py:25-27, tests/test_100dgauss.py:105-110) behind a
+    3000-generation transient; the same gate for cfg3 and for cfg5 (its per-GPU share and whole).  The gate is bench.py's (batch_moment_gate): what the
+    JSON line reports as posterior.gate is what is asserted here."""
+    import bench
+    for start in ("exact", "reference"):
+        g = bench.posterior_gate(0, start=start)
+        assert g["generations"] == bench.POSTERIOR_GATE_GENS and g["batches"] == bench.GATE_BATCHES
+        assert g["gate_pass"], g
+        assert 0.99 <= g["var_ratio_min"] <= g["var_ratio_max"] <= 1.01 and g["max_abs_mean_over_sigma"] <= 0.01, g
+        assert g["mcse_var_ratio_max"] <= 0.01 / 3 and g["mcse_mean_over_sigma_max"] <= 0.01 / 3, g
+        assert 0.15 < g["acceptance_fraction"] < 0.20                    # (cfg2's DREAM: 0.172-0.176)
+    others = bench.posterior_gates_other_configs(0)
+    assert len(others) == 3
+    for g in others:
+        assert "error" not in g and g["gate_pass"], g
+        assert 0.99 <= g["var_ratio_min"] <= g["var_ratio_max"] <= 1.01 and g["max_abs_mean_over_sigma"] <= 0.01, g
+
+
+def test_outlier_reset_keeps_the_modes_at_cfg5_share():
+    """cfg5 (one GPU's share of the 8-D mixture, N = 32768) with CR adaptation and the outlier reset on: chains parked in the far tail are reset, everybody
+    ends in one of the two modes, the mode weights are preserved and the per-axis variance inside each mode is that of the 2-D reference target
+    (dblgauss_rv.py:11-32: sigma = 0.25)."""
     from bipymc_amd import _lib as L
     from bipymc_amd.engine import HipEngine
-    from bipymc_amd.utils import banana_rv, d100_gauss, mixture_nd
+    from bipymc_amd.utils import mixture_nd
     np.random.seed(5)
-
-    def moments(e, n_burn_rows):
-        cnt, s1, s2, sh = e.reduce_moments(n_burn_rows)
-        return sh + s1 / cnt, s2 / cnt - (s1 / cnt) ** 2
-
-    # cfg3: DE-MC, banana, N = 65536, snooker 0.1.  E = (0, 1.16125), Var = (1.3225, 1.25614) (SURVEY a13)
-    ban = banana_rv.Banana_2D()
-    tid, tp, d = ban._bpm_target_spec()
-    N = 65536
-    y1, y2 = ban.rvs(N)
-    e = HipEngine(algo=L.ALGO_DEMC, n_chains=N, dim=2, target_id=tid, target_params=tp, seed=1, p_snooker=0.1)
-    e.set_state(np.stack([y1, y2], axis=1))
-    e.begin_run(); e.step(400)
-    mean, var = moments(e, 100 * N)
-    assert abs(mean[0]) < 0.01 and abs(mean[1] - 1.16125) < 0.0117            # 1 % of the scale
-    assert abs(var[0] / 1.3225 - 1) < 0.01 and abs(var[1] / 1.25614 - 1) < 0.01
-    e.close()
-
-    # cfg2: DREAM, 100-D Gaussian, N = 8192: mean 0, var_i = i + 1
-    g = d100_gauss.Gauss_100D()
-    tid, tp, d = g._bpm_target_spec()
-    e = HipEngine(algo=L.ALGO_DREAM, n_chains=8192, dim=d, target_id=tid, target_params=tp, seed=2, burnin_gen=200, n_cr_gen=50)
-    e.set_state(g.rvs(8192))
-    e.begin_run(); e.step(1500)
-    mean, var = moments(e, 300 * 8192)
-    sig2 = np.arange(d) + 1.0
-    assert np.max(np.abs(mean) / np.sqrt(sig2)) < 0.03
-    assert abs(np.mean(var / sig2) - 1) < 0.01                                 # 1 % on the pooled variance
-    assert np.max(np.abs(var / sig2 - 1)) < 0.035                              # each coordinate: MC noise of the slow common mode
-    e.close()
-
-    # cfg5 (one GPU's share of the 8-D mixture, N = 32768) with CR adaptation and outlier reset on: per-axis
-    # moments inside each mode are those of the 2-D reference target: var 0.0625 around 0 and 2
     m = mixture_nd.BimodeGauss_ND(8)
     tid, tp, d = m._bpm_target_spec()
     N = 32768

@@ -378,7 +378,9 @@ def test_device_resident_likelihood_against_oracle(algo, d, N, kw):
     (bpm_propose_device / bpm_commit_device): no PCIe.  Against OracleSampler(ll_fn=...) with the same formula in NumPy: accept counts equal, state
     and history to 1e-10 (torch's and NumPy's row sums differ in the last bits).  In a child process that imports torch FIRST: the torch wheel carries
     a HIP runtime of its own, and a process can initialise only one (the library then binds to the one already loaded) -- the order a user's script has."""
-    pytest.importorskip("torch")
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:      # (NOT imported here: torch brings HIP / HSA / RCCL copies of its own, and importing it into a process
+        pytest.skip("PyTorch is not installed")       #  whose library is already loaded breaks RCCL's first contact for every later test)
     import json as _json
     import subprocess
     import sys
