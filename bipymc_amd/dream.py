@@ -4,7 +4,8 @@
 Adds to DeMcMpi the DREAM proposal (crossover subspace mask, `del_pairs` distinct pairs,
 uniform + normal jitter, gamma = 1 jumps every 5th generation) and the adaptation of the
 crossover probabilities `p_cr` during burn-in; all of it runs in the HIP update kernel
-(bipymc_amd/csrc/kernels.h) and the once-per-generation CR reduction (`cr_partial_kernel` + `cr_final_kernel`).
+(bipymc_amd/csrc/kernels.h) and the once-per-generation CR reduction (level 1 inside the burn-in flavours of the update kernel or
+`cr_level1_kernel`, `cr_mid_kernel` beyond 512 partial sums, `cr_final_kernel`).
 """
 from __future__ import division, print_function
 
