@@ -394,17 +394,17 @@ def measured_copy_bandwidth(torch, dev):
 OTHER_CONFIG_PREHEAT_S = 0.1      # untimed steady-state generations of a scratch sampler (no history) in front of every extra configuration
 
 
-def _counter_traffic(tag):
-    """HBM-side bytes per update launch of a configuration from the committed counter passes (profiles/r04_pmc_<tag>.txt: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate passes; FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes, see profiles/r04_row_gather_floor.txt for what
-    that means on random rows), or None: offline numbers like the headline's profiles/traffic_cfg2.json."""
-    import re
+def _counter_traffic(tag, lib):
+    """HBM-side bytes per update launch of a configuration from the committed counter passes (profiles/traffic_configs.json, written by tools/prof_cfgs.sh
+    from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; FETCH_SIZE x 2 on gfx950 as MI355X_MICROARCH.md prescribes) -- or None when
+    the counters were taken on ANOTHER build of the library than the one being timed (the file carries the build id)."""
     try:
-        t = open(os.path.join(ROOT, "profiles", "r04_pmc_%s.txt" % tag)).read()
-        f = float(re.search(r"FETCH_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
-        w = float(re.search(r"WRITE_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
-        return (2.0 * f + w) * 1024.0
-    except (OSError, AttributeError, ValueError):
+        from bipymc_amd import _lib as L
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs.json")))
+        if t.get("build_id") != L.build_id(lib):
+            return None
+        return t[tag]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
         return None
 
 
@@ -471,8 +471,8 @@ def other_configs(device, budget_s=6.0):
                         acceptance_fraction=st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"]),
                         packet_fence=ls["fence"],
                         roofline=dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                      traffic=(_counter_traffic("cfg3") if name.startswith("cfg3") else
-                                               (_counter_traffic("cfg5") if name.startswith("cfg5 whole") else None)),
+                                      traffic=(_counter_traffic("cfg3", e.lib) if name.startswith("cfg3") else
+                                               (_counter_traffic("cfg5", e.lib) if name.startswith("cfg5 whole") else None)),
                                       kernel=kernel, bytes_per_unit=bpu, units_per_launch=N / 2.0,
                                       avg_launch_us=(ev_ms * 1e3 / ev_n) if ev_n > 0 else None, launches_timed=ev_n,
                                       note="achieved = n_chains x bytes_per_unit / device-timed generation period (two update "

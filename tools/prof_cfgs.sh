@@ -23,4 +23,17 @@ done
 unset BPM_QUEUE_INFLIGHT
 cd $R
 cat $P/${TAG}_other_configs_plain.txt; for c in cfg3 cfg5 cfg5_burnin cfg5_local cfg2_burnin; do echo "== $c"; head -5 $P/${TAG}_kernel_stats_$c.csv | cut -c1-200; done; cat $P/${TAG}_pmc_cfg3.txt $P/${TAG}_pmc_cfg5.txt
+# HBM-side bytes per update launch of cfg3 / cfg5 for bench.py's configs[].roofline.traffic, WITH the build id of the library the counters were taken on
+python - <<PY
+import json, re, sys
+sys.path.insert(0, "$R")
+from bipymc_amd import _lib
+out = {"build_id": _lib.build_id(_lib.load()), "correction": "FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section)"}
+for c in ("cfg3", "cfg5"):
+    t = open("$P/${TAG}_pmc_%s.txt" % c).read()
+    f = float(re.search(r"FETCH_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
+    w = float(re.search(r"WRITE_SIZE per .*?steady\(last \d+ dispatches\)-mean=([0-9.]+)", t).group(1))
+    out[c] = {"hbm_bytes_per_launch": (2 * f + w) * 1024.0, "fetch_size_kb_uncorrected": f, "write_size_kb": w, "source": "profiles/${TAG}_pmc_%s.txt" % c}
+json.dump(out, open("$P/traffic_configs.json", "w"), indent=1)
+PY
 find $O -name "*.db" -size +20M -delete

@@ -13,7 +13,10 @@ for i in 1 2 3; do python bench.py $ARGS 2>/dev/null | tail -1 >> $O/bench_drive
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.jsonl
 cd /tmp; export TMPDIR=/tmp
 echo "kernel trace" >> $O/progress.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py $ARGS --no-cpu-baseline --no-other-configs --preheat 0.1 > $O/kt.log 2>&1
+# (the DEFAULT invocation's 1000 timed generations, and nothing else of the steady-state kernel in the process: no pre-heat, no posterior gates -- their
+# samplers keep no history and their launches of the same instantiation are ~0.2 us shorter; rounds 2-4 traced the driver's 20 generations behind a
+# 0.1 s pre-heat, i.e. mostly pre-heat launches)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-other-configs --no-moments --preheat 0 > $O/kt.log 2>&1
 # The counter passes run on the library's own queue like everything else, throttled to 64 dispatches between two drains
 # (BPM_QUEUE_INFLIGHT): rocprofv3's counter collection serialises every dispatch behind packets of its own and stops forwarding the
 # packets of a queue that has more than a few hundred dispatches outstanding (fine with 256, a drain timeout with 600 or without a
