@@ -87,6 +87,24 @@ def test_cfg5_share_on_the_shipped_path_equals_the_oracle():
               dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1), hist_rows=(2, 10))
 
 
+def test_cfg4_and_cfg5_total_populations_on_one_gpu_equal_the_oracle():
+    """BASELINE configs[3] and configs[4] name 65536 chains at d = 100 and 262144 chains at d = 8 (sharded over 8 GPUs there; the sharded runs are pinned
+    to the one-rank run bit for bit in tests/test_gpu_api.py and tests/test_gpu_push.py).  Here the ONE-rank run of those total populations meets the oracle
+    directly: the in-kernel draw path of one wavefront per chain (> 16384 chains: no plan records), the lean form of four lanes per chain
+    (>= 49152 chains), level 2 of the CR reduction (cr_mid_kernel) and the outlier check at full size."""
+    N, d = 65536, 100
+    params = R.gauss_equicorr_params(0.5, np.sqrt(np.arange(d) + 1.0))
+    rs = np.random.RandomState(12)
+    X0 = np.sqrt(np.arange(d) + 1.0) * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
+    _run_both(R.ALGO_DREAM, N, d, R.TARGET_GAUSS_EQUICORR, params, 42, X0, 6, dict(del_pairs=3, n_cr=3, burnin_gen=3, n_cr_gen=1), hist_rows=(2, 6))
+    N, d = 262144, 8
+    mp = R.mixture_pairs_params(0.25, 0.75, [0, 0], [2, 2], [0.25, 0.25], [0.25, 0.25], 0.8, -0.8)
+    rs = np.random.RandomState(13)
+    X0 = np.where(rs.uniform(size=(N, 1)) < 0.25, 0.0, 2.0) + 0.25 * rs.normal(size=(N, d))
+    X0[:5] = 30.0                                                         # a few chains in the far tail for the outlier check
+    _run_both(R.ALGO_DREAM, N, d, R.TARGET_MIXTURE_PAIRS, mp, 3, X0, 8, dict(del_pairs=3, n_cr=3, burnin_gen=6, n_cr_gen=1, outlier_every=4), hist_rows=(3, 8))
+
+
 @pytest.mark.parametrize("N,d,tgt", [(40000, 8, "mix"), (70001, 2, "gauss"), (8195, 100, "gauss"), (5000, 20, "gauss"), (4099, 300, "gauss")])
 def test_cr_statistics_summed_inside_the_update_kernels_equal_the_oracle(N, d, tgt):
     """Round 4: level 1 of the CR reduction (dream.py:119-140) is written by the burn-in flavours of the update kernel themselves -- a wavefront's 16 / 64
