@@ -1019,6 +1019,26 @@ def posterior_gates_other_configs(device):
     return out
 
 
+def reference_at_the_headline_configuration():
+    """What the GENUINE reference does at bench.py's own workload (tests/golden/e2e_anchor_cfg2_headline.json, recorded by oracle/gen_anchor_cfg2.py: DreamMpi,
+    100-D Gaussian, 8192 chains from exact draws, n_cr_gen = 50, burnin_gen = 200): the numbers that belong beside posterior.p_cr / acceptance_fraction."""
+    path = os.path.join(ROOT, "tests", "golden", "e2e_anchor_cfg2_headline.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    runs = doc["runs"]
+    return dict(config=doc["config"],
+                acceptance_with_uniform_p_cr_generations_1_to_50=[float(np.mean([t["window_acceptance"] for t in r["trajectory"] if t["generation"] <= 50])) for r in runs],
+                p_cr_after_burnin=[[float("%.3g" % v) for v in r["p_cr_final"]] for r in runs],
+                acceptance_after_burnin=[r["acceptance_after_burnin"] for r in runs],
+                var_ratio_pooled_after_burnin=[r["var_ratio_pooled_after_burnin"] for r in runs],
+                note="the reference's CR adaptation collapses to a ONE-HOT p_cr within a generation of its start at this configuration (the zero-variance clamp of "
+                     "dream.py:129 meets the per-update re-estimation of dream.py:134-140) and its acceptance is that of the surviving CR value; this build "
+                     "re-estimates p_cr once per generation from all chains and stays mixed (posterior.p_cr).  At the reference's own p_cr -- uniform or one-hot -- "
+                     "the device accepts the same fraction (tests/test_gpu_api.py::test_headline_configuration_at_the_references_own_p_cr)")
+
+
 def reference_scenario_on_the_device(device):
     """The reference's OWN d = 100 scenario (tests/test_100dgauss.py:100-110: DreamMpi n_chains = 100, n_cr_gen = 50, burnin_gen = 2000, run_mcmc(500000),
     n_burn = 200000; DeMcMpi n_chains = 200) through the drop-in classes on the device, beside the family the genuine reference produced under
@@ -1474,6 +1494,7 @@ def main(argv=None):
         if world == 1 and not use_dist and not args.no_moments and CHAINS_PER_GPU == 8192:
             # the per-coordinate gate (every variance within 1 %, every mean within 0.01 sigma, batch-means standard errors): cfg2 from exact draws
             # -- this defines posterior.gate_pass -- and from the reference's start; cfg3 and cfg5; the reference's own scenario beside its family
+            out["posterior"]["reference_at_this_configuration"] = reference_at_the_headline_configuration()
             for key, fn in (("gate", lambda: posterior_gate(local_rank, start="exact")),
                             ("gate_from_reference_start", lambda: posterior_gate(local_rank, start="reference")),
                             ("gates_other_configs", lambda: posterior_gates_other_configs(local_rank)),

@@ -136,6 +136,41 @@ def test_reference_families_hold_the_device(scenario):
         A.check(scenario, got, "device, seed %d" % seed)
 
 
+def test_headline_configuration_at_the_references_own_p_cr(golden_dir):
+    """The genuine reference AT THE HEADLINE SIZE (oracle/gen_anchor_cfg2.py -> tests/golden/e2e_anchor_cfg2_headline.json: DreamMpi, 100-D Gaussian, 8192
+    chains from exact draws of the target, n_cr_gen = 50, burnin_gen = 200; two seeds, ~45 minutes each): with p_cr uniform (generations 1-50) it accepts
+    0.165 of its updates; its CR adaptation then collapses to a one-hot p_cr within one generation (the zero-variance clamp of dream.py:129 meets the
+    per-update re-estimation of dream.py:134-140; see tests/test_oracle_golden.py::test_headline_configuration_at_fixed_p_cr...) and the acceptance becomes
+    that of the surviving CR value.  The device at the reference's own p_cr -- uniform, and the one-hot vector each reference run ended with, installed
+    through bpm_set_adapt_state -- must accept the same fraction at the same size (tolerance 0.006); what differs between the two is the adaptation's
+    outcome (this build: (0.25, 0.27, 0.48), a documented deviation), not the update."""
+    from bipymc_amd import _lib as L
+    from bipymc_amd.engine import HipEngine
+    from bipymc_amd.utils import d100_gauss
+    doc = json.load(open(os.path.join(golden_dir, "e2e_anchor_cfg2_headline.json")))
+    g = d100_gauss.Gauss_100D()
+    tid, tp, d = g._bpm_target_spec()
+    N = 8192
+
+    def acceptance(p_cr, seed, gens=50):
+        np.random.seed(seed)
+        e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=seed, burnin_gen=0, n_cr_gen=50)
+        e.set_state(g.rvs(N))
+        e.set_adapt_state(p_cr=p_cr, delta_m=np.zeros(3), n_cr_updates=np.zeros(3))
+        e.begin_run()
+        e.step(gens)
+        st = e.stats()
+        e.close()
+        return st["local_n_accepted"] / float(st["local_n_accepted"] + st["local_n_rejected"])
+    uniform_ref = np.mean([np.mean([s_["window_acceptance"] for s_ in r["trajectory"] if s_["generation"] <= 50]) for r in doc["runs"]])
+    assert abs(acceptance([1 / 3.0] * 3, 11) - uniform_ref) < 0.006, uniform_ref
+    for k, r in enumerate(doc["runs"]):
+        p = np.array(r["p_cr_final"])
+        assert np.max(p) > 1.0 - 1e-12 and np.sum(p > 1e-12) == 1          # the reference's own p_cr at this configuration: one-hot
+        onehot = (p > 0.5).astype(float)
+        assert abs(acceptance(onehot, 12 + k) - r["acceptance_after_burnin"]) < 0.006, (p, r["acceptance_after_burnin"])
+
+
 def test_host_callback_equals_device_target():
     """An arbitrary Python ln_like_fn (samplers.py:36-43) takes the propose/commit path; with the same
     target it must reproduce the fused device path (same draws, ln_like equal to rounding)."""
