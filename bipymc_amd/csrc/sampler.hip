@@ -431,6 +431,7 @@ struct bpm_sampler {
     int prop_mode = 0;                       // how the open half generation was proposed: 1 host staging (chunks), 2 device-resident
     int64_t prop_active = 0;                 // its active work items
     bool prop_whole = false;                 // it was proposed through bpm_propose (caller-owned buffers): bpm_commit finishes it
+    std::vector<uint8_t> prop_done;          // [prop_chunks] 1: the piece's ln-likes have been handed in
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
     int32_t* trace_i32 = nullptr;      // per-chain decision trace (bpm_set_trace: test variant only; always null in the product library)
@@ -897,6 +898,9 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (s->h_ids) (void)hipHostFree(s->h_ids);
     if (s->h_props) (void)hipHostFree(s->h_props);
     if (s->h_ll) (void)hipHostFree(s->h_ll);
+#ifdef BPM_EXPERIMENT_XCD
+    if (free_buffers) { if (s->xcd_args) (void)hipFree(s->xcd_args); if (s->xcd_ctl) (void)hipFree(s->xcd_ctl); }
+#endif
     for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
@@ -2860,6 +2864,7 @@ extern "C" int bpm_propose_begin(bpm_handle_t s, int32_t n_chunks) {
         HIPCK(hipEventRecord(s->chunk_ev[(size_t)k], s->stream));
     }
     s->prop_chunks = n_chunks; s->prop_mode = 1; s->prop_given = 0; s->prop_active = 0; s->prop_whole = false;
+    s->prop_done.assign((size_t)n_chunks, 0);
     s->proposed = true;
     return 0;
 }
@@ -2884,6 +2889,7 @@ extern "C" int bpm_commit_chunk(bpm_handle_t s, int32_t k, const double* ll) {
     CK(set_device(s));
     if (!s->proposed || s->prop_mode != 1) return fail("bpm_commit_chunk: call bpm_propose_begin first");
     if (k < 0 || k >= s->prop_chunks) return fail("bpm_commit_chunk: bad chunk");
+    if (s->prop_done[(size_t)k]) return fail("bpm_commit_chunk: the values of piece " + std::to_string(k) + " were handed in already");
     const PhaseArgs& a = s->cur_args[s->phase];
     const uint32_t w0 = chunk_lo(a.n_items, s->prop_chunks, k), w1 = chunk_lo(a.n_items, s->prop_chunks, k + 1);
     if (w1 > w0) {
@@ -2893,6 +2899,7 @@ extern "C" int bpm_commit_chunk(bpm_handle_t s, int32_t k, const double* ll) {
         for (uint32_t w = w0; w < w1; ++w) s->prop_active += s->h_ids[w] >= 0 ? 1 : 0;
         HIPCK(hipMemcpyAsync(s->aux_buf + s->n_local + w0, s->h_ll + w0, (size_t)(w1 - w0) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     }
+    s->prop_done[(size_t)k] = 1;
     s->prop_given += 1;
     return 0;
 }

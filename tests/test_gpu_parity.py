@@ -360,9 +360,12 @@ def test_chunked_read_back_of_the_host_callback_path_against_oracle(algo, d, N, 
     # misuse is an error, not a hang or a silent half generation
     from bipymc_amd._lib import BpmError
     it = eng.propose_chunks(2)
-    next(it)
+    k0, rows0, _ids0 = next(it)
     with pytest.raises(BpmError, match="chunks were given"):
         eng.commit_end()
+    eng.commit_chunk(k0, np.zeros(len(rows0)))
+    with pytest.raises(BpmError, match="handed in already"):
+        eng.commit_chunk(k0, np.zeros(len(rows0)))
     with pytest.raises(BpmError, match="another entry point"):
         eng.commit(np.zeros(N))
 

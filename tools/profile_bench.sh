@@ -33,7 +33,7 @@ unset BPM_QUEUE_INFLIGHT
 echo "summaries" >> $O/progress.txt
 cd $R
 K="phase_fused_kernel<1, 1, 64, 2, 3, 1>"
-python tools/rocpd_summary.py stats $(find $O/kt -name "*.db" | head -1) > $P/${TAG}_kernel_stats_bench_driver.csv
+python tools/rocpd_summary.py stats $(find $O/kt -name "*.db" | head -1) > $P/${TAG}_kernel_stats_bench_default.csv
 {
   echo "# rocprofv3 --pmc passes of: python bench.py $ARGS --no-cpu-baseline --no-moments --preheat 0   (kernel $K, the timed + untimed steady-state launches)"
   python tools/rocpd_summary.py pmc $(find $O/f -name "*.db" | head -1) FETCH_SIZE "$K" 40
@@ -59,4 +59,4 @@ json.dump({"hbm_bytes_per_launch": (2 * f + w) * 1024.0, "fetch_size_kb_uncorrec
           open("$P/traffic_cfg2.json", "w"), indent=1)
 PY
 find $O -name "*.db" -size +20M -delete
-cat $P/${TAG}_bench_lines_driver_invocation.jsonl | cut -c1-250; cut -c1-250 $P/${TAG}_bench_line_default.json; head -5 $P/${TAG}_kernel_stats_bench_driver.csv | cut -c1-200; cat $P/${TAG}_pmc_bench_driver.txt; cat $P/traffic_cfg2.json
+cat $P/${TAG}_bench_lines_driver_invocation.jsonl | cut -c1-250; cut -c1-250 $P/${TAG}_bench_line_default.json; head -5 $P/${TAG}_kernel_stats_bench_default.csv | cut -c1-200; cat $P/${TAG}_pmc_bench_driver.txt; cat $P/traffic_cfg2.json
