@@ -233,6 +233,12 @@ struct PhaseArgs {
     uint32_t algo;
     uint32_t P, n_cr;
     double* cr_part1;      // != nullptr: this launch sums its updates' CR statistics itself, chunk by chunk of cr_g1 positions (HOT 3 / 4 only)
+    // consumer-side fold (round 5; one wavefront per chain, HOT 3 / 4): != nullptr -- the PREVIOUS generation's level-1 partial sums have not been folded
+    // into the totals yet: wavefront 0 of every workgroup of this launch folds them itself (cr_fold: cr_final_kernel's own code, same bits), the workgroup
+    // takes p_cr from that, workgroup 0 stores the new totals into cr_fold_out (another block than cr_fold_tot: the other workgroups still read that one)
+    const double* cr_fold_part;
+    const double* cr_fold_tot;
+    double* cr_fold_out;
     uint32_t cr_chunk0, cr_n1;   // first chunk of this half generation, chunks per generation (the stride of the m-major partial arrays)
     uint32_t adapt_on;     // dream.py:92  burnin_gen > k
     uint32_t cr_gate;      // dream.py:123 history length > n_cr_gen
@@ -323,12 +329,47 @@ __device__ __forceinline__ int gsum_i(int v) {
 constexpr uint32_t CR_FINAL_MAX = 512;        // partial sums cr_final_kernel folds by itself (8 per lane)
 __host__ __device__ inline uint32_t cr_chunks_of(uint32_t n_half, uint32_t g1) { return (n_half + g1 - 1u) / g1; }
 struct CrTotals { double p[MAX_CR], d[MAX_CR], n[MAX_CR]; };
+// the end of a fold: T = old totals with this generation's sums already added where some update contributed (any) -> p_cr (dream.py:132-140)
+__device__ __forceinline__ void cr_finalize(bool any, uint32_t n_cr, CrTotals& T) {
+    if (!any) return;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && T.n[m] != 0.0) ? 1u : 0u;
+    if (nz == n_cr) {
+#pragma unroll
+        for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.d[m] / T.n[m];     // dream.py:134-137
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) sum += T.p[m];
+#pragma unroll
+    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.p[m] / sum;            // dream.py:140
+}
+// ONE array of partial sums (the delta or the count sums of one CR value) the way cr_fold adds it: lane l holds partials l, l + 64, ... (plain loads:
+// see PLAIN above), adds them in order, the fixed DPP tree over the lanes.  A workgroup that folds with a wavefront per array (phase_fused_kernel) gets
+// cr_fold's bits.
+template <int ROUNDS>
+__device__ __forceinline__ double cr_array_sum(const double* arr, uint32_t nb) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    double v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t b = (uint32_t)r * WAVE + lane;
+        v[r] = b < nb ? arr[b] : 0.0;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) s += v[r];
+    return gsum<WAVE>(s);
+}
 // totals T = (p_cr | delta_m | n_cr_updates) + one generation's partial sums part[m * stride + b], b < nb <= 64 ROUNDS (delta) and
 // part[(MAX_CR + m) * stride + b] (counts), by ONE wavefront: lane l holds partials l, l + 64, ... -- ALL loads of the kernel issued before the first
 // add (a loop with a round trip per 64 partials cost 5 us at cfg2; a workgroup of 16 wavefronts with an LDS hand-over 4.7) -- adds them in order, the
 // lanes' sums meet in the fixed DPP tree.  (A partial beyond nb reads as +0.0: x + 0.0 == x, the result is a function of nb alone.)  Nothing changes
 // when no update contributed; p_cr is re-estimated once every CR value has been used, then normalised.  All 64 lanes take part.
-template <int ROUNDS>
+// PLAIN: ordinary loads of the partial sums -- for a caller whose packet acquired (an update kernel: its L2 starts clean, the sums were stored through by
+// an EARLIER launch) and whose 256 workgroups read the same 24 KB: the agent-scope form misses the L2 every time
+template <int ROUNDS, bool PLAIN = false>
 __device__ __forceinline__ void cr_fold(const double* tot, const double* part, uint32_t nb, uint32_t stride, uint32_t n_cr, CrTotals& T) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
 #pragma unroll
@@ -345,8 +386,13 @@ __device__ __forceinline__ void cr_fold(const double* tot, const double* part, u
                     const uint32_t b = (uint32_t)r * WAVE + lane;
                     vd[mm][r] = 0.0; vn[mm][r] = 0.0;
                     if (m0 + mm < (int)n_cr && b < nb) {     // (agent-scope loads: written by kernels whose packets may carry no release fence)
-                        vd[mm][r] = __hip_atomic_load(&part[(uint64_t)(m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vn[mm][r] = __hip_atomic_load(&part[(uint64_t)(MAX_CR + m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (PLAIN) {
+                            vd[mm][r] = part[(uint64_t)(m0 + mm) * stride + b];
+                            vn[mm][r] = part[(uint64_t)(MAX_CR + m0 + mm) * stride + b];
+                        } else {
+                            vd[mm][r] = __hip_atomic_load(&part[(uint64_t)(m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            vn[mm][r] = __hip_atomic_load(&part[(uint64_t)(MAX_CR + m0 + mm) * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
@@ -362,19 +408,7 @@ __device__ __forceinline__ void cr_fold(const double* tot, const double* part, u
             }
         }
     }
-    if (!any) return;
-    uint32_t nz = 0;
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) nz += (m < (int)n_cr && T.n[m] != 0.0) ? 1u : 0u;
-    if (nz == n_cr) {
-#pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.d[m] / T.n[m];     // dream.py:134-137
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) sum += T.p[m];
-#pragma unroll
-    for (int m = 0; m < MAX_CR; ++m) if (m < (int)n_cr) T.p[m] = T.p[m] / sum;            // dream.py:140
+    cr_finalize(any, n_cr, T);
 }
 __device__ __forceinline__ void cr_write_totals(const CrTotals& T, uint32_t n_cr, double* out) {
 #pragma unroll
@@ -668,13 +702,15 @@ __device__ __forceinline__ uint32_t chain_to_pos(const PhaseArgs& a, uint32_t c)
 // Build the proposal of chain c (dream.py:43-93 / demc.py:161-182).
 // ALGO compile-time; NP = compile-time number of pairs (0: runtime a.P, DREAM only).
 struct NoEarly { template <class W> __device__ __forceinline__ void operator()(W&) const {} };
+// p_cr handed in by the caller (a workgroup that folded the CR totals itself, PhaseArgs::cr_fold_part) instead of read from a.cr_state -- by value: registers
+struct PcrGiven { bool on = false; double p[MAX_CR]; };
 // EARLY: work on the own row (wk.x) that the caller wants done while the partner rows are still on their way -- the re-evaluation of the
 // current state's ln_like (lean_scalars): behind the proposal it sat on the critical path of the latency-bound launches (cfg5's share:
 // 10.05 instead of 9.3 us per generation), here it runs in the shadow of the partner fetches.
 template <int ALGO, int LPC, int DPL, int NP, int LOAD_LL = 1 /* 1 always, 0 never, 2 unless a.lean */, class EARLY = NoEarly>
 __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bool active, int q, int cw,
                                               uint32_t* s_part, Work<DPL>& wk, const uint32_t* rec = nullptr,
-                                              unsigned long long* bpm_stamp = nullptr, EARLY early = EARLY()) {
+                                              unsigned long long* bpm_stamp = nullptr, EARLY early = EARLY(), const PcrGiven pcr_ovr = PcrGiven()) {
     constexpr bool DREAM = ALGO == ALGO_DREAM;
     // FAST: partner ids straight into registers, every lane for itself, when a lane IS a chain (LPC == 1: no other
     // lane to share the work with, so the LDS hand-over loop would only re-evaluate the same Philox block once per
@@ -706,7 +742,7 @@ __device__ __forceinline__ void make_proposal(const PhaseArgs& a, uint32_t c, bo
     double pcr[MAX_CR];                        // p_cr (uniform pointer: one scalar load of the whole block)
     if (DREAM) {
 #pragma unroll
-        for (int m = 0; m < MAX_CR; ++m) pcr[m] = a.cr_state[m];
+        for (int m = 0; m < MAX_CR; ++m) pcr[m] = pcr_ovr.on ? pcr_ovr.p[m] : a.cr_state[m];      // (pcr_ovr: the workgroup folded the totals itself, cr_fold_part)
     }
     // gamma table held across the wavefront's lanes: the lookup by d' is then a v_readlane, not a dependent load
     double gtab[DPL];
@@ -1314,6 +1350,7 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
         a_hot = a_in;
         a_hot.mode = 0u; trace_set(a_hot, nullptr, nullptr, nullptr); a_hot.pack = nullptr;
         a_hot.replay = 0u; a_hot.x_next = nullptr; a_hot.adapt_on = ADAPT ? 1u : 0u; a_hot.stamps = nullptr;
+        if (!ADAPT) a_hot.cr_fold_part = nullptr;
         if (!SHARD) { a_hot.accbits = nullptr; a_hot.lo = 0; a_hot.L.world = 1; a_hot.acc_by_item = 0u; a_hot.n_peers = 0u; a_hot.peer_tab = nullptr; }
         if (ALGO == ALGO_DREAM) a_hot.n_cr = 3;
         if (NOPLAN) { a_hot.plan = nullptr; a_hot.rec_tab = nullptr; }
@@ -1377,6 +1414,45 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     if (LPC == WAVE && !active) {                // whole wavefront idle
         if (CRP) run = false; else return;
     }
+    // ---- consumer-side fold of the PREVIOUS generation's CR statistics (PhaseArgs::cr_fold_part), cr_final_kernel's arithmetic spread over the
+    // workgroup: wavefront k < 2 n_cr sums ONE array of partial sums (delta sums of CR value k, or the counts of CR value k - n_cr) exactly as cr_fold does
+    // -- 8 loads per lane, in flight behind the wavefront's record load -- and leaves the total in LDS; behind the barrier every wavefront finishes the
+    // fold for itself (a few additions and divisions on uniform values).  Same sums in the same order as cr_final_kernel: same bits (tested against the
+    // crnofold path).  One wavefront folding everything (48 loads per lane, six DPP trees) cost the launch 2.0 us, this form 1.3 us -- against the 4.5 us dispatch of
+    // cr_final_kernel it replaces: cfg2's burn-in generation 20.9 -> 18.5 us (profiles/r05_consumer_side_fold.txt).
+    // (The barrier HERE, ahead of every wavefront's loads: with it where the CR value is drawn -- behind the row requests, so that only the folding
+    // wavefronts would feel the fold -- the compiler serialised the partner-row loads of EVERY launch of the flavour, 23 instead of 8.3 us per launch.)
+    PcrGiven pcr_fold;
+    if constexpr (CRP && LPC == WAVE) {
+        static_assert(2 * MAX_CR <= 1024 / WAVE, "a wavefront per array of partial sums");
+        pcr_fold.on = a.cr_fold_part != nullptr;         // uniform over the launch
+        if (pcr_fold.on) {
+            __shared__ double s_tot[2 * MAX_CR];
+            const uint32_t n_cr = a.n_cr;
+            if ((uint32_t)cw < 2u * n_cr) {              // uniform per wavefront
+                const uint32_t arr = (uint32_t)cw < n_cr ? (uint32_t)cw : (uint32_t)MAX_CR + ((uint32_t)cw - n_cr);
+                const double tsum = cr_array_sum<CR_FINAL_MAX / WAVE>(a.cr_fold_part + (uint64_t)arr * a.cr_n1, a.cr_n1);
+                if (q == 0) s_tot[arr] = tsum;
+            }
+            __syncthreads();
+            CrTotals T;
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) { T.p[m] = a.cr_fold_tot[m]; T.d[m] = a.cr_fold_tot[MAX_CR + m]; T.n[m] = a.cr_fold_tot[2 * MAX_CR + m]; }
+            bool any = false;
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m) {
+                if (m < (int)n_cr) {
+                    const double td = s_tot[m], tn = s_tot[MAX_CR + m];
+                    if (tn > 0.0) { any = true; T.n[m] += tn; T.d[m] += td; }
+                }
+            }
+            cr_finalize(any, n_cr, T);
+            if (blockIdx.x == 0 && cw == 0 && q == 0) cr_write_totals(T, n_cr, a.cr_fold_out);
+#pragma unroll
+            for (int m = 0; m < MAX_CR; ++m)
+                pcr_fold.p[m] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(T.p[m])), __builtin_amdgcn_readfirstlane(__double2loint(T.p[m])));
+        }
+    }
   if (run) {
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);   // wavefront-uniform: header draws and Feistel walks go to the scalar unit
     const typename Target<TARGET, LPC, DPL>::Consts tc = Target<TARGET, LPC, DPL>::load(q, a.L.dim, a.tparams);
@@ -1397,6 +1473,8 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
         const bool lean_early = LEAN_CT || a.lean != 0u;
         auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
         make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : 2)>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, early);
+    } else if constexpr (CRP && LPC == WAVE) {
+        make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, NoEarly(), pcr_fold);
     } else {      // (one wavefront per chain: exactly the call of rounds 1-3)
         make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, stamp_arg);
     }

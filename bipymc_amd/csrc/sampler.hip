@@ -152,6 +152,9 @@ typedef void (*EvalLaunch)(const double*, uint32_t, uint32_t, uint32_t, const do
 // update launches of the generation being run that took a flavour which writes level 1 of the CR reduction ITSELF (kernels.h: CRP): what
 // finish_generation holds against the host's prediction (gen_cr_inkernel) before it lets cr_final_kernel fold the partial sums
 static thread_local int g_crp_launched = 0;
+// ... and those that were handed a pending fold of the previous generation's sums AND took a flavour that folds (PhaseArgs::cr_fold_part; bpm_sampler::cr_pending)
+static thread_local int g_crfold_launched = 0;
+static thread_local bool g_call_last_gen = false;      // run_generations: the generation being run is the last one of the bpm_step call (its fold is dispatched)
 static inline uint32_t grid_for(uint32_t n_items, int lpc) {
     const uint32_t cpw = (uint32_t)(block_for(lpc) / lpc);
     return (n_items + cpw - 1) / cpw;
@@ -223,6 +226,7 @@ template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
     static hipFunction_t fn = nullptr;
     if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL)) ++g_crp_launched;
+    if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL) && LPC == WAVE && a.cr_fold_part != nullptr) ++g_crfold_launched;
     constexpr unsigned blk = (unsigned)block_for_hot(LPC, HOT, DPL), cpw = blk / (unsigned)LPC;      // (burn-in flavours of one wavefront per chain: 16 chains per workgroup)
     launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, (a.n_items + cpw - 1u) / cpw, blk, s);
 }
@@ -412,9 +416,20 @@ struct bpm_sampler {
     double* w_m2 = nullptr;
     int64_t w_rows = 0;        // history rows folded into the Welford moments
     double* tparams = nullptr;
-    double* cr_state = nullptr;
+    double* cr_state = nullptr;       // the CURRENT totals block p_cr | delta_m | n_cr_updates: one of the two halves of cr_state_base (cr_state_alt the other)
+    double* cr_state_alt = nullptr;
+    double* cr_state_base = nullptr;
     // CR reduction (kernels.h): level-1 partial sums [2 MAX_CR][cr_n1] of a generation (chunks of cr_g1 positions), two buffers for the cr_mid_kernel passes
-    double* cr_p1 = nullptr;
+    double* cr_p1 = nullptr;          // two generations' worth: generation t writes half t & 1 (cr_p1_cur) -- the update kernel that folds generation t's sums
+    double* cr_p1_cur = nullptr;      // (consumer-side fold, below) writes its own level 1 in the same launch
+    // Consumer-side fold (round 5): with one wavefront per chain and at most CR_FINAL_MAX level-1 sums a generation's fold is NOT dispatched (cr_final_kernel:
+    // one wavefront at the floor of a dependent launch, 4.5 us of cfg2's 20.6 us burn-in generation): it stays pending, and wavefront 0 of every workgroup of
+    // the NEXT generation's first update launch folds the sums itself (PhaseArgs::cr_fold_part: the same device function, the same bits), workgroup 0 stores
+    // the new totals into the other totals block, which the second launch and everything later read.  What cannot consume a pending fold -- the last generation
+    // of a bpm_step call, the first steady-state generation, a launch that takes another flavour -- gets cr_final_kernel as before (cr_flush_pending).
+    bool cr_pending = false;
+    const double* cr_pend_src = nullptr;
+    bool gen_fold_planned = false;    // this generation's first update launch was given a pending fold: finish_generation checks that it took a flavour that folds
     double* cr_p2[2] = {nullptr, nullptr};
     uint32_t cr_g1 = 16, cr_n1 = 0;
     bool gen_cr_inkernel = false;     // this generation's update kernels write level 1 themselves (both launches are burn-in flavours: HOT 3 / 4)
@@ -889,7 +904,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     }
     if (s->ctrl_fine && s->ctrl && free_buffers) (void)hipFree(s->ctrl);
     if (s->arena) { s->G = nullptr; s->om = nullptr; }       // (both live inside the arena)
-    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->okeys, s->olist, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->tparams, s->cr_state, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
+    void* ptrs[] = {s->tb[0].chunk_count, s->tb[1].chunk_count, s->hist_tmp, s->gen_sums, s->gs_shift, s->gs_part, s->arena, s->tab_peerG, s->tab_all, s->om, s->sel, s->sel_state, s->okeys, s->olist, s->G, s->ll, s->hist, s->llhist, s->w_mean, s->tparams, s->cr_state_base, s->cr_p1, s->cr_p2[0], s->cr_p2[1], s->counters, s->acc_count,
                     s->prop_buf, s->aux_buf, s->ids_buf, s->tb[0].perm, s->tb[0].inv, s->tb[0].plan, s->tb[0].sidx, s->tb[0].plan_count,
                     s->tb[1].perm, s->tb[1].inv, s->tb[1].plan, s->tb[1].sidx, s->tb[1].plan_count, s->gamma_tab, s->x_next, s->accbits_all, s->PK, s->xstat, s->ckpt_G, s->ckpt_ll, s->ckpt_acc, s->ckpt_counters, s->trace_i32, s->trace_f64, s->trace_mask, s->scratch};
     if (free_buffers)
@@ -1082,14 +1097,16 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     CKD(dev_alloc(&s->tparams, (size_t)np + 2));       // (+2: the wide-row kernels read the Gaussian's 1/sigma as pairs)
     HIPCKD(hipMemsetAsync(s->tparams, 0, ((size_t)np + 2) * sizeof(double), s->stream));
     if (np > 0) HIPCKD(hipMemcpyAsync(s->tparams, s->tparams_h.data(), (size_t)np * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    CKD(dev_alloc_state(&s->cr_state, 3 * MAX_CR, s->coherent));
+    CKD(dev_alloc_state(&s->cr_state_base, 6 * MAX_CR, s->coherent));
+    s->cr_state = s->cr_state_base; s->cr_state_alt = s->cr_state_base + 3 * MAX_CR;
     if (cfg->algo == BPM_ALGO_DREAM) {       // the partial sums of the CR reduction (kernels.h)
         const uint32_t n_first = (s->N + 1u) / 2u;
         s->cr_g1 = (uint32_t)cr_g1(s->shape.lpc);
         s->cr_n1 = cr_chunks_of(n_first, s->cr_g1) + cr_chunks_of(s->N - n_first, s->cr_g1);
         const size_t n2 = ((size_t)s->cr_n1 + WAVE - 1) / WAVE;
-        CKD(dev_alloc_state(&s->cr_p1, (size_t)2 * MAX_CR * s->cr_n1, s->coherent));
-        HIPCKD(hipMemsetAsync(s->cr_p1, 0, (size_t)2 * MAX_CR * s->cr_n1 * sizeof(double), s->stream));
+        CKD(dev_alloc_state(&s->cr_p1, (size_t)4 * MAX_CR * s->cr_n1, s->coherent));
+        HIPCKD(hipMemsetAsync(s->cr_p1, 0, (size_t)4 * MAX_CR * s->cr_n1 * sizeof(double), s->stream));
+        s->cr_p1_cur = s->cr_p1;
         if (s->cr_n1 > CR_FINAL_MAX)
             for (auto& b : s->cr_p2) { CKD(dev_alloc_state(&b, (size_t)2 * MAX_CR * n2, s->coherent)); HIPCKD(hipMemsetAsync(b, 0, (size_t)2 * MAX_CR * n2 * sizeof(double), s->stream)); }
     }
@@ -1097,6 +1114,7 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
         double init[3 * MAX_CR] = {0};
         for (int m = 0; m < s->cfg.n_cr; ++m) init[m] = 1.0 / s->cfg.n_cr;   // dream.py:114
         HIPCKD(hipMemcpyAsync(s->cr_state, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
+        HIPCKD(hipMemcpyAsync(s->cr_state_alt, init, sizeof(init), hipMemcpyHostToDevice, s->stream));
         HIPCKD(hipStreamSynchronize(s->stream));
     }
     // position-ordered history append: one wavefront per chain writes whole 128-byte lines whatever the row's place, nothing to gain there
@@ -1445,6 +1463,32 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
 
 // Everything of one generation that is decided on the host: flip, shuffle key, group ranges
 // (demc.py:81-86,95-100), gating flags (dream.py:92,123), history row.
+// totals (cr_state) + `cnt` partial sums of one generation -> cr_state: cr_final_kernel on the queue the generation loop runs on
+static int launch_cr_final(bpm_sampler* s, const double* src, uint32_t cnt) {
+    const uint32_t n_cr = (uint32_t)s->cfg.n_cr;
+    const int fence = s->dq_fence | bpm::DirectQueue::ACQUIRE;
+    // (ROUNDS = partials per lane, the next power of two: a partial beyond cnt reads as +0.0, the sums do not depend on the choice)
+    typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
+    const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
+    const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
+    if (g_dq) {
+        struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
+        const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
+        if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
+        g_dq_need_acquire = false;
+    } else {
+        hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+// the fold nobody consumed (bpm_sampler::cr_pending)
+static int cr_flush_pending(bpm_sampler* s) {
+    if (!s->cr_pending) return 0;
+    s->cr_pending = false;
+    return launch_cr_final(s, s->cr_pend_src, s->cr_n1);
+}
+
 static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     const bool dream = s->cfg.algo == BPM_ALGO_DREAM;
     const uint64_t t = (uint64_t)s->t_abs;
@@ -1574,6 +1618,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.pack_stride = s->xstride();
         }
         a.cr_part1 = nullptr; a.cr_chunk0 = 0u; a.cr_n1 = s->cr_n1;
+        a.cr_fold_part = nullptr; a.cr_fold_tot = nullptr; a.cr_fold_out = nullptr;
         if (sync) {      // samplers.py:261-308: one launch, every local chain against all other chains, updates banked
             a.algo = (uint32_t)BPM_ALGO_DEMC;
             a.mode = 2u;
@@ -1587,6 +1632,9 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     // (HOT 3 / 4: single GPU, work item = position, no trace ...: the predicate launch_fused applies), else computed from the slots in finish_generation
     s->gen_cr_inkernel = false;
     g_crp_launched = 0;
+    g_crfold_launched = 0;
+    s->gen_fold_planned = false;
+    if (s->cr_p1) s->cr_p1_cur = s->cr_p1 + (size_t)(s->t_abs & 1) * 2 * MAX_CR * s->cr_n1;
 #ifdef BPM_PRELOAD      // (the specialised flavours exist only in the preload build: without it every launch ends in the general kernel, which writes the slots)
     if (s->gen_cr_reduce && dream && s->cfg.target_id != BPM_TARGET_HOST_CALLBACK && s->shape.idx != SHAPE_WIDE && crp_shape(s->shape.lpc, s->shape.dpl) &&
         !test_path("nohot") && !test_path("crslots")) {
@@ -1599,13 +1647,27 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             const uint32_t n_first = (s->N + 1u) / 2u;
             for (int ph = 0; ph < 2; ++ph) {
                 PhaseArgs& a = s->cur_args[ph];
-                a.cr_part1 = s->cr_p1;
+                a.cr_part1 = s->cr_p1_cur;
                 a.cr_chunk0 = a.upd_off == 0u ? 0u : cr_chunks_of(n_first, s->cr_g1);
             }
             s->gen_cr_inkernel = true;
         }
     }
 #endif
+    // a pending fold of the previous generation's CR statistics (bpm_sampler::cr_pending): consumed by this generation's first update launch when that one
+    // takes a flavour that can (one wavefront per chain, in-kernel level 1), else dispatched now, ahead of the update launches
+    if (s->cr_pending) {
+        PhaseArgs& a0 = s->cur_args[0];
+        if (s->gen_cr_inkernel && s->shape.lpc == WAVE && a0.n_items > 0 && a0.cr_part1 != nullptr) {
+            a0.cr_fold_part = s->cr_pend_src; a0.cr_fold_tot = s->cr_state; a0.cr_fold_out = s->cr_state_alt;
+            std::swap(s->cr_state, s->cr_state_alt);
+            s->cur_args[1].cr_state = s->cr_state;      // (the second launch reads what workgroup 0 of the first one stored; the first takes p_cr from its own fold)
+            s->cr_pending = false;
+            s->gen_fold_planned = true;
+        } else {
+            CK(cr_flush_pending(s));
+        }
+    }
     return 0;
 }
 
@@ -1622,6 +1684,9 @@ static int finish_generation(bpm_sampler* s) {
         // flavour that does not write level 1 writes the chains' slots (kernels.h: finish_update<..., CRP_W>), so "none did" falls back to
         // cr_level1_kernel over the slots; a mix of the two would fold stale partial sums into p_cr -- an error, never a silent result.
         bool level1_from_slots = !s->gen_cr_inkernel;
+        if (s->gen_fold_planned && g_crfold_launched != 1)
+            return fail("CR reduction: the first update launch of generation " + std::to_string((long long)s->t_abs) + " was handed the previous generation's fold and took a flavour that "
+                        "does not fold (launch_fused's flavour choice and prepare_generation's prediction disagree)");
         if (s->gen_cr_inkernel) {
             const int want = (s->cur_args[0].n_items > 0 ? 1 : 0) + (s->cur_args[1].n_items > 0 ? 1 : 0);
             if (g_crp_launched == 0 && want > 0) level1_from_slots = true;
@@ -1634,17 +1699,17 @@ static int finish_generation(bpm_sampler* s) {
             typedef void (*L1K)(Layout, PermKey, const uint32_t*, uint32_t, uint32_t, uint32_t, double*);
             const L1K l1 = s->cr_g1 == 4u ? cr_level1_kernel<4> : (s->cr_g1 == 16u ? cr_level1_kernel<16> : cr_level1_kernel<64>);
             if (g_dq) {
-                struct { Layout L; PermKey pk; const uint32_t* perm; uint32_t N, n_cr, n1, _pad; double* part1; } ka{s->L, a0.pk, a0.perm_tab, s->N, n_cr, s->cr_n1, 0u, s->cr_p1};
+                struct { Layout L; PermKey pk; const uint32_t* perm; uint32_t N, n_cr, n1, _pad; double* part1; } ka{s->L, a0.pk, a0.perm_tab, s->N, n_cr, s->cr_n1, 0u, s->cr_p1_cur};
                 const bpm::DqKernel* k = g_dq->kernel(reinterpret_cast<const void*>(l1));
                 if (!k || g_dq->launch(*k, (uint32_t)(((uint64_t)s->cr_n1 * s->cr_g1 + CR_L1_THREADS - 1) / CR_L1_THREADS), 1, CR_L1_THREADS, &ka, sizeof(ka), fence) != 0)
                     return fail("direct AQL queue: cr_level1_kernel: " + g_dq->why());
             } else {
                 hipLaunchKernelGGL(l1, dim3((unsigned)(((uint64_t)s->cr_n1 * s->cr_g1 + CR_L1_THREADS - 1) / CR_L1_THREADS)), dim3(CR_L1_THREADS), 0, s->stream, s->L, a0.pk, a0.perm_tab, s->N,
-                                   n_cr, s->cr_n1, s->cr_p1);
+                                   n_cr, s->cr_n1, s->cr_p1_cur);
                 HIPCK(hipGetLastError());
             }
         }
-        const double* src = s->cr_p1;
+        const double* src = s->cr_p1_cur;
         uint32_t cnt = s->cr_n1;
         int flip = 0;
         while (cnt > CR_FINAL_MAX) {
@@ -1660,17 +1725,13 @@ static int finish_generation(bpm_sampler* s) {
             }
             src = dst; cnt = nn; flip ^= 1;
         }
-        // (ROUNDS = partials per lane, the next power of two: a partial beyond cnt reads as +0.0, the sums do not depend on the choice)
-        typedef void (*FinalK)(const double*, const double*, uint32_t, uint32_t, double*);
-        const uint32_t rounds = (cnt + WAVE - 1) / WAVE;
-        const FinalK kfn = rounds <= 1 ? cr_final_kernel<1> : (rounds <= 2 ? cr_final_kernel<2> : (rounds <= 4 ? cr_final_kernel<4> : cr_final_kernel<8>));
-        if (g_dq) {
-            struct { const double* tot; const double* part; uint32_t nb, n_cr; double* cr_state; } fa{s->cr_state, src, cnt, n_cr, s->cr_state};
-            const bpm::DqKernel* kf = g_dq->kernel(reinterpret_cast<const void*>(kfn));
-            if (!kf || g_dq->launch(*kf, 1, 1, WAVE, &fa, sizeof(fa), fence) != 0) return fail("direct AQL queue: cr_final_kernel: " + g_dq->why());
+        static const bool no_defer = test_path("crnofold");
+        if (!level1_from_slots && cnt <= CR_FINAL_MAX && src == s->cr_p1_cur && s->shape.lpc == WAVE && !g_call_last_gen && !no_defer) {
+            // consumer-side fold: no dispatch -- the next generation's first update launch folds (prepare_generation), or cr_flush_pending
+            s->cr_pending = true;
+            s->cr_pend_src = src;
         } else {
-            hipLaunchKernelGGL(kfn, dim3(1), dim3(WAVE), 0, s->stream, (const double*)s->cr_state, src, cnt, n_cr, s->cr_state);
-            HIPCK(hipGetLastError());
+            CK(launch_cr_final(s, src, cnt));
         }
         s->w_rows += 1;
     }
@@ -2163,6 +2224,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             if (push && !s0->push_agent_scope) g_dq_update_fence = bpm::DirectQueue::FENCED | bpm::DirectQueue::SYSTEM;
             g_wt_stores = !plain_stores && !s0->coherent && direct && !(g_dq_update_fence & bpm::DirectQueue::RELEASE);
             g_dq_call_last_gen = direct && done == n_gens - 1;
+            g_call_last_gen = done == n_gens - 1;
             if (push && !push_entered) {
                 // entry barrier of the call: a peer's first update kernel may push into THIS replica only after this rank has finished
                 // whatever its host did to the replica before the call (bpm_set_state, a warm start, ...) -- and vice versa
@@ -2171,7 +2233,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 push_entered = true;
             }
             const int rc_gen = group_generation(g, n_gens - done, push ? 3 : (replay ? 2 : 0), fn);
-            g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false;
+            g_wt_stores = false; g_dq_call_last_gen = false; g_dq_release_this = false; g_call_last_gen = false;
             g_group_direct = false;
             if (direct) {
                 g_dq = nullptr;

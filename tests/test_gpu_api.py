@@ -364,7 +364,8 @@ def test_alternative_kernel_paths_on_one_gpu():
     wt8 -- round 2's two 8-byte write-through stores per lane instead of one 16-byte store; histchain -- the history append by chain
     index instead of in shuffle order (what fewer than 64 lanes per chain use); crslots -- level 1 of the CR reduction computed from the slots by
     cr_level1_kernel (what a rank of a world and the general kernel use) instead of inside the update kernels; lean -- ln_like of the current state
-    re-evaluated from the own row and accepts counted per wavefront (what >= 49152 chains per GPU use) at any size;
+    re-evaluated from the own row and accepts counted per wavefront (what >= 49152 chains per GPU use) at any size; crnofold -- every generation's
+    CR fold dispatched as cr_final_kernel instead of left to the next generation's first update launch (the consumer-side fold of round 5);
     and the operational switches BPM_DIRECT_QUEUE=0 (HIP stream launches) and BPM_QUEUE_INFLIGHT (a drain every few dispatches)."""
     import subprocess
     import sys
@@ -378,6 +379,7 @@ out = []
 for spec, algo, N, kw in ((d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 96, dict(burnin_gen=6, n_cr_gen=2)),
                           (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 101, dict(burnin_gen=6, n_cr_gen=2, del_pairs=2)),
                           (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), L.ALGO_DREAM, 9001, dict(burnin_gen=9, n_cr_gen=2)),   # 564 level-1 chunks
+                          (d100_gauss.Gauss_100D()._bpm_target_spec(), L.ALGO_DREAM, 8192, dict(burnin_gen=11, n_cr_gen=2)),   # 512 level-1 chunks: the most the fold takes
                           (banana_rv.Banana_2D()._bpm_target_spec(), L.ALGO_DEMC, 77, dict(p_snooker=0.2))):
     tid, tp, d = spec
     e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=5, **kw)
@@ -391,7 +393,7 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
     for paths, extra in (("", {}), ("nohot", {}), ("mode1", {}), ("noplan", {}), ("noperm", {}), ("mode1,noplan", {}), ("planall", {}),
                          ("planall,mode1", {}), ("", {"BPM_DIRECT_QUEUE": "0"}), ("nohot", {"BPM_DIRECT_QUEUE": "0"}),
                          ("", {"BPM_QUEUE_INFLIGHT": "3"}), ("wt8", {}), ("histchain", {}), ("wt8,histchain,nohot", {}), ("crslots", {}), ("lean", {}),
-                         ("crslots,lean,mode1", {})):
+                         ("crslots,lean,mode1", {}), ("crnofold", {}), ("crnofold", {"BPM_DIRECT_QUEUE": "0"})):
         env = dict(os.environ)
         for k in ("BPM_TEST_PATHS", "BPM_DIRECT_QUEUE", "BPM_QUEUE_INFLIGHT"):
             env.pop(k, None)
