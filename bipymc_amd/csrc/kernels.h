@@ -233,12 +233,13 @@ struct PhaseArgs {
     uint32_t algo;
     uint32_t P, n_cr;
     double* cr_part1;      // != nullptr: this launch sums its updates' CR statistics itself, chunk by chunk of cr_g1 positions (HOT 3 / 4 only)
-    // consumer-side fold (round 5; one wavefront per chain, HOT 3 / 4): != nullptr -- the PREVIOUS generation's level-1 partial sums have not been folded
+    // consumer-side fold (round 5; HOT 3 / 4): != nullptr -- the PREVIOUS generation's level-1 partial sums have not been folded
     // into the totals yet: wavefront 0 of every workgroup of this launch folds them itself (cr_fold: cr_final_kernel's own code, same bits), the workgroup
     // takes p_cr from that, workgroup 0 stores the new totals into cr_fold_out (another block than cr_fold_tot: the other workgroups still read that one)
     const double* cr_fold_part;
     const double* cr_fold_tot;
     double* cr_fold_out;
+    uint32_t cr_fold_nb;   // partial sums per array (= their stride): the generation's level-1 sums, or what cr_mid_kernel passes left of them; <= CR_FINAL_MAX
     uint32_t cr_chunk0, cr_n1;   // first chunk of this half generation, chunks per generation (the stride of the m-major partial arrays)
     uint32_t adapt_on;     // dream.py:92  burnin_gen > k
     uint32_t cr_gate;      // dream.py:123 history length > n_cr_gen
@@ -353,9 +354,10 @@ __device__ __forceinline__ double cr_array_sum(const double* arr, uint32_t nb) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     double v[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {      // (every lane loads, index clamped, the value selected afterwards: a predicated load is guarded by s_waitcnt vmcnt(0))
         const uint32_t b = (uint32_t)r * WAVE + lane;
-        v[r] = b < nb ? arr[b] : 0.0;
+        const double x = arr[b < nb ? b : nb - 1u];
+        v[r] = b < nb ? x : 0.0;
     }
     double s = 0.0;
 #pragma unroll
@@ -1415,24 +1417,24 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
         if (CRP) run = false; else return;
     }
     // ---- consumer-side fold of the PREVIOUS generation's CR statistics (PhaseArgs::cr_fold_part), cr_final_kernel's arithmetic spread over the
-    // workgroup: wavefront k < 2 n_cr sums ONE array of partial sums (delta sums of CR value k, or the counts of CR value k - n_cr) exactly as cr_fold does
-    // -- 8 loads per lane, in flight behind the wavefront's record load -- and leaves the total in LDS; behind the barrier every wavefront finishes the
+    // workgroup: each of the 2 n_cr arrays of partial sums (delta sums / counts of one CR value) is summed by ONE wavefront exactly as cr_fold does --
+    // up to 8 loads per lane, in flight behind the wavefront's record load -- the totals meet in LDS; behind the barrier every wavefront finishes the
     // fold for itself (a few additions and divisions on uniform values).  Same sums in the same order as cr_final_kernel: same bits (tested against the
-    // crnofold path).  One wavefront folding everything (48 loads per lane, six DPP trees) cost the launch 2.0 us, this form 1.3 us -- against the 4.5 us dispatch of
-    // cr_final_kernel it replaces: cfg2's burn-in generation 20.9 -> 18.5 us (profiles/r05_consumer_side_fold.txt).
+    // crnofold path).  One wavefront folding everything (48 loads per lane, six DPP trees) cost cfg2's launch 2.0 us, this form 1.3 us -- against the 4.5 us
+    // dispatch of cr_final_kernel it replaces: cfg2's burn-in generation 20.9 -> 18.5 us (profiles/r05_consumer_side_fold.txt).
     // (The barrier HERE, ahead of every wavefront's loads: with it where the CR value is drawn -- behind the row requests, so that only the folding
     // wavefronts would feel the fold -- the compiler serialised the partner-row loads of EVERY launch of the flavour, 23 instead of 8.3 us per launch.)
     PcrGiven pcr_fold;
-    if constexpr (CRP && LPC == WAVE) {
-        static_assert(2 * MAX_CR <= 1024 / WAVE, "a wavefront per array of partial sums");
+    if constexpr (CRP) {
         pcr_fold.on = a.cr_fold_part != nullptr;         // uniform over the launch
         if (pcr_fold.on) {
             __shared__ double s_tot[2 * MAX_CR];
-            const uint32_t n_cr = a.n_cr;
-            if ((uint32_t)cw < 2u * n_cr) {              // uniform per wavefront
-                const uint32_t arr = (uint32_t)cw < n_cr ? (uint32_t)cw : (uint32_t)MAX_CR + ((uint32_t)cw - n_cr);
-                const double tsum = cr_array_sum<CR_FINAL_MAX / WAVE>(a.cr_fold_part + (uint64_t)arr * a.cr_n1, a.cr_n1);
-                if (q == 0) s_tot[arr] = tsum;
+            constexpr uint32_t NWV = (uint32_t)(BLK / WAVE);
+            const uint32_t n_cr = a.n_cr, wv = (uint32_t)lane / (uint32_t)WAVE;
+            for (uint32_t k = wv; k < 2u * n_cr; k += NWV) {      // uniform per wavefront
+                const uint32_t arr = k < n_cr ? k : (uint32_t)MAX_CR + (k - n_cr);
+                const double tsum = cr_array_sum<CR_FINAL_MAX / WAVE>(a.cr_fold_part + (uint64_t)arr * a.cr_fold_nb, a.cr_fold_nb);
+                if ((lane & (WAVE - 1)) == 0) s_tot[arr] = tsum;
             }
             __syncthreads();
             CrTotals T;
@@ -1447,7 +1449,7 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
                 }
             }
             cr_finalize(any, n_cr, T);
-            if (blockIdx.x == 0 && cw == 0 && q == 0) cr_write_totals(T, n_cr, a.cr_fold_out);
+            if (blockIdx.x == 0 && lane == 0) cr_write_totals(T, n_cr, a.cr_fold_out);
 #pragma unroll
             for (int m = 0; m < MAX_CR; ++m)
                 pcr_fold.p[m] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(T.p[m])), __builtin_amdgcn_readfirstlane(__double2loint(T.p[m])));
@@ -1472,8 +1474,8 @@ __global__ __launch_bounds__(block_for_hot(LPC, HOT, DPL)) void phase_fused_kern
     if constexpr (LEAN) {
         const bool lean_early = LEAN_CT || a.lean != 0u;
         auto early = [tc, q, dim_early, lean_early](Work<DPL>& k) { if (lean_early) k.ll_cur = Target<TARGET, LPC, DPL>::eval(k.x, q, dim_early, tc); };
-        make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : 2)>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, early);
-    } else if constexpr (CRP && LPC == WAVE) {
+        make_proposal<ALGO, LPC, DPL, NP, (LEAN_CT ? 0 : 2)>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, early, pcr_fold);
+    } else if constexpr (CRP) {
         make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, stamp_arg, NoEarly(), pcr_fold);
     } else {      // (one wavefront per chain: exactly the call of rounds 1-3)
         make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk, rec, stamp_arg);

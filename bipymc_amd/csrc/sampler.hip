@@ -226,7 +226,7 @@ template <int ALGO, int T, int NP, int LPC, int DPL, int HOT>
 static void launch_hot(const PhaseArgs& a, hipStream_t s) {
     static hipFunction_t fn = nullptr;
     if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL)) ++g_crp_launched;
-    if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL) && LPC == WAVE && a.cr_fold_part != nullptr) ++g_crfold_launched;
+    if (ALGO == ALGO_DREAM && hot_is_adapt(HOT) && crp_shape(LPC, DPL) && a.cr_fold_part != nullptr) ++g_crfold_launched;
     constexpr unsigned blk = (unsigned)block_for_hot(LPC, HOT, DPL), cpw = blk / (unsigned)LPC;      // (burn-in flavours of one wavefront per chain: 16 chains per workgroup)
     launch_packed(phase_fused_kernel<ALGO, T, LPC, DPL, NP, HOT>, fn, a, (a.n_items + cpw - 1u) / cpw, blk, s);
 }
@@ -422,13 +422,14 @@ struct bpm_sampler {
     // CR reduction (kernels.h): level-1 partial sums [2 MAX_CR][cr_n1] of a generation (chunks of cr_g1 positions), two buffers for the cr_mid_kernel passes
     double* cr_p1 = nullptr;          // two generations' worth: generation t writes half t & 1 (cr_p1_cur) -- the update kernel that folds generation t's sums
     double* cr_p1_cur = nullptr;      // (consumer-side fold, below) writes its own level 1 in the same launch
-    // Consumer-side fold (round 5): with one wavefront per chain and at most CR_FINAL_MAX level-1 sums a generation's fold is NOT dispatched (cr_final_kernel:
+    // Consumer-side fold (round 5): where the update kernels sum level 1 themselves (one GPU, HOT 3 / 4) a generation's fold is NOT dispatched (cr_final_kernel:
     // one wavefront at the floor of a dependent launch, 4.5 us of cfg2's 20.6 us burn-in generation): it stays pending, and wavefront 0 of every workgroup of
     // the NEXT generation's first update launch folds the sums itself (PhaseArgs::cr_fold_part: the same device function, the same bits), workgroup 0 stores
     // the new totals into the other totals block, which the second launch and everything later read.  What cannot consume a pending fold -- the last generation
     // of a bpm_step call, the first steady-state generation, a launch that takes another flavour -- gets cr_final_kernel as before (cr_flush_pending).
     bool cr_pending = false;
-    const double* cr_pend_src = nullptr;
+    const double* cr_pend_src = nullptr;      // (the generation's level-1 sums, or what the cr_mid_kernel passes left of them: cr_pend_cnt <= CR_FINAL_MAX per array)
+    uint32_t cr_pend_cnt = 0;
     bool gen_fold_planned = false;    // this generation's first update launch was given a pending fold: finish_generation checks that it took a flavour that folds
     double* cr_p2[2] = {nullptr, nullptr};
     uint32_t cr_g1 = 16, cr_n1 = 0;
@@ -1486,7 +1487,7 @@ static int launch_cr_final(bpm_sampler* s, const double* src, uint32_t cnt) {
 static int cr_flush_pending(bpm_sampler* s) {
     if (!s->cr_pending) return 0;
     s->cr_pending = false;
-    return launch_cr_final(s, s->cr_pend_src, s->cr_n1);
+    return launch_cr_final(s, s->cr_pend_src, s->cr_pend_cnt);
 }
 
 static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
@@ -1618,7 +1619,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
             a.pack_stride = s->xstride();
         }
         a.cr_part1 = nullptr; a.cr_chunk0 = 0u; a.cr_n1 = s->cr_n1;
-        a.cr_fold_part = nullptr; a.cr_fold_tot = nullptr; a.cr_fold_out = nullptr;
+        a.cr_fold_part = nullptr; a.cr_fold_tot = nullptr; a.cr_fold_out = nullptr; a.cr_fold_nb = 0u;
         if (sync) {      // samplers.py:261-308: one launch, every local chain against all other chains, updates banked
             a.algo = (uint32_t)BPM_ALGO_DEMC;
             a.mode = 2u;
@@ -1658,8 +1659,8 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     // takes a flavour that can (one wavefront per chain, in-kernel level 1), else dispatched now, ahead of the update launches
     if (s->cr_pending) {
         PhaseArgs& a0 = s->cur_args[0];
-        if (s->gen_cr_inkernel && s->shape.lpc == WAVE && a0.n_items > 0 && a0.cr_part1 != nullptr) {
-            a0.cr_fold_part = s->cr_pend_src; a0.cr_fold_tot = s->cr_state; a0.cr_fold_out = s->cr_state_alt;
+        if (s->gen_cr_inkernel && a0.n_items > 0 && a0.cr_part1 != nullptr) {
+            a0.cr_fold_part = s->cr_pend_src; a0.cr_fold_nb = s->cr_pend_cnt; a0.cr_fold_tot = s->cr_state; a0.cr_fold_out = s->cr_state_alt;
             std::swap(s->cr_state, s->cr_state_alt);
             s->cur_args[1].cr_state = s->cr_state;      // (the second launch reads what workgroup 0 of the first one stored; the first takes p_cr from its own fold)
             s->cr_pending = false;
@@ -1726,10 +1727,11 @@ static int finish_generation(bpm_sampler* s) {
             src = dst; cnt = nn; flip ^= 1;
         }
         static const bool no_defer = test_path("crnofold");
-        if (!level1_from_slots && cnt <= CR_FINAL_MAX && src == s->cr_p1_cur && s->shape.lpc == WAVE && !g_call_last_gen && !no_defer) {
+        if (!level1_from_slots && cnt <= CR_FINAL_MAX && !g_call_last_gen && !no_defer) {
             // consumer-side fold: no dispatch -- the next generation's first update launch folds (prepare_generation), or cr_flush_pending
             s->cr_pending = true;
             s->cr_pend_src = src;
+            s->cr_pend_cnt = cnt;
         } else {
             CK(launch_cr_final(s, src, cnt));
         }

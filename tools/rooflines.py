@@ -57,7 +57,7 @@ out = [
           "product::phase_fused_kernel<1, 1, 64, 2, 3, 1>" if os.path.exists(os.path.join(P, T + "_kernel_stats_bench_default.csv")) else "64, 2, 3, 1>", 7216, 4096,
           traffic(T + "_pmc_bench_driver.txt"), "kernel-trace duration (python bench.py --no-moments --preheat 0 under rocprofv3 --kernel-trace); bench.py reports the back-to-back launch period"),
     entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", T + "_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
-          "Welford moments r/w add 32 d bytes per update; level 1 of the CR reduction inside the kernel (round 4), + cr_final_kernel per generation"),
+          "Welford moments r/w add 32 d bytes per update; level 1 of the CR reduction inside the kernel (round 4); the fold of a generation's sums inside the NEXT generation's first launch (round 5: that launch 10.0-10.6 us, the other 8.3-8.7), no reduction dispatch"),
     entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", T + "_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
           traffic(T + "_pmc_cfg3.txt"), "latency bound: launch floor + dependent Infinity-Cache round trips; a 16-byte row is an eighth of a 128-byte line"),
     entry("cfg5 DREAM mixture d=8 N=262144 steady", "phase_fused_kernel<1,2,4,2,3,2>", T + "_kernel_stats_cfg5.csv", "<1, 2, 4, 2, 3, 2>", 592, 131072,
