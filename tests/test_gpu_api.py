@@ -409,6 +409,63 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
+def test_cr_fold_inside_the_next_launch_equals_the_dispatched_fold_over_random_call_sequences():
+    """Round 5: during DREAM's burn-in a generation's CR fold is not dispatched -- the next generation's first update launch folds the partial sums in every
+    workgroup (kernels.h: PhaseArgs::cr_fold_part), the last generation of a step call and whatever cannot consume a pending fold get cr_final_kernel
+    (sampler.hip: cr_pending).  Seeded random call sequences -- step calls of 1 ... 20 generations through and past a 60-generation burn-in, reads of the
+    CR statistics and the state in between, a new run, the outlier check due every 7 generations -- on every kernel shape (64 / 16 / 4 / 1 lanes per chain,
+    with and without cr_mid_kernel passes): p_cr, delta_m, n_cr_updates, state and ln-like after every call equal, bit for bit, what the test variant leaves
+    with every fold dispatched (crnofold), with level 1 from the slots (crslots) and with the general kernel (nohot)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+from bipymc_amd.utils import d100_gauss, mixture_nd
+out = []
+cases = ((d100_gauss.Gauss_100D()._bpm_target_spec(), 2048, dict(burnin_gen=60, n_cr_gen=3)),
+         (d100_gauss.Gauss_100D(dim=20)._bpm_target_spec(), 333, dict(burnin_gen=60, n_cr_gen=2)),
+         (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), 6000, dict(burnin_gen=60, n_cr_gen=3, outlier_every=7)),
+         (mixture_nd.BimodeGauss_ND(8)._bpm_target_spec(), 40000, dict(burnin_gen=60, n_cr_gen=3)),          # 2500 level-1 sums: one cr_mid_kernel pass
+         (mixture_nd.BimodeGauss_ND(2)._bpm_target_spec(), 3001, dict(burnin_gen=60, n_cr_gen=2)))
+for ci, ((tid, tp, d), N, kw) in enumerate(cases):
+    rs = np.random.RandomState(100 + ci)
+    e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=tid, target_params=tp, seed=77 + ci, keep_history=True, **kw)
+    e.set_state(np.random.RandomState(ci).normal(size=(N, d)) + 0.5)
+    e.begin_run()
+    done = 0
+    while done < 90:
+        k = int(rs.choice([1, 1, 2, 3, 5, 8, 20]))
+        e.step(k)
+        done += k
+        st = e.stats()
+        out += [st["p_cr"], st["delta_m"], st["n_cr_updates"], np.array([st["local_n_accepted"], st["n_outlier_resets"]], dtype=float)]
+        if rs.randint(0, 3) == 0:
+            out += [e.get_state(), e.get_loglike()]
+        if done > 30 and rs.randint(0, 8) == 0:
+            e.begin_run()                      # (a new run_mcmc call: the generation counter of the run restarts, burn-in is on again)
+    out += [e.get_state(), e.get_loglike()]
+    e.close()
+np.save(sys.argv[1], np.concatenate([np.asarray(o, dtype=float).reshape(-1) for o in out]))
+'''
+    res = []
+    for paths in ("", "crnofold", "crslots", "nohot"):
+        env = dict(os.environ)
+        env.pop("BPM_TEST_PATHS", None)
+        if paths:
+            env["BPM_TEST_PATHS"] = paths
+            env["BPM_LIB_PATH"] = _test_lib_path()
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npy")
+            subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
+            res.append(np.load(f))
+    for r in res[1:]:
+        assert r.shape == res[0].shape and np.array_equal(res[0], r)
+
+
 def test_outlier_check_reads_position_ordered_history_where_it_lies():
     """DREAM burn-in with the outlier check on a sampler that appends its history in shuffle order (fewer than 64 lanes per chain, one GPU): the
     state rows stay in position order and the check's kernels find a chain's rows through the rows' shuffle keys (outlier_row_keys), the ln-like rows
