@@ -767,7 +767,7 @@ def host_callback_config(device, budget_s=4.5):
     half = N // 2
     out = []
 
-    def run(name, one_generation, init, seconds, extra):
+    def run(name, one_generation, init, seconds, extra, max_calls=5000):
         e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, device=device,
                       del_pairs=DEL_PAIRS, burnin_gen=0, n_cr_gen=N_CR_GEN, n_cr=3)
         try:
@@ -779,7 +779,7 @@ def host_callback_config(device, budget_s=4.5):
             for _ in range(3):                                        # warm-up
                 one_generation(e, t_py)
             gens, t_py[0], t0 = 0, 0.0, time.perf_counter()
-            while time.perf_counter() - t0 < seconds and gens < 5000:
+            while time.perf_counter() - t0 < seconds and gens < max_calls:
                 one_generation(e, t_py)
                 gens += 1
             e.synchronize()
@@ -879,6 +879,31 @@ def host_callback_config(device, budget_s=4.5):
             dict(pcie=dict(d2h_bytes_per_half_generation=N * 4, h2d_bytes_per_half_generation=0, staging="none: proposals and ln-likes stay in device memory")))
     except Exception as ex:                                           # noqa: BLE001
         out.append(dict(config="cfg2 shape with a device-resident (torch) callback", error=str(ex)))
+    # (c) the same likelihood as a few lines of HIP source, compiled with hiprtc into ONE kernel between the library's proposal and commit kernels
+    # (bpm_set_device_likelihood; bipymc_amd.HipLikelihood): bpm_step drives the sampler, no host code inside a generation
+    try:
+        src = ("__device__ double ln_like(const double* x, int d, const double* p) {\n"
+               "    double s1 = 0.0, s2 = 0.0;\n"
+               "    for (int j = 0; j < d; ++j) { const double z = x[j] * p[3 + j]; s1 += z; s2 += z * z; }\n"
+               "    return p[0] - 0.5 * (p[1] * s2 - p[2] * s1 * s1);\n}\n")
+        pblock = np.concatenate([[c0, a, b], isig])
+        STEP = 50
+
+        def gen_src(e, t_py):                                         # (`run` counts generations: STEP of them per call here)
+            e.step(STEP)
+        n0 = len(out)
+        run("cfg2 shape with ln_like_fn given as HIP SOURCE (bipymc_amd.HipLikelihood: compiled at construction into a kernel between the proposal and the "
+            "commit kernel, bpm_step drives the sampler): DREAM gauss d=100 N=8192 steady", gen_src, lambda e: e.set_device_likelihood(src, pblock), budget_s * 0.15,
+            dict(pcie=dict(d2h_bytes_per_half_generation=0, h2d_bytes_per_half_generation=0, staging="none"), generations_per_step_call=STEP),
+            max_calls=80)                                             # (3 + 80 calls of 50 generations: inside the 6000 reserved history rows)
+        if len(out) > n0:                                             # `run` timed step calls of STEP generations each
+            ent = out[-1]
+            ent["steps"] *= STEP
+            ent["value"] *= STEP
+            ent["ms_per_step"] /= STEP
+            ent["share_of_time_in_the_callback"] = 0.0
+    except Exception as ex:                                           # noqa: BLE001
+        out.append(dict(config="cfg2 shape with ln_like_fn given as HIP source", error=str(ex)))
     return out
 
 

@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 
 from .demc import DeMcMpi  # noqa: F401
 from .dream import DreamMpi  # noqa: F401
+from .device_likelihood import HipLikelihood  # noqa: F401

@@ -91,6 +91,9 @@ SIGNATURES = {
     "bpm_commit_device": (C.c_int, [_H, C.c_void_p]),
     "bpm_state_device": (C.c_int, [_H, _P(C.c_void_p), _ip, _ip]),
     "bpm_set_loglike_device": (C.c_int, [_H, C.c_void_p]),
+    "bpm_set_device_likelihood": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_double), C.c_int32]),
+    "bpm_refresh_device_loglike": (C.c_int, [_H]),
+    "bpm_check_device_likelihood": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]),
     "bpm_get_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_get_loglike_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_reserve_history": (C.c_int, [_H, C.c_int64]),
@@ -137,7 +140,7 @@ def load():
 
 
 # The files a library's build id is the SHA-256 of, in this order (bipymc_amd/csrc/Makefile: ID_SRCS)
-_ID_SRCS = ("csrc/sampler.hip", "csrc/kernels.h", "csrc/kernels_wide.h", "csrc/philox.h", "csrc/rocrand_check.h", "csrc/aql_queue.h",
+_ID_SRCS = ("csrc/sampler.hip", "csrc/kernels.h", "csrc/kernels_wide.h", "csrc/philox.h", "csrc/rocrand_check.h", "csrc/aql_queue.h", "csrc/user_likelihood.h",
             "../include/bipymc_hip.h", "../include/bipymc_hip_test.h", "csrc/Makefile")
 
 

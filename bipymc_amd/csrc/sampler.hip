@@ -37,6 +37,7 @@
 #include "rocrand_check.h"
 #endif
 #include "aql_queue.h"
+#include "user_likelihood.h"
 
 using namespace bpm;
 
@@ -448,6 +449,10 @@ struct bpm_sampler {
     int64_t prop_active = 0;                 // its active work items
     bool prop_whole = false;                 // it was proposed through bpm_propose (caller-owned buffers): bpm_commit finishes it
     std::vector<uint8_t> prop_done;          // [prop_chunks] 1: the piece's ln-likes have been handed in
+    // the caller's ln_like_fn as a kernel compiled from HIP source (user_likelihood.h; bpm_set_device_likelihood): bpm_step then drives a host-callback sampler
+    hipModule_t user_mod = nullptr;
+    hipFunction_t user_fn = nullptr;
+    double* user_params = nullptr;
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
     int32_t* trace_i32 = nullptr;      // per-chain decision trace (bpm_set_trace: test variant only; always null in the product library)
@@ -918,6 +923,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (free_buffers) { if (s->xcd_args) (void)hipFree(s->xcd_args); if (s->xcd_ctl) (void)hipFree(s->xcd_ctl); }
 #endif
     for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
+    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_params) (void)hipFree(s->user_params); }
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -2168,10 +2174,12 @@ static bool group_goes_direct(const Group& g, bool push, bool& group_direct) {
             s0->cfg.algo != BPM_ALGO_DEMC_SYNC && !s0->trace_i32 && !s0->stamps && !g_host_timing && !s0->dq->failed() && !s0->shape_needs_scratch);
 }
 
+static int run_generations_user(bpm_sampler* s, int64_t n_gens);      // (a host-callback sampler with a device likelihood: below, beside the host-callback core)
 static int run_generations(const Group& g, int64_t n_gens) {
     bpm_sampler* s0 = g.h[0];
+    if (s0->cfg.target_id == BPM_TARGET_HOST_CALLBACK && s0->user_fn && g.R == 1) return run_generations_user(s0, n_gens);
     PhaseLaunch fn = pick_fused(s0);
-    if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit");
+    if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit (or give it a device likelihood: bpm_set_device_likelihood)");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
     int64_t done = 0;
     const bool push = s0->push_enabled && s0->push_connected;
@@ -2869,19 +2877,20 @@ extern "C" int bpm_synchronize(bpm_handle_t s) {
 // caller evaluates (bpm_propose_begin / _chunk, bpm_commit_chunk / _end), through the caller-owned buffers of rounds 1-4 (bpm_propose / bpm_commit:
 // the same calls with one chunk and a compaction copy), or from DEVICE memory the caller's own framework computed them in (bpm_propose_device /
 // bpm_commit_device: no PCIe).  Then the commit kernel: Metropolis (samplers.py:328-336), append (chain.py:51-54), CR statistics.
-static int propose_launch(bpm_sampler* s, const char* who) {
+static int propose_launch(bpm_sampler* s, const char* who, bool clear_ids = true) {
     if (!s->run_open) return fail(std::string(who) + ": call bpm_begin_run first");
     if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail(std::string(who) + ": sampler has a device target; use bpm_step");
     if (s->proposed) return fail(std::string(who) + ": previous proposals not committed");
     if (s->phase == 0) CK(prepare_generation(s, 1));
     const PhaseArgs& a = s->cur_args[s->phase];
-    HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
+    // (only entries the proposal kernel does not write -- work items beyond n_items, which nobody reads: kept for the host transports as rounds 1-4 had it)
+    if (clear_ids) HIPCK(hipMemsetAsync(s->ids_buf, 0xFF, s->n_local * sizeof(int32_t), s->stream));
     if (a.n_items > 0) g_propose[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
     return 0;
 }
 // the commit kernel + the bookkeeping of the half generation (the ln-likes of every active work item are in aux_buf[n_local ..) on the stream by now)
-static int commit_finish(bpm_sampler* s, int64_t n_active) {
+static int commit_finish(bpm_sampler* s, int64_t n_active, bool sync = true) {
     const PhaseArgs& a = s->cur_args[s->phase];
     if (a.n_items > 0) g_commit[s->cfg.algo == BPM_ALGO_DREAM ? 1 : 0][s->shape.idx](a, s->stream);
     HIPCK(hipGetLastError());
@@ -2894,7 +2903,7 @@ static int commit_finish(bpm_sampler* s, int64_t n_active) {
         return finish_generation(s);       // (synchronous DE-MC: never DREAM, no outlier check)
     }
     CK(allgather_state(s));
-    HIPCK(hipStreamSynchronize(s->stream));
+    if (sync) HIPCK(hipStreamSynchronize(s->stream));
     s->proposed = false; s->prop_mode = 0;
     if (s->phase == 0) {
         s->phase = 1;
@@ -2975,6 +2984,98 @@ extern "C" int bpm_commit_end(bpm_handle_t s) {
     s->prop_whole = false;
     if (s->prop_given != s->prop_chunks) return fail("bpm_commit_end: " + std::to_string(s->prop_given) + " of " + std::to_string(s->prop_chunks) + " chunks were given their ln-likes (bpm_commit_chunk)");
     return commit_finish(s, s->prop_active);
+}
+
+// ---- the caller's likelihood as a kernel compiled from HIP source (user_likelihood.h): proposal kernel -> the caller's kernel -> commit kernel, all on the
+// sampler's stream, no host code inside a generation.  samplers.py:36-43 evaluates ln_like_fn(theta, **ln_kwargs) row by row on the host; here `params` takes
+// the place of ln_kwargs.
+static bpm::Hiprtc g_hiprtc;
+static int user_eval_launch(bpm_sampler* s, const double* rows, const int32_t* ids, uint32_t n, double* out) {
+    if (n == 0) return 0;
+    int n_i = (int)n, ld_i = (int)s->ld, d_i = (int)s->dim, rpb = 0, ldp = 0;
+    bpm::user_eval_tile(s->dim, rpb, ldp);
+    const double* params = s->user_params;
+    void* args[] = {(void*)&rows, (void*)&ids, (void*)&n_i, (void*)&ld_i, (void*)&d_i, (void*)&params, (void*)&out, (void*)&rpb, (void*)&ldp};
+    const unsigned block = (unsigned)bpm::USER_EVAL_BLOCK, per = rpb > 0 ? (unsigned)rpb : block, grid = (n + per - 1u) / per;
+    const unsigned lds = rpb > 0 ? (unsigned)rpb * (unsigned)ldp * (unsigned)sizeof(double) : 0u;
+    HIPCK(hipModuleLaunchKernel(s->user_fn, grid, 1, 1, block, 1, 1, lds, s->stream, args, nullptr));
+    return 0;
+}
+// ln-like of the local chains' CURRENT states from the installed device likelihood (what bpm_set_loglike takes from the host)
+static int user_refresh_ll(bpm_sampler* s) {
+    CK(user_eval_launch(s, s->G + (uint64_t)s->rank * s->L.blk, nullptr, s->n_local, s->ll));
+    if (s->hist_rows >= 1 && s->hist_rows == s->rows_logical)
+        HIPCK(hipMemcpyAsync(s->llhist + (size_t)(s->hist_rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+static int run_generations_user(bpm_sampler* s, int64_t n_gens) {
+    const int halves = s->cfg.algo == BPM_ALGO_DEMC_SYNC ? 1 : 2;
+    for (int64_t g = 0; g < n_gens; ++g) {
+        for (int h = 0; h < halves; ++h) {
+            CK(propose_launch(s, "bpm_step", false));      // (the proposal kernel writes the id of EVERY work item below n_items, -1 for an idle one)
+            const PhaseArgs& a = s->cur_args[s->phase];
+            int64_t act = (int64_t)a.n_items;
+            if (s->world > 1 && a.n_items > 0) {      // (a rank of a world: half of its work items sit in the other pool)
+                HIPCK(hipMemcpyAsync(s->h_ids, s->ids_buf, s->n_local * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+                HIPCK(hipStreamSynchronize(s->stream));
+                act = 0;
+                for (uint32_t w = 0; w < a.n_items; ++w) act += s->h_ids[w] >= 0 ? 1 : 0;
+            }
+            CK(user_eval_launch(s, s->prop_buf, s->world > 1 ? s->ids_buf : nullptr, a.n_items, s->aux_buf + s->n_local));
+            s->proposed = true; s->prop_mode = 3; s->prop_chunks = 0;
+            CK(commit_finish(s, act, false));
+        }
+    }
+    return 0;
+}
+
+extern "C" int bpm_check_device_likelihood(const char* hip_source, const char* arch, char* log, int64_t log_cap) {
+    if (!hip_source) return fail("bpm_check_device_likelihood: null source");
+    std::vector<char> code;
+    const std::string why = bpm::compile_user_likelihood(g_hiprtc, hip_source, (arch && *arch) ? arch : "gfx950", code);
+    if (log && log_cap > 0) {
+        const size_t n = std::min(why.size(), (size_t)log_cap - 1);
+        std::memcpy(log, why.data(), n);
+        log[n] = '\0';
+    }
+    return why.empty() ? 0 : fail("bpm_check_device_likelihood: " + why);
+}
+
+extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source, const double* params, int32_t n_params) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK) return fail("bpm_set_device_likelihood: the sampler has a shipped device target (create it with BPM_TARGET_HOST_CALLBACK)");
+    if (s->proposed) return fail("bpm_set_device_likelihood: a half generation is open (bpm_propose ... without its commit)");
+    if (!hip_source || n_params < 0 || (n_params > 0 && !params)) return fail("bpm_set_device_likelihood: bad argument");
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, s->cfg.device));
+    std::vector<char> code;
+    const std::string why = bpm::compile_user_likelihood(g_hiprtc, hip_source, prop.gcnArchName, code);
+    if (!why.empty()) return fail("bpm_set_device_likelihood: " + why);
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    HIPCK(hipModuleLoadData(&mod, code.data()));
+    if (hipModuleGetFunction(&fn, mod, "bpm_user_eval") != hipSuccess || !fn) {
+        (void)hipGetLastError();
+        (void)hipModuleUnload(mod);
+        return fail("bpm_set_device_likelihood: the compiled module has no bpm_user_eval kernel");
+    }
+    HIPCK(hipStreamSynchronize(s->stream));                      // (a previous likelihood's launches are done)
+    if (s->user_mod) (void)hipModuleUnload(s->user_mod);
+    if (s->user_params) { (void)hipFree(s->user_params); s->user_params = nullptr; }
+    s->user_mod = mod; s->user_fn = fn;
+    CK(dev_alloc(&s->user_params, (size_t)std::max(n_params, 1)));
+    HIPCK(hipMemsetAsync(s->user_params, 0, (size_t)std::max(n_params, 1) * sizeof(double), s->stream));
+    if (n_params > 0) HIPCK(hipMemcpyAsync(s->user_params, params, (size_t)n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    return user_refresh_ll(s);
+}
+
+extern "C" int bpm_refresh_device_loglike(bpm_handle_t s) {
+    CK(check_handle(s));
+    CK(set_device(s));
+    if (!s->user_fn) return fail("bpm_refresh_device_loglike: no device likelihood installed (bpm_set_device_likelihood)");
+    return user_refresh_ll(s);
 }
 
 // the caller-owned-buffer form of rounds 1-4, compacted to the active work items.  Since round 5 the read-back runs in pieces INSIDE the call: the

@@ -81,6 +81,7 @@ class DeMcMpi(object):
         #                      (a torch / cupy array) -- nothing crosses PCIe (include/bipymc_hip.h: bpm_propose_device / bpm_commit_device)
         # callback_chunks > 1: the half generation's proposals are handed to ln_like_fn in that many pieces, the DMA of piece k + 1 under the evaluation
         # of piece k (vectorized=True: one call per piece); default: one call per half generation
+        #   ln_like_fn = HipLikelihood(source, params)  (device_likelihood.py): compiled into a kernel of the generation loop -- no callback at all
         vec = kwargs.get("vectorized", False)
         self._device_callback = isinstance(vec, str) and vec == "device"
         if isinstance(vec, str) and not self._device_callback:
@@ -135,6 +136,16 @@ class DeMcMpi(object):
             # without a history param_est_moments answers from per-generation population sums (whole-generation burn-ins)
             running_moments=kwargs.get("running_moments", not kwargs.get("keep_history", True)), **self._engine_kwargs(kwargs))
         self.n_local = self.n_chains // self.comm.size
+        # ln_like_fn given as HIP source: a host-callback target whose likelihood is a kernel between the proposal and the commit kernel
+        # (include/bipymc_hip.h: bpm_set_device_likelihood); an engine without the entry point (the CPU test engine) calls its python_fn
+        from .device_likelihood import HipLikelihood
+        self._hip_likelihood = None
+        if isinstance(ln_like_fn, HipLikelihood) and not self.uses_device_target:
+            if hasattr(self._engine, "set_device_likelihood"):
+                self._engine.set_device_likelihood(ln_like_fn.source, ln_like_fn.params)
+                self._hip_likelihood = ln_like_fn
+            elif ln_like_fn.python_fn is None:
+                raise TypeError("HipLikelihood without python_fn on an engine that cannot compile it")
         self._connect_exchange()
         self._hist_cache = None
         self._hist_cache_rows = -1
@@ -272,6 +283,9 @@ class DeMcMpi(object):
         self._hist_cache = None
         self._hist_cache_rows = -1
         if not self.uses_device_target:
+            if self._hip_likelihood is not None:
+                self._engine.refresh_device_loglike()
+                return
             if self._device_callback:
                 self._engine.set_loglike_device(self.log_like_fn(self._engine.state_device(), **self._ln_kwargs))
                 return
@@ -322,7 +336,7 @@ class DeMcMpi(object):
         chunk = int(self.checkpoint) if self.checkpoint and self.checkpoint > 0 else n_gens
         while done < n_gens:
             todo = min(chunk, n_gens - done)
-            if self.uses_device_target:
+            if self.uses_device_target or self._hip_likelihood is not None:
                 eng.step(todo)
             else:
                 for _ in range(todo):

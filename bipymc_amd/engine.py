@@ -295,6 +295,17 @@ class HipEngine(object):
     def set_loglike_device(self, ll):
         self._ck(self.lib.bpm_set_loglike_device(self._h, C.c_void_p(_device_pointer(ll, self.n_local, "ln_like values"))))
 
+    def set_device_likelihood(self, source, params=()):
+        """ln_like_fn as HIP source (include/bipymc_hip.h: bpm_set_device_likelihood): compiled with hiprtc into a kernel that runs between the proposal
+        and the commit kernel; `step` then drives this host-callback sampler.  The current states are evaluated at once."""
+        p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
+        src = source.encode() if isinstance(source, str) else bytes(source)
+        self._ck(self.lib.bpm_set_device_likelihood(self._h, src, p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None, int(p.size)))
+        self.has_device_likelihood = True
+
+    def refresh_device_loglike(self):
+        self._ck(self.lib.bpm_refresh_device_loglike(self._h))
+
     def reserve_history(self, rows):
         self._ck(self.lib.bpm_reserve_history(self._h, int(rows)))
 

@@ -252,6 +252,18 @@ int bpm_propose_device(bpm_handle_t h, const double** rows_dev, const int32_t** 
 int bpm_commit_device(bpm_handle_t h, const double* ll_dev);
 int bpm_state_device(bpm_handle_t h, const double** rows_dev, int32_t* n_rows, int32_t* ld);
 int bpm_set_loglike_device(bpm_handle_t h, const double* ll_dev);
+/* ... and with the likelihood given as HIP SOURCE (round 5; samplers.py:36-43 takes any Python callable -- this is the form of it that runs at device
+ * speed with no framework in the process): `hip_source` defines
+ *     __device__ double ln_like(const double* x, int d, const double* p)       (x: one parameter vector; p: the caller's parameter block = ln_kwargs)
+ * bpm_set_device_likelihood compiles it with hiprtc (loaded on demand) into one kernel -- a thread per proposal row -- that runs between the library's
+ * proposal and commit kernels, copies the n_params doubles of `params` to the device and evaluates the current states (what bpm_set_loglike takes from
+ * the host).  From then on bpm_step drives this host-callback sampler like one with a shipped target: no host code inside a generation.  f64 arithmetic
+ * is compiled unfused (-ffp-contract=off) like the library's own.  A source that does not compile: error, the compiler's log in bpm_last_error.
+ * bpm_refresh_device_loglike re-evaluates the current states (after bpm_set_state / bpm_init_chains / a warm start).
+ * bpm_check_device_likelihood compiles only (no sampler, no GPU needed; arch NULL = "gfx950"): 0 or -1 with the reason in `log` (and bpm_last_error). */
+int bpm_set_device_likelihood(bpm_handle_t h, const char* hip_source, const double* params, int32_t n_params);
+int bpm_refresh_device_loglike(bpm_handle_t h);
+int bpm_check_device_likelihood(const char* hip_source, const char* arch, char* log, int64_t log_cap);
 
 /* history of this rank's chains: out[(g - g_lo) * n_local * dim + i * dim + j], g in [g_lo, g_hi) */
 int bpm_get_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);

@@ -4,6 +4,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -198,3 +199,18 @@ def test_no_kernel_spills_or_touches_scratch_memory(built):
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
         asm = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co]).decode()
     assert asm.count("scratch_load") + asm.count("scratch_store") == 0
+
+
+def test_hip_source_likelihood_compiles_without_a_gpu():
+    """bpm_check_device_likelihood (include/bipymc_hip.h): hiprtc builds the caller's ln_like + the wrapper kernel for gfx950 with no device in the
+    machine; a source that does not compile comes back as an error carrying the compiler's log (through HipLikelihood.check as ValueError)."""
+    from bipymc_amd import HipLikelihood
+    ok = HipLikelihood("__device__ double ln_like(const double* x, int d, const double* p) { double s = 0; for (int j = 0; j < d; ++j) s += x[j] * x[j] * p[0]; return -0.5 * s; }",
+                       params=[2.0])
+    assert ok.check() and ok.check("gfx950")
+    with pytest.raises(ValueError, match="does not compile(.|\n)*expected"):
+        HipLikelihood("__device__ double ln_like(const double* x, int d, const double* p) { return x[0] }").check()
+    with pytest.raises(ValueError, match="ln_like"):                 # the wrapper calls a function the source does not define
+        HipLikelihood("__device__ double other(const double* x) { return x[0]; }").check()
+    with pytest.raises(TypeError):
+        ok(np.zeros(3))                                              # no python_fn: device only

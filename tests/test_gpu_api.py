@@ -221,6 +221,58 @@ def test_callback_transports_agree():
     assert r.returncode == 0 and b"transports ok" in r.stdout, r.stdout.decode()[-3000:]
 
 
+def test_hip_source_likelihood_through_the_sampler_classes(tmp_path):
+    """ln_like_fn = HipLikelihood(source, params) (bipymc_amd/device_likelihood.py): DreamMpi / DeMcMpi run it inside the generation loop.  The same seed
+    with the same formula as a vectorised NumPy callback (the host-callback transport) gives the same run -- accept counts equal, chains to 1e-9 -- and the
+    posterior of a 6-D Gaussian with unequal scales comes out; a checkpoint + warm start goes on with the device likelihood; a prior's -inf is honoured."""
+    from bipymc_amd import DeMcMpi, DreamMpi, HipLikelihood
+    d = 6
+    mu, sig = np.arange(d) * 0.5, 1.0 + 0.5 * np.arange(d)
+    src = """
+    __device__ double ln_like(const double* x, int d, const double* p) {
+        if (x[0] < p[2 * d]) return -INFINITY;                       // a prior: x_0 above a bound
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) { const double z = (x[j] - p[j]) / p[d + j]; s += z * z; }
+        return -0.5 * s;
+    }"""
+    bound = -1.0
+
+    def np_ll(X):
+        X = np.atleast_2d(X)
+        z = (X - mu) / sig
+        s = np.zeros(len(X))
+        for j in range(d):                                            # (the kernel's summation order)
+            s += z[:, j] * z[:, j]
+        return np.where(X[:, 0] < bound, -np.inf, -0.5 * s)
+
+    ll = HipLikelihood(src, params=np.concatenate([mu, sig, [bound]]), python_fn=lambda th: float(np_ll(th)[0]))
+    assert ll.check()
+    for cls, kw in ((DreamMpi, dict(n_cr_gen=10, burnin_gen=100)), (DeMcMpi, dict(p_snooker=0.1))):
+        a = cls(ll, mu, varepsilon=1e-3, n_chains=512, seed=21, **kw)
+        b = cls(np_ll, mu, varepsilon=1e-3, n_chains=512, seed=21, vectorized=True, **kw)
+        assert a._hip_likelihood is ll and not a.uses_device_target and b._hip_likelihood is None
+        a.run_mcmc(512 * 301)
+        b.run_mcmc(512 * 301)
+        assert a.local_n_accepted == b.local_n_accepted and a.local_n_rejected == b.local_n_rejected
+        np.testing.assert_allclose(a.param_est(0)[2], b.param_est(0)[2], rtol=1e-9, atol=1e-11)
+        ch = a.param_est(512 * 150)[2]
+        assert ch[:, 0].min() >= bound
+        # x_0 ~ N(0, 1) truncated at -1: mean 0.2876, the others untruncated
+        assert abs(ch[:, 0].mean() - 0.2876) < 0.05
+        np.testing.assert_allclose(ch[:, 1:].mean(axis=0), mu[1:], atol=0.12 * sig[1:].max())
+        np.testing.assert_allclose(ch[:, 1:].std(axis=0), sig[1:], rtol=0.08)
+    f = str(tmp_path / "ck.npz")
+    a = DreamMpi(ll, mu, varepsilon=1e-3, n_chains=64, seed=3, n_cr_gen=5, burnin_gen=20, h5_file=f)
+    a.run_mcmc(64 * 30)
+    a.save_state(f)
+    a2 = DreamMpi(ll, None, dim=d, n_chains=64, seed=3, n_cr_gen=5, burnin_gen=20, h5_file=f, warm_start=True)
+    np.testing.assert_allclose(a2._engine.get_loglike(), a._engine.get_loglike(), rtol=0, atol=0)
+    a2.run_mcmc(64 * 10)
+    assert a2.param_est(0)[2].shape == (64 * 39, d)            # (demc.py:79: 29 + 9 generations behind the start row)
+    with pytest.raises(Exception, match="does not compile"):
+        DreamMpi(HipLikelihood("double ln_like(x) { }"), mu, n_chains=8, seed=1)
+
+
 def test_nan_ratio_raises_like_numpy():
     """both ln_like values -inf -> alpha NaN -> the reference's np.random.choice raises ValueError (samplers.py:336)"""
     from bipymc_amd import DeMcMpi

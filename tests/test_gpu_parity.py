@@ -628,6 +628,70 @@ def test_propose_commit_path_against_oracle(algo, d, N, kw):
     np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-11, atol=1e-13)
 
 
+# ------------------------------------------------------------------ ln_like_fn as HIP source (bpm_set_device_likelihood) against the oracle
+GAUSS_EQUICORR_HIP = """
+__device__ double ln_like(const double* x, int d, const double* p) {      // p = [rho, c0, a, b, 1/sigma ...] (oracle/sampler_ref.py: ll_gauss_equicorr)
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < d; ++j) { const double z = x[j] * p[4 + j]; s1 += z; s2 += z * z; }
+    return p[1] - 0.5 * (p[2] * s2 - p[3] * s1 * s1);
+}
+"""
+
+
+@pytest.mark.parametrize("algo,d,N,kw", [
+    (R.ALGO_DREAM, 10, 16, dict(burnin_gen=6, n_cr_gen=2)),
+    (R.ALGO_DREAM, 100, 64, dict(burnin_gen=5, n_cr_gen=1)),
+    (R.ALGO_DREAM, 7, 501, dict(burnin_gen=0, del_pairs=2)),
+    (R.ALGO_DEMC, 2, 24, dict(p_snooker=0.3)),
+    (R.ALGO_DEMC_SYNC, 3, 10, dict()),
+    (R.ALGO_DREAM, 600, 12, dict(burnin_gen=5, n_cr_gen=1)),
+])
+def test_hip_source_likelihood_against_oracle(algo, d, N, kw):
+    """Round 5: the caller's likelihood written as HIP source, compiled with hiprtc into a kernel between the proposal and the commit kernel, the
+    sampler driven by bpm_step (no host code inside a generation) -- against OracleSampler(ll_fn = the same formula in NumPy): accept counts equal,
+    state / ln-like / whole history to 1e-11 (the summation order of the two formulas differs), CR statistics to 1e-9.  Several step calls, a state
+    rewritten from the host in between (bpm_refresh_device_loglike)."""
+    params = _gauss_params(d, rho=0.4)
+
+    def py_ll(theta):
+        return float(R.ll_gauss_equicorr(theta, params))
+
+    eng = _engine(algo=algo, n_chains=N, dim=d, target_id=R.TARGET_HOST, target_params=None, seed=78, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("del_pairs", "burnin_gen", "n_cr_gen", "p_snooker")}
+    ora = R.OracleSampler(algo, N, d, R.TARGET_HOST, None, 78, ll_fn=py_ll, **okw)
+    X0 = np.random.RandomState(5).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
+    eng.set_state(X0)
+    with pytest.raises(Exception, match="bpm_propose / bpm_commit"):
+        eng.begin_run()
+        eng.step(1)                                     # (a host-callback sampler without a device likelihood cannot be stepped)
+    with pytest.raises(Exception, match="does not compile"):
+        eng.set_device_likelihood("__device__ double ln_like(const double* x) { return x[0] }")
+    eng.set_device_likelihood(GAUSS_EQUICORR_HIP, params)
+    np.testing.assert_allclose(eng.get_loglike(), [py_ll(x) for x in X0], rtol=1e-12, atol=1e-12)
+    ora.set_state(X0)
+    eng.begin_run()
+    g = 0
+    for k in (1, 4, 2):
+        eng.step(k)
+        for _ in range(k):
+            ora._generation(g, 0.5, True, 1e-12 if algo == R.ALGO_DREAM else 1e-15, 1e-2, None)
+            g += 1
+        np.testing.assert_allclose(eng.get_state(), ora.X, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(eng.get_loglike(), ora.ll, rtol=1e-11, atol=1e-12)
+    st = eng.stats()
+    assert st["local_n_accepted"] == ora.local_n_accepted and st["local_n_rejected"] == ora.local_n_rejected
+    if algo == R.ALGO_DREAM:
+        np.testing.assert_allclose(st["p_cr"], ora.cr.p_cr, rtol=1e-9)
+        np.testing.assert_allclose(st["n_cr_updates"], ora.cr.n_cr_updates, rtol=0)
+    np.testing.assert_allclose(eng.get_history(), ora.history_array(), rtol=1e-11, atol=1e-13)
+    # a state rewritten from the host: the ln-likes come from the device likelihood again
+    X1 = eng.get_state() + 0.125
+    eng.set_state(X1)
+    eng.refresh_device_loglike()
+    np.testing.assert_allclose(eng.get_loglike(), [py_ll(x) for x in X1], rtol=1e-12, atol=1e-12)
+    eng.close()
+
+
 # ------------------------------------------------------------------ the outlier check's device-side selection
 @pytest.mark.parametrize("N", [4, 7, 100, 4097, 262144])
 def test_outlier_quartile_selection_equals_numpy(N):

@@ -400,3 +400,14 @@ def test_exchange_is_chosen_collectively(monkeypatch):
     # an RCCL exchange asked for by name: no mapping at all
     s = run(Eng(), [], exchange="dense")
     assert s.exchange_used == "dense" and s._engine.calls == []
+
+
+def test_hip_likelihood_needs_an_engine_that_compiles_it_or_a_python_fn(oracle_engine):
+    """ln_like_fn = HipLikelihood(source, params): the HIP engine compiles the source into the generation loop (tests/test_gpu_api.py); an engine without
+    bpm_set_device_likelihood (the CPU test engine) can only go through python_fn -- without one the constructor says so before any chain exists."""
+    from bipymc_amd import DreamMpi, HipLikelihood
+    src = "__device__ double ln_like(const double* x, int d, const double* p) { double s = 0; for (int j = 0; j < d; ++j) s += x[j] * x[j]; return -0.5 * s; }"
+    with pytest.raises(TypeError, match="python_fn"):
+        DreamMpi(HipLikelihood(src), np.zeros(3), n_chains=8, seed=2)
+    ll = HipLikelihood(src, params=[1.0, 2.0], python_fn=lambda th: -0.5 * float(np.sum(np.asarray(th) ** 2)))
+    assert ll(np.ones(3)) == -1.5 and ll.params.dtype == np.float64 and ll.params.shape == (2,)
