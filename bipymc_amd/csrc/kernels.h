@@ -1732,8 +1732,9 @@ __global__ __launch_bounds__(REPLAY_WG) void phase_replay_sorted_kernel(const Ph
     store_row<LPC, DPL>(row_ptr(a.L, c), lane, a.L.ld, wk.p);
 }
 
-// Host-callback ln_like_fn: proposals out ...
-template <int ALGO, int LPC, int DPL>
+// Host-callback ln_like_fn: proposals out ...  (NP: the pair count as a compile-time constant -- partner ids in registers, one Philox evaluation per lane
+// with one wavefront per chain, make_proposal: RL / FAST / QUAD -- or 0: read from a.P.  Same draws, same bits.)
+template <int ALGO, int LPC, int DPL, int NP = 0>
 __global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const PhaseArgs a) {
     __shared__ uint32_t s_part[(block_for(LPC) / LPC) * MAX_PARTNERS];
     const int lane = threadIdx.x;
@@ -1745,7 +1746,7 @@ __global__ __launch_bounds__(block_for(LPC)) void phase_propose_kernel(const Pha
     if (LPC == WAVE && !active) return;
     if (LPC == WAVE) c = __builtin_amdgcn_readfirstlane(c);
     Work<DPL> wk;
-    make_proposal<ALGO, LPC, DPL, 0>(a, c, active, q, cw, s_part, wk);
+    make_proposal<ALGO, LPC, DPL, NP>(a, c, active, q, cw, s_part, wk);
     if (!active) return;
     store_row<LPC, DPL>(a.prop_buf + (uint64_t)w * a.L.ld, q, a.L.ld, wk.p);
     if (q == 0) {

@@ -266,7 +266,12 @@ static void launch_fused(const PhaseArgs& a, hipStream_t s) {
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_propose(const PhaseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
+    // the usual pair counts as compile-time constants (DREAM's default 3, DE-MC's 1): the partner ids stay in registers (kernels.h: phase_propose_kernel)
+    constexpr int NPC = ALGO == ALGO_DREAM ? 3 : 1;
+    if (a.mode != 2u && a.P == (uint32_t)NPC && !(ALGO != ALGO_DREAM && a.p_snooker > 0.0))
+        hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL, NPC>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
+    else
+        hipLaunchKernelGGL((phase_propose_kernel<ALGO, LPC, DPL>), dim3(grid_for(a.n_items, LPC)), dim3(block_for(LPC)), 0, s, a);
 }
 template <int ALGO, int LPC, int DPL>
 static void launch_commit(const PhaseArgs& a, hipStream_t s) {
@@ -2990,6 +2995,7 @@ extern "C" int bpm_commit_end(bpm_handle_t s) {
 // sampler's stream, no host code inside a generation.  samplers.py:36-43 evaluates ln_like_fn(theta, **ln_kwargs) row by row on the host; here `params` takes
 // the place of ln_kwargs.
 static bpm::Hiprtc g_hiprtc;
+static std::mutex g_hiprtc_mu;      // (the loader's state and hiprtc's own: one compilation at a time per process)
 static int user_eval_launch(bpm_sampler* s, const double* rows, const int32_t* ids, uint32_t n, double* out) {
     if (n == 0) return 0;
     int n_i = (int)n, ld_i = (int)s->ld, d_i = (int)s->dim, rpb = 0, ldp = 0;
@@ -3033,7 +3039,8 @@ static int run_generations_user(bpm_sampler* s, int64_t n_gens) {
 extern "C" int bpm_check_device_likelihood(const char* hip_source, const char* arch, char* log, int64_t log_cap) {
     if (!hip_source) return fail("bpm_check_device_likelihood: null source");
     std::vector<char> code;
-    const std::string why = bpm::compile_user_likelihood(g_hiprtc, hip_source, (arch && *arch) ? arch : "gfx950", code);
+    std::string why;
+    { std::lock_guard<std::mutex> lk(g_hiprtc_mu); why = bpm::compile_user_likelihood(g_hiprtc, hip_source, (arch && *arch) ? arch : "gfx950", code); }
     if (log && log_cap > 0) {
         const size_t n = std::min(why.size(), (size_t)log_cap - 1);
         std::memcpy(log, why.data(), n);
@@ -3051,7 +3058,8 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
     hipDeviceProp_t prop;
     HIPCK(hipGetDeviceProperties(&prop, s->cfg.device));
     std::vector<char> code;
-    const std::string why = bpm::compile_user_likelihood(g_hiprtc, hip_source, prop.gcnArchName, code);
+    std::string why;
+    { std::lock_guard<std::mutex> lk(g_hiprtc_mu); why = bpm::compile_user_likelihood(g_hiprtc, hip_source, prop.gcnArchName, code); }
     if (!why.empty()) return fail("bpm_set_device_likelihood: " + why);
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
