@@ -889,11 +889,16 @@ def host_callback_config(device, budget_s=4.5):
         pblock = np.concatenate([[c0, a, b], isig])
         STEP = 50
 
+        form = {}
+
         def gen_src(e, t_py):                                         # (`run` counts generations: STEP of them per call here)
+            if not form:
+                fused, why = e.device_likelihood_info()
+                form.update(update_kernel_compiled_around_the_likelihood=bool(fused), why_not=why or None)
             e.step(STEP)
         n0 = len(out)
-        run("cfg2 shape with ln_like_fn given as HIP SOURCE (bipymc_amd.HipLikelihood: compiled at construction into a kernel between the proposal and the "
-            "commit kernel, bpm_step drives the sampler): DREAM gauss d=100 N=8192 steady", gen_src, lambda e: e.set_device_likelihood(src, pblock), budget_s * 0.15,
+        run("cfg2 shape with ln_like_fn given as HIP SOURCE (bipymc_amd.HipLikelihood: the update kernel compiled at construction around the caller's function, "
+            "bpm_step drives the sampler): DREAM gauss d=100 N=8192 steady", gen_src, lambda e: e.set_device_likelihood(src, pblock), budget_s * 0.15,
             dict(pcie=dict(d2h_bytes_per_half_generation=0, h2d_bytes_per_half_generation=0, staging="none"), generations_per_step_call=STEP),
             max_calls=80)                                             # (3 + 80 calls of 50 generations: inside the 6000 reserved history rows)
         if len(out) > n0:                                             # `run` timed step calls of STEP generations each
@@ -902,6 +907,8 @@ def host_callback_config(device, budget_s=4.5):
             ent["value"] *= STEP
             ent["ms_per_step"] /= STEP
             ent["share_of_time_in_the_callback"] = 0.0
+            ent["form"] = dict(form, note="true: ONE launch per half generation (the library's update kernel compiled at run time with the caller's function "
+                                          "as its target); false: proposal / likelihood / commit kernels")
     except Exception as ex:                                           # noqa: BLE001
         out.append(dict(config="cfg2 shape with ln_like_fn given as HIP source", error=str(ex)))
     return out

@@ -94,6 +94,7 @@ SIGNATURES = {
     "bpm_set_device_likelihood": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_double), C.c_int32]),
     "bpm_refresh_device_loglike": (C.c_int, [_H]),
     "bpm_check_device_likelihood": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]),
+    "bpm_get_device_likelihood_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.c_char_p, C.c_int64]),
     "bpm_get_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_get_loglike_history": (C.c_int, [_H, C.c_int64, C.c_int64, _dp]),
     "bpm_reserve_history": (C.c_int, [_H, C.c_int64]),

@@ -19,8 +19,10 @@
 // For an arbitrary host ln_like_fn the same code is split into a propose and a
 // commit kernel (STAGE).
 #pragma once
+#ifndef __HIPCC_RTC__      // (under hiprtc -- user_likelihood.h compiles this header at run time around a caller's likelihood -- both come built in)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "philox.h"
 

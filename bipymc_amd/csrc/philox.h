@@ -12,7 +12,9 @@
 //
 // CPU statement of the same layout: oracle/philox_ref.py (tests only).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #if defined(__HIPCC__)
 #define BPM_HD __host__ __device__ __forceinline__

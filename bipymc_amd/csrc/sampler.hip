@@ -38,6 +38,7 @@
 #endif
 #include "aql_queue.h"
 #include "user_likelihood.h"
+#include "embedded_src.h"
 
 using namespace bpm;
 
@@ -429,8 +430,8 @@ struct bpm_sampler {
     double* cr_p1 = nullptr;          // two generations' worth: generation t writes half t & 1 (cr_p1_cur) -- the update kernel that folds generation t's sums
     double* cr_p1_cur = nullptr;      // (consumer-side fold, below) writes its own level 1 in the same launch
     // Consumer-side fold (round 5): where the update kernels sum level 1 themselves (one GPU, HOT 3 / 4) a generation's fold is NOT dispatched (cr_final_kernel:
-    // one wavefront at the floor of a dependent launch, 4.5 us of cfg2's 20.6 us burn-in generation): it stays pending, and wavefront 0 of every workgroup of
-    // the NEXT generation's first update launch folds the sums itself (PhaseArgs::cr_fold_part: the same device function, the same bits), workgroup 0 stores
+    // one wavefront at the floor of a dependent launch, 4.5 us of cfg2's 20.6 us burn-in generation): it stays pending, and every workgroup of the NEXT
+    // generation's first update launch folds the sums itself (PhaseArgs::cr_fold_part: a wavefront per array of partial sums, the same additions in the same order), workgroup 0 stores
     // the new totals into the other totals block, which the second launch and everything later read.  What cannot consume a pending fold -- the last generation
     // of a bpm_step call, the first steady-state generation, a launch that takes another flavour -- gets cr_final_kernel as before (cr_flush_pending).
     bool cr_pending = false;
@@ -458,6 +459,12 @@ struct bpm_sampler {
     hipModule_t user_mod = nullptr;
     hipFunction_t user_fn = nullptr;
     double* user_params = nullptr;
+    // ... and the update kernel itself compiled around it (user_likelihood.h: compile_user_fused): one launch per half generation; nullptr: the three-kernel form
+    hipModule_t user_fused_mod = nullptr;
+    hipFunction_t user_fused_fn = nullptr;     // the general instantiation
+    hipFunction_t user_fused_hot = nullptr;    // the steady-state one (HOT 2): launched when phase_args_hot(a, dream, false, false) holds
+    unsigned user_fused_block = 0;
+    std::string user_fused_why;              // why the fused form is not in use (bpm_get_device_likelihood_info)
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
     int32_t* trace_i32 = nullptr;      // per-chain decision trace (bpm_set_trace: test variant only; always null in the product library)
@@ -928,7 +935,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (free_buffers) { if (s->xcd_args) (void)hipFree(s->xcd_args); if (s->xcd_ctl) (void)hipFree(s->xcd_ctl); }
 #endif
     for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
-    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_params) (void)hipFree(s->user_params); }
+    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_fused_mod) (void)hipModuleUnload(s->user_fused_mod); if (s->user_params) (void)hipFree(s->user_params); }
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -1667,7 +1674,7 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     }
 #endif
     // a pending fold of the previous generation's CR statistics (bpm_sampler::cr_pending): consumed by this generation's first update launch when that one
-    // takes a flavour that can (one wavefront per chain, in-kernel level 1), else dispatched now, ahead of the update launches
+    // takes a flavour that can (a burn-in flavour that sums level 1 itself: HOT 3 / 4), else dispatched now, ahead of the update launches
     if (s->cr_pending) {
         PhaseArgs& a0 = s->cur_args[0];
         if (s->gen_cr_inkernel && a0.n_items > 0 && a0.cr_part1 != nullptr) {
@@ -2180,10 +2187,30 @@ static bool group_goes_direct(const Group& g, bool push, bool& group_direct) {
 }
 
 static int run_generations_user(bpm_sampler* s, int64_t n_gens);      // (a host-callback sampler with a device likelihood: below, beside the host-callback core)
+// the update kernel compiled at run time around a caller's likelihood (bpm_sampler::user_fused_fn): the general instantiation's launch, from a module
+static thread_local bpm_sampler* g_user_cur = nullptr;
+static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
+    bpm_sampler* s = g_user_cur;
+    if (!s || !s->user_fused_fn) return;
+    PhaseArgs ka = a;
+    ka.tparams = s->user_params;                   // the caller's parameter block is the target's
+    size_t sz = sizeof(ka);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    const unsigned block = s->user_fused_block, cpw = block / (unsigned)s->shape.lpc, grid = (a.n_items + cpw - 1u) / cpw;
+    static const bool no_hot = test_path("nohot");
+    const bool hot = !no_hot && s->user_fused_hot && phase_args_hot(a, s->cfg.algo == BPM_ALGO_DREAM, false, false);
+    (void)hipExtModuleLaunchKernel(hot ? s->user_fused_hot : s->user_fused_fn, grid * block, 1, 1, block, 1, 1, 0, st, nullptr, extra, nullptr, take_stop_event(), 0);
+    ++g_timed_launches; ++g_n_stream;
+}
 static int run_generations(const Group& g, int64_t n_gens) {
     bpm_sampler* s0 = g.h[0];
-    if (s0->cfg.target_id == BPM_TARGET_HOST_CALLBACK && s0->user_fn && g.R == 1) return run_generations_user(s0, n_gens);
-    PhaseLaunch fn = pick_fused(s0);
+    // a caller's likelihood compiled from HIP source (bpm_set_device_likelihood): the update kernel compiled around it runs the ordinary generation loop
+    // (one launch per half generation, on the HIP stream); without it, the proposal / likelihood / commit kernels of run_generations_user
+    const bool user_fused = s0->cfg.target_id == BPM_TARGET_HOST_CALLBACK && s0->user_fused_fn != nullptr && g.R == 1;
+    if (s0->cfg.target_id == BPM_TARGET_HOST_CALLBACK && s0->user_fn && g.R == 1 && !user_fused) return run_generations_user(s0, n_gens);
+    if (user_fused && s0->world > 1 && !s0->comm) return fail("bpm_step: a host-callback sampler of a world needs an RCCL communicator (create it with a unique id)");
+    g_user_cur = user_fused ? s0 : nullptr;
+    PhaseLaunch fn = user_fused ? launch_user_fused : pick_fused(s0);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit (or give it a device likelihood: bpm_set_device_likelihood)");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
     int64_t done = 0;
@@ -2211,7 +2238,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // stay on the stream altogether.
             // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
             bool group_direct = false;
-            const bool direct = group_goes_direct(g, push, group_direct);
+            const bool direct = group_goes_direct(g, push, group_direct) && !user_fused;      // (a run-time module's kernel is launched on the stream)
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (direct && !s->dq_active) {
@@ -3016,6 +3043,8 @@ static int user_refresh_ll(bpm_sampler* s) {
     return 0;
 }
 static int run_generations_user(bpm_sampler* s, int64_t n_gens) {
+    // (a rank of a world exchanges through its RCCL communicator like the host transports do: allgather_state in commit_finish)
+    if (s->world > 1 && !s->comm) return fail("bpm_step: a host-callback sampler of a world needs an RCCL communicator (create it with a unique id)");
     const int halves = s->cfg.algo == BPM_ALGO_DEMC_SYNC ? 1 : 2;
     for (int64_t g = 0; g < n_gens; ++g) {
         for (int h = 0; h < halves; ++h) {
@@ -3076,7 +3105,66 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
     CK(dev_alloc(&s->user_params, (size_t)std::max(n_params, 1)));
     HIPCK(hipMemsetAsync(s->user_params, 0, (size_t)std::max(n_params, 1) * sizeof(double), s->stream));
     if (n_params > 0) HIPCK(hipMemcpyAsync(s->user_params, params, (size_t)n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    return user_refresh_ll(s);
+    CK(user_refresh_ll(s));
+    // the faster form: the update kernel itself compiled around the likelihood.  Whatever goes wrong here leaves the three-kernel form in place
+    // (bpm_get_device_likelihood_info says which is in use and why).  BPM_USER_FUSED=0: not attempted (A/B, tests).
+    if (s->user_fused_mod) { (void)hipModuleUnload(s->user_fused_mod); s->user_fused_mod = nullptr; }
+    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_why.clear();
+    const bool want_fused = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 0);      // (read at every call: a test switches it)
+    if (!want_fused) { s->user_fused_why = "BPM_USER_FUSED=0"; return 0; }
+    if (s->shape.idx == SHAPE_WIDE) { s->user_fused_why = "rows wider than 512 coordinates run on the looped kernel, which has no run-time form"; return 0; }
+    {
+        const int algo = s->cfg.algo == BPM_ALGO_DREAM ? ALGO_DREAM : ALGO_DEMC;
+        const int np = s->cfg.algo != BPM_ALGO_DREAM ? 1 : (s->cfg.del_pairs == 3 ? 3 : 0);
+#ifdef BPM_TEST_HOOKS
+        const bool hooks = true;
+#else
+        const bool hooks = false;
+#endif
+        std::vector<char> fcode;
+        std::string lowered[2], fwhy;
+        { std::lock_guard<std::mutex> lk(g_hiprtc_mu);
+          fwhy = bpm::compile_user_fused(g_hiprtc, hip_source, prop.gcnArchName, bpm_src_kernels_h, bpm_src_philox_h, algo, s->shape.lpc, s->shape.dpl, np, s->dim, hooks, fcode, lowered); }
+        if (!fwhy.empty()) { s->user_fused_why = fwhy; return 0; }
+        hipModule_t fm = nullptr;
+        hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr;
+        if (hipModuleLoadData(&fm, fcode.data()) != hipSuccess) { (void)hipGetLastError(); s->user_fused_why = "hipModuleLoadData failed"; return 0; }
+        if (hipModuleGetFunction(&ff, fm, lowered[0].c_str()) != hipSuccess || hipModuleGetFunction(&fh, fm, lowered[1].c_str()) != hipSuccess ||
+            hipModuleGetFunction(&fs, fm, "bpm_user_sizeof") != hipSuccess || !ff || !fh || !fs) {
+            (void)hipGetLastError(); (void)hipModuleUnload(fm);
+            s->user_fused_why = "the compiled module lacks " + lowered[0];
+            return 0;
+        }
+        // the module's view of the argument block must be this library's
+        unsigned int* d_out = nullptr;
+        unsigned int h_out[2] = {0u, 0u};
+        if (dev_alloc(&d_out, 2) != 0) { (void)hipModuleUnload(fm); s->user_fused_why = "out of device memory"; return 0; }
+        void* sargs[] = {(void*)&d_out};
+        const bool ran = hipModuleLaunchKernel(fs, 1, 1, 1, 1, 1, 1, 0, s->stream, sargs, nullptr) == hipSuccess &&
+                         hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, s->stream) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
+        (void)hipFree(d_out);
+        if (!ran || h_out[0] != (unsigned)sizeof(PhaseArgs) || h_out[1] != (unsigned)block_for(s->shape.lpc)) {
+            (void)hipGetLastError(); (void)hipModuleUnload(fm);
+            s->user_fused_why = "the module's argument block differs from the library's (" + std::to_string(h_out[0]) + " against " + std::to_string(sizeof(PhaseArgs)) + " bytes)";
+            return 0;
+        }
+        s->user_fused_mod = fm; s->user_fused_fn = ff; s->user_fused_hot = fh; s->user_fused_block = h_out[1];
+    }
+    return 0;
+}
+
+// which form of the device likelihood runs: *fused = 1 the update kernel compiled around it (one launch per half generation), 0 the three-kernel form
+// (then `why`, if given, says why: up to why_cap - 1 characters); error when no device likelihood is installed
+extern "C" int bpm_get_device_likelihood_info(bpm_handle_t s, int32_t* fused, char* why, int64_t why_cap) {
+    CK(check_handle(s));
+    if (!s->user_fn) return fail("bpm_get_device_likelihood_info: no device likelihood installed (bpm_set_device_likelihood)");
+    if (fused) *fused = s->user_fused_fn ? 1 : 0;
+    if (why && why_cap > 0) {
+        const size_t n = std::min(s->user_fused_why.size(), (size_t)why_cap - 1);
+        std::memcpy(why, s->user_fused_why.data(), n);
+        why[n] = '\0';
+    }
+    return 0;
 }
 
 extern "C" int bpm_refresh_device_loglike(bpm_handle_t s) {

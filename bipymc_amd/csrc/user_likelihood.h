@@ -26,6 +26,8 @@ struct Hiprtc {
     int (*GetCodeSize)(void*, size_t*) = nullptr;
     int (*GetCode)(void*, char*) = nullptr;
     int (*DestroyProgram)(void**) = nullptr;
+    int (*AddNameExpression)(void*, const char*) = nullptr;
+    int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
 };
 
 // -> "" or the reason hiprtc cannot be used
@@ -42,7 +44,7 @@ inline std::string load_hiprtc(Hiprtc& h) {
     h.f = reinterpret_cast<decltype(h.f)>(dlsym(lib, "hiprtc" #f));                 \
     if (!h.f) return "hiprtc symbol hiprtc" #f " missing";
     BPM_RTC_SYM(CreateProgram) BPM_RTC_SYM(CompileProgram) BPM_RTC_SYM(GetProgramLogSize) BPM_RTC_SYM(GetProgramLog)
-    BPM_RTC_SYM(GetCodeSize) BPM_RTC_SYM(GetCode) BPM_RTC_SYM(DestroyProgram)
+    BPM_RTC_SYM(GetCodeSize) BPM_RTC_SYM(GetCode) BPM_RTC_SYM(DestroyProgram) BPM_RTC_SYM(AddNameExpression) BPM_RTC_SYM(GetLoweredName)
 #undef BPM_RTC_SYM
     h.lib = lib;
     return "";
@@ -122,6 +124,103 @@ inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_sr
     if (rc != 0) {
         h.DestroyProgram(&prog);
         return "the likelihood source does not compile (it must define `__device__ double ln_like(const double* x, int d, const double* p)`):\n" + log;
+    }
+    size_t sz = 0;
+    if (h.GetCodeSize(prog, &sz) != 0 || sz == 0) { h.DestroyProgram(&prog); return "hiprtcGetCodeSize failed"; }
+    code.resize(sz);
+    const int rg = h.GetCode(prog, code.data());
+    h.DestroyProgram(&prog);
+    if (rg != 0) return "hiprtcGetCode failed";
+    return "";
+}
+
+// ---- the caller's likelihood INSIDE the update kernel ---------------------------------------------------------------------------------------------
+// The second, faster form: the library's own update kernel (kernels.h: phase_fused_kernel, the general instantiation) compiled at run time with the
+// caller's function as its target -- one launch per half generation instead of three.  Target<TARGET_USER>::eval: the lanes of a chain put their
+// coordinates of the row into LDS, the chain's first lane calls ln_like on it, the value goes back to the chain's lanes.  kernels.h / philox.h travel
+// inside the library as string literals (embedded_src.h, written by the Makefile).  The kernel-argument block must be the library's own: the program
+// is compiled with the library's BPM_TEST_HOOKS setting and exports sizeof(PhaseArgs) for the caller to compare.
+// Two instantiations: the general one (HOT 0) and the steady-state one without update records (HOT 2: what phase_args_hot(a, dream, false, false) fixes is
+// a compile-time constant) -- name_expr[0 / 1].
+inline std::string user_fused_program(const std::string& user_src, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, std::string name_expr[2]) {
+    std::string s;
+    s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
+         "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t;\n"
+         "#ifndef INFINITY\n#define INFINITY (__builtin_huge_val())\n#endif\n#ifndef NAN\n#define NAN (__builtin_nan(\"\"))\n#endif\n"
+         "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n"
+         "#define BPM_VARIANT_NS v_user\n";
+    if (test_hooks) s += "#define BPM_TEST_HOOKS 1\n";
+    s += "#define BPM_USER_LDP " + std::to_string((int)(dim | 1u)) + "\n";
+    s += "#define BPM_USER_DIM " + std::to_string((int)dim) + "\n";      // (the caller's loops over d get a compile-time trip count: the sampler's dimension is fixed)
+    s += "#include \"kernels.h\"\n#line 1 \"ln_like.hip\"\n" + user_src + "\n";
+    s += "namespace bpm { inline namespace BPM_VARIANT_NS {\n"
+         "constexpr int TARGET_USER = 64;\n"
+         "template <int LPC, int DPL>\n"
+         "struct Target<TARGET_USER, LPC, DPL> {\n"
+         "    struct Consts { const double* tp; };\n"
+         "    static __device__ __forceinline__ Consts load(int, uint32_t, const double* tp) { Consts k; k.tp = tp; return k; }\n"
+         "    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const Consts& k) {\n"
+         "        if (LPC == 1) return (double)::ln_like(v, BPM_USER_DIM, k.tp);      // (a lane is a chain: the row is the lane's registers)\n"
+         "        __shared__ double rows[(block_for(LPC) / LPC) * BPM_USER_LDP];\n"
+         "        const int cw = (int)threadIdx.x / LPC;\n"
+         "        double* row = rows + cw * BPM_USER_LDP;\n"
+         "#pragma unroll\n"
+         "        for (int s = 0; s < DPL; ++s) {\n"
+         "            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (uint32_t)(s & 1);\n"
+         "            if (j < dim) row[j] = v[s];\n"
+         "        }\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
+         "        __builtin_amdgcn_wave_barrier();\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n"
+         "        double r = 0.0;\n"
+         "        if (q == 0) r = (double)::ln_like(row, BPM_USER_DIM, k.tp);\n"
+         "        if (LPC == WAVE) r = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(r)), __builtin_amdgcn_readfirstlane(__double2loint(r)));\n"
+         "        else if (LPC > 1) r = __shfl(r, (((int)threadIdx.x & (WAVE - 1)) / LPC) * LPC);\n"
+         "        __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
+         "        __builtin_amdgcn_wave_barrier();\n"
+         "        return r;\n"
+         "    }\n"
+         "};\n";
+    for (int k = 0; k < 2; ++k) {
+        const std::string inst = "phase_fused_kernel<" + std::to_string(algo) + ", TARGET_USER, " + std::to_string(lpc) + ", " + std::to_string(dpl) + ", " +
+                                 std::to_string(np) + ", " + (k == 0 ? "0" : "2") + ">";
+        s += "template __global__ void " + inst + "(const PhaseArgs);\n";
+        name_expr[k] = "bpm::" + inst;
+        name_expr[k].replace(name_expr[k].find("TARGET_USER"), 11, "bpm::TARGET_USER");
+    }
+    s += "extern \"C\" __global__ void bpm_user_sizeof(unsigned int* out) { out[0] = (unsigned int)sizeof(PhaseArgs); out[1] = (unsigned int)block_for(" +
+         std::to_string(lpc) + "); }\n"
+         "}}\n";
+    return s;
+}
+// -> "" with `code` and the kernel's lowered (mangled) name, or the reason
+inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, const std::string& arch, const char* kernels_h, const char* philox_h,
+                                      int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, std::vector<char>& code, std::string lowered[2]) {
+    const std::string why = load_hiprtc(h);
+    if (!why.empty()) return why;
+    std::string expr[2];
+    const std::string src = user_fused_program(user_src, algo, lpc, dpl, np, dim, test_hooks, expr);
+    const char* hdr_src[] = {kernels_h, philox_h};
+    const char* hdr_names[] = {"kernels.h", "philox.h"};
+    void* prog = nullptr;
+    if (h.CreateProgram(&prog, src.c_str(), "bpm_user_fused.hip", 2, hdr_src, hdr_names) != 0 || !prog) return "hiprtcCreateProgram failed";
+    for (int k = 0; k < 2; ++k)
+        if (h.AddNameExpression(prog, expr[k].c_str()) != 0) { h.DestroyProgram(&prog); return "hiprtcAddNameExpression failed"; }
+    const std::string a = "--offload-arch=" + arch;
+    const char* opts[] = {a.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function"};
+    const int rc = h.CompileProgram(prog, 5, opts);
+    std::string log;
+    size_t n = 0;
+    if (h.GetProgramLogSize(prog, &n) == 0 && n > 1) {
+        log.resize(n);
+        if (h.GetProgramLog(prog, &log[0]) != 0) log.clear();
+        while (!log.empty() && (log.back() == '\0' || log.back() == '\n')) log.pop_back();
+    }
+    if (rc != 0) { h.DestroyProgram(&prog); return "the update kernel does not compile around this likelihood:\n" + log; }
+    for (int k = 0; k < 2; ++k) {
+        const char* low = nullptr;
+        if (h.GetLoweredName(prog, expr[k].c_str(), &low) != 0 || !low) { h.DestroyProgram(&prog); return "hiprtcGetLoweredName failed for " + expr[k]; }
+        lowered[k] = low;
     }
     size_t sz = 0;
     if (h.GetCodeSize(prog, &sz) != 0 || sz == 0) { h.DestroyProgram(&prog); return "hiprtcGetCodeSize failed"; }

@@ -2,8 +2,8 @@
 
 The reference takes any Python callable as ln_like_fn (bipymc/samplers.py:36-43) and evaluates it row by row on the host; here that path is the
 host callback (7-9e6 chain-updates/s at 8192 chains x 100 dimensions) or a device-resident framework callback (vectorized="device", 3e7).  A
-likelihood written as a few lines of HIP C runs INSIDE the generation loop instead -- compiled at construction with hiprtc into one kernel between the
-library's proposal and commit kernels (include/bipymc_hip.h: bpm_set_device_likelihood), no host code per generation:
+likelihood written as a few lines of HIP C runs INSIDE the update kernel instead -- the library compiles its own update kernel around the function at
+construction (hiprtc, about two seconds; include/bipymc_hip.h: bpm_set_device_likelihood), no host code per generation, 4e8 at that shape:
 
     ll = HipLikelihood('''
         __device__ double ln_like(const double* x, int d, const double* p) {      // p: the parameter block below (what ln_kwargs is to a callable)

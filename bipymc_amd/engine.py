@@ -303,6 +303,14 @@ class HipEngine(object):
         self._ck(self.lib.bpm_set_device_likelihood(self._h, src, p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None, int(p.size)))
         self.has_device_likelihood = True
 
+    def device_likelihood_info(self):
+        """-> (fused, why): fused True -- the update kernel itself was compiled around the likelihood (one launch per half generation); False -- the
+        proposal / likelihood / commit kernels run, `why` says why the fused form is not in use"""
+        fused = C.c_int32(0)
+        why = C.create_string_buffer(1 << 14)
+        self._ck(self.lib.bpm_get_device_likelihood_info(self._h, C.byref(fused), why, len(why)))
+        return bool(fused.value), why.value.decode(errors="replace")
+
     def refresh_device_loglike(self):
         self._ck(self.lib.bpm_refresh_device_loglike(self._h))
 

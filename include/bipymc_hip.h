@@ -264,6 +264,11 @@ int bpm_set_loglike_device(bpm_handle_t h, const double* ll_dev);
 int bpm_set_device_likelihood(bpm_handle_t h, const char* hip_source, const double* params, int32_t n_params);
 int bpm_refresh_device_loglike(bpm_handle_t h);
 int bpm_check_device_likelihood(const char* hip_source, const char* arch, char* log, int64_t log_cap);
+/* bpm_set_device_likelihood also compiles the UPDATE KERNEL ITSELF around the caller's function (the library carries its kernel source; rows of up to
+ * 512 coordinates): bpm_step then needs one launch per half generation instead of three (proposal / likelihood / commit).  Whatever fails on that way
+ * leaves the three-kernel form in use: *fused says which runs, `why` (up to why_cap - 1 characters, may be NULL) why not the fused one.
+ * Environment: BPM_USER_FUSED=0 does not attempt it. */
+int bpm_get_device_likelihood_info(bpm_handle_t h, int32_t* fused, char* why, int64_t why_cap);
 
 /* history of this rank's chains: out[(g - g_lo) * n_local * dim + i * dim + j], g in [g_lo, g_hi) */
 int bpm_get_history(bpm_handle_t h, int64_t g_lo, int64_t g_hi, double* out);

@@ -251,6 +251,7 @@ def test_hip_source_likelihood_through_the_sampler_classes(tmp_path):
         a = cls(ll, mu, varepsilon=1e-3, n_chains=512, seed=21, **kw)
         b = cls(np_ll, mu, varepsilon=1e-3, n_chains=512, seed=21, vectorized=True, **kw)
         assert a._hip_likelihood is ll and not a.uses_device_target and b._hip_likelihood is None
+        assert a._engine.device_likelihood_info()[0], a._engine.device_likelihood_info()[1]      # the update kernel itself was compiled around the likelihood
         a.run_mcmc(512 * 301)
         b.run_mcmc(512 * 301)
         assert a.local_n_accepted == b.local_n_accepted and a.local_n_rejected == b.local_n_rejected

@@ -638,17 +638,23 @@ __device__ double ln_like(const double* x, int d, const double* p) {      // p =
 """
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("algo,d,N,kw", [
     (R.ALGO_DREAM, 10, 16, dict(burnin_gen=6, n_cr_gen=2)),
     (R.ALGO_DREAM, 100, 64, dict(burnin_gen=5, n_cr_gen=1)),
+    (R.ALGO_DREAM, 100, 1000, dict(burnin_gen=3, n_cr_gen=1)),
     (R.ALGO_DREAM, 7, 501, dict(burnin_gen=0, del_pairs=2)),
+    (R.ALGO_DREAM, 30, 77, dict(burnin_gen=4, n_cr_gen=2, del_pairs=1)),
     (R.ALGO_DEMC, 2, 24, dict(p_snooker=0.3)),
+    (R.ALGO_DEMC, 2, 3000, dict()),
+    (R.ALGO_DEMC, 150, 40, dict(p_snooker=0.2)),
     (R.ALGO_DEMC_SYNC, 3, 10, dict()),
     (R.ALGO_DREAM, 600, 12, dict(burnin_gen=5, n_cr_gen=1)),
 ])
-def test_hip_source_likelihood_against_oracle(algo, d, N, kw):
+def test_hip_source_likelihood_against_oracle(algo, d, N, kw, fused, monkeypatch):
     """Round 5: the caller's likelihood written as HIP source, compiled with hiprtc into a kernel between the proposal and the commit kernel, the
-    sampler driven by bpm_step (no host code inside a generation) -- against OracleSampler(ll_fn = the same formula in NumPy): accept counts equal,
+    sampler driven by bpm_step (no host code inside a generation) -- in both forms: the update kernel itself compiled around the likelihood (fused: one
+    launch per half generation) and the proposal / likelihood / commit kernels -- against OracleSampler(ll_fn = the same formula in NumPy): accept counts equal,
     state / ln-like / whole history to 1e-11 (the summation order of the two formulas differs), CR statistics to 1e-9.  Several step calls, a state
     rewritten from the host in between (bpm_refresh_device_loglike)."""
     params = _gauss_params(d, rho=0.4)
@@ -666,7 +672,11 @@ def test_hip_source_likelihood_against_oracle(algo, d, N, kw):
         eng.step(1)                                     # (a host-callback sampler without a device likelihood cannot be stepped)
     with pytest.raises(Exception, match="does not compile"):
         eng.set_device_likelihood("__device__ double ln_like(const double* x) { return x[0] }")
+    monkeypatch.setenv("BPM_USER_FUSED", "1" if fused else "0")
     eng.set_device_likelihood(GAUSS_EQUICORR_HIP, params)
+    is_fused, why = eng.device_likelihood_info()
+    # fused: the update kernel itself compiled around the likelihood (one launch per half generation); else proposal / likelihood / commit kernels
+    assert is_fused == (fused and d <= 512), why
     np.testing.assert_allclose(eng.get_loglike(), [py_ll(x) for x in X0], rtol=1e-12, atol=1e-12)
     ora.set_state(X0)
     eng.begin_run()
