@@ -108,6 +108,23 @@ class DirectQueue {
         return slot.object ? &slot : nullptr;
     }
 
+    // ... and a kernel of a module loaded at run time (hipModuleLoadData: a caller's likelihood compiled by hiprtc, user_likelihood.h), by its lowered name;
+    // the name must be unique among the process's code objects (the module's device code lives in a namespace of its own)
+    const DqKernel* kernel_by_name(const std::string& lowered) {
+        std::lock_guard<std::recursive_mutex> lk(mu_);
+        auto it = named_.find(lowered);
+        if (it != named_.end()) return it->second.object ? &it->second : nullptr;
+        DqKernel k;
+        k.name = lowered;
+        Lookup lkp{this, lowered + ".kd", &k, false};
+        (void)loader_.hsa_ven_amd_loader_iterate_executables(&DirectQueue::exe_cb, &lkp);
+        if (!lkp.found) k.object = 0;
+        auto& slot = named_[lowered];
+        slot = k;
+        return slot.object ? &slot : nullptr;
+    }
+    void forget_named(const std::string& lowered) { std::lock_guard<std::recursive_mutex> lk(mu_); named_.erase(lowered); }      // (its module is being unloaded)
+
     // One dispatch.  `args` = the explicit kernel arguments laid out as the kernel's kernarg segment has them (natural
     // alignment), `nbytes` their size; the hidden arguments a kernel that asks for blockDim / gridDim reads are appended here.
     // fence: ACQUIRE | RELEASE at agent scope (what a HIP stream puts around every kernel).  sig: 0 / 1 = this dispatch
@@ -439,6 +456,7 @@ class DirectQueue {
     std::string why_;
     std::recursive_mutex mu_;
     std::map<const void*, DqKernel> kernels_;
+    std::map<std::string, DqKernel> named_;      // kernels of run-time modules, by lowered name (kernel_by_name)
     DqKernel fence_kernel_;
     bool unreleased_ = false;
     bool in_drain_ = false;

@@ -464,6 +464,8 @@ struct bpm_sampler {
     hipFunction_t user_fused_fn = nullptr;     // the general instantiation
     hipFunction_t user_fused_hot = nullptr;    // the steady-state one (HOT 2): launched when phase_args_hot(a, dream, false, false) holds
     unsigned user_fused_block = 0;
+    std::string user_fused_names[2];         // their lowered names: what the library's own queue dispatches them by (DirectQueue::kernel_by_name)
+    bool user_fused_dq = false;              // ... and both were found among the loaded code objects
     std::string user_fused_why;              // why the fused form is not in use (bpm_get_device_likelihood_info)
     double* aux_buf = nullptr;
     int32_t* ids_buf = nullptr;
@@ -935,7 +937,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (free_buffers) { if (s->xcd_args) (void)hipFree(s->xcd_args); if (s->xcd_ctl) (void)hipFree(s->xcd_ctl); }
 #endif
     for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
-    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_fused_mod) (void)hipModuleUnload(s->user_fused_mod); if (s->user_params) (void)hipFree(s->user_params); }
+    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_fused_mod) { if (s->dq) { s->dq->forget_named(s->user_fused_names[0]); s->dq->forget_named(s->user_fused_names[1]); } (void)hipModuleUnload(s->user_fused_mod); } if (s->user_params) (void)hipFree(s->user_params); }
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -1045,7 +1047,8 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // profiles/r02_table_build_modes.txt; removed in round 3.)
     // the library's own AQL queue for the steady state of a single-GPU sampler (aql_queue.h); without it (no large BAR, a runtime
     // without the loader extension, BPM_DIRECT_QUEUE=0) the same kernels are launched on the stream
-    if (cfg->target_id != BPM_TARGET_HOST_CALLBACK) {
+    // (a host-callback sampler uses it once it has been given a likelihood as HIP source: the update kernel compiled around it, bpm_set_device_likelihood)
+    {
         s->dq = bpm::DirectQueue::for_device(cfg->device);
         if (s->dq && s->dq->failed()) s->dq = nullptr;       // (a queue that failed earlier in this process is not adopted: HIP stream launches)
         if (s->dq && !s->dq->kernel(reinterpret_cast<const void*>(perm_table_kernel))) s->dq = nullptr;      // (HIP's copy of the code object not found)
@@ -1171,11 +1174,13 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     const uint32_t plan_max_local = test_path("planall") ? 0xFFFFFFFFu : 16384u;
     s->win_K = PERM_CHUNK;
     s->plan_on = !no_plan && s->shape.idx == 3 && s->n_local <= plan_max_local &&
-                 (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) && tid != BPM_TARGET_HOST_CALLBACK;
+                 (cfg->algo == BPM_ALGO_DREAM ? cfg->del_pairs <= 5 : cfg->algo == BPM_ALGO_DEMC) &&
+                 // (a single-rank host-callback sampler too: the update kernel compiled around a likelihood given as HIP source reads them, bpm_set_device_likelihood)
+                 (tid != BPM_TARGET_HOST_CALLBACK || s->world == 1);
     if (s->plan_on) {
         const size_t per_gen = (size_t)s->N * PLAN_WORDS * sizeof(uint32_t);
         s->win_K = (int)std::max<size_t>(1, std::min<size_t>((size_t)s->win_K, ((size_t)512 << 20) / per_gen));
-        s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG;
+        s->sorted_on = s->world > 1 && s->world <= (uint32_t)MAX_SEG && tid != BPM_TARGET_HOST_CALLBACK;
     }
     for (auto& B : s->tb) {
         CKD(dev_alloc(&B.perm, (size_t)s->win_K * s->N));
@@ -2198,7 +2203,18 @@ static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     const unsigned block = s->user_fused_block, cpw = block / (unsigned)s->shape.lpc, grid = (a.n_items + cpw - 1u) / cpw;
     static const bool no_hot = test_path("nohot");
-    const bool hot = !no_hot && s->user_fused_hot && phase_args_hot(a, s->cfg.algo == BPM_ALGO_DREAM, false, false);
+    // (the steady-state instantiation was compiled for update records exactly when this sampler builds them: HOT 1 / HOT 2)
+    const bool hot = !no_hot && s->user_fused_hot && (a.rec_tab != nullptr) == s->plan_on && phase_args_hot(a, s->cfg.algo == BPM_ALGO_DREAM, a.rec_tab != nullptr, false);
+    if (g_dq) {      // the library's own queue (launch_packed's packet: the module's kernels take the argument block alone, no preloaded leading arguments)
+        const bpm::DqKernel* k = g_dq->kernel_by_name(s->user_fused_names[hot ? 1 : 0]);
+        const int sig = g_dq_sig; g_dq_sig = -1;
+        int fence = g_dq_update_fence;
+        if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
+        if (g_dq_release_this) { fence |= bpm::DirectQueue::RELEASE; g_dq_release_this = false; }
+        if (!k || g_dq->launch(*k, grid, 1, block, &ka, sizeof(ka), fence, sig) != 0) g_dq_error = true;
+        ++g_timed_launches; ++g_n_direct;
+        return;
+    }
     (void)hipExtModuleLaunchKernel(hot ? s->user_fused_hot : s->user_fused_fn, grid * block, 1, 1, block, 1, 1, 0, st, nullptr, extra, nullptr, take_stop_event(), 0);
     ++g_timed_launches; ++g_n_stream;
 }
@@ -2238,7 +2254,8 @@ static int run_generations(const Group& g, int64_t n_gens) {
             // stay on the stream altogether.
             // With the push exchange a rank of a world runs on its own queue too: nothing of its generation loop is a collective call.
             bool group_direct = false;
-            const bool direct = group_goes_direct(g, push, group_direct) && !user_fused;      // (a run-time module's kernel is launched on the stream)
+            // (a run-time module's kernels go through the library's queue when it found them by name, else on the stream)
+            const bool direct = group_goes_direct(g, push, group_direct) && (!user_fused || s0->user_fused_dq);
             for (int r = 0; r < g.R; ++r) {
                 bpm_sampler* s = g.h[r];
                 if (direct && !s->dq_active) {
@@ -3108,8 +3125,11 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
     CK(user_refresh_ll(s));
     // the faster form: the update kernel itself compiled around the likelihood.  Whatever goes wrong here leaves the three-kernel form in place
     // (bpm_get_device_likelihood_info says which is in use and why).  BPM_USER_FUSED=0: not attempted (A/B, tests).
-    if (s->user_fused_mod) { (void)hipModuleUnload(s->user_fused_mod); s->user_fused_mod = nullptr; }
-    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_why.clear();
+    if (s->user_fused_mod) {
+        if (s->dq) { s->dq->forget_named(s->user_fused_names[0]); s->dq->forget_named(s->user_fused_names[1]); }
+        (void)hipModuleUnload(s->user_fused_mod); s->user_fused_mod = nullptr;
+    }
+    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_dq = false; s->user_fused_why.clear();
     const bool want_fused = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 0);      // (read at every call: a test switches it)
     if (!want_fused) { s->user_fused_why = "BPM_USER_FUSED=0"; return 0; }
     if (s->shape.idx == SHAPE_WIDE) { s->user_fused_why = "rows wider than 512 coordinates run on the looped kernel, which has no run-time form"; return 0; }
@@ -3122,9 +3142,12 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         const bool hooks = false;
 #endif
         std::vector<char> fcode;
-        std::string lowered[2], fwhy;
+        std::string lowered[2], fwhy, ns;
         { std::lock_guard<std::mutex> lk(g_hiprtc_mu);
-          fwhy = bpm::compile_user_fused(g_hiprtc, hip_source, prop.gcnArchName, bpm_src_kernels_h, bpm_src_philox_h, algo, s->shape.lpc, s->shape.dpl, np, s->dim, hooks, fcode, lowered); }
+          static std::atomic<int> module_no{0};
+          ns = "v_user" + std::to_string(module_no.fetch_add(1));
+          fwhy = bpm::compile_user_fused(g_hiprtc, hip_source, ns, prop.gcnArchName, bpm_src_kernels_h, bpm_src_philox_h, algo, s->shape.lpc, s->shape.dpl, np, s->dim, hooks,
+                                         s->plan_on ? 1 : 2, fcode, lowered); }
         if (!fwhy.empty()) { s->user_fused_why = fwhy; return 0; }
         hipModule_t fm = nullptr;
         hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr;
@@ -3149,6 +3172,9 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
             return 0;
         }
         s->user_fused_mod = fm; s->user_fused_fn = ff; s->user_fused_hot = fh; s->user_fused_block = h_out[1];
+        s->user_fused_names[0] = lowered[0]; s->user_fused_names[1] = lowered[1];
+        static const bool dq_wanted = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 2);      // (2: fused, but launched on the stream -- A/B)
+        s->user_fused_dq = dq_wanted && s->dq && s->dq->kernel_by_name(lowered[0]) != nullptr && s->dq->kernel_by_name(lowered[1]) != nullptr;
     }
     return 0;
 }

@@ -140,15 +140,17 @@ inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_sr
 // coordinates of the row into LDS, the chain's first lane calls ln_like on it, the value goes back to the chain's lanes.  kernels.h / philox.h travel
 // inside the library as string literals (embedded_src.h, written by the Makefile).  The kernel-argument block must be the library's own: the program
 // is compiled with the library's BPM_TEST_HOOKS setting and exports sizeof(PhaseArgs) for the caller to compare.
-// Two instantiations: the general one (HOT 0) and the steady-state one without update records (HOT 2: what phase_args_hot(a, dream, false, false) fixes is
-// a compile-time constant) -- name_expr[0 / 1].
-inline std::string user_fused_program(const std::string& user_src, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, std::string name_expr[2]) {
+// Two instantiations: the general one (HOT 0) and the steady-state one (`hot`: 1 with update records, 2 without -- what phase_args_hot(a, dream, with_plan,
+// false) fixes is a compile-time constant) -- name_expr[0 / 1].
+// `ns`: the inline namespace the program's device code lives in -- unique per module of the process: the library's queue finds kernels by name.
+inline std::string user_fused_program(const std::string& user_src, const std::string& ns, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks,
+                                      int hot, std::string name_expr[2]) {
     std::string s;
     s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
          "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t;\n"
          "#ifndef INFINITY\n#define INFINITY (__builtin_huge_val())\n#endif\n#ifndef NAN\n#define NAN (__builtin_nan(\"\"))\n#endif\n"
          "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n"
-         "#define BPM_VARIANT_NS v_user\n";
+         "#define BPM_VARIANT_NS " + ns + "\n";
     if (test_hooks) s += "#define BPM_TEST_HOOKS 1\n";
     s += "#define BPM_USER_LDP " + std::to_string((int)(dim | 1u)) + "\n";
     s += "#define BPM_USER_DIM " + std::to_string((int)dim) + "\n";      // (the caller's loops over d get a compile-time trip count: the sampler's dimension is fixed)
@@ -183,7 +185,7 @@ inline std::string user_fused_program(const std::string& user_src, int algo, int
          "};\n";
     for (int k = 0; k < 2; ++k) {
         const std::string inst = "phase_fused_kernel<" + std::to_string(algo) + ", TARGET_USER, " + std::to_string(lpc) + ", " + std::to_string(dpl) + ", " +
-                                 std::to_string(np) + ", " + (k == 0 ? "0" : "2") + ">";
+                                 std::to_string(np) + ", " + (k == 0 ? "0" : std::to_string(hot)) + ">";
         s += "template __global__ void " + inst + "(const PhaseArgs);\n";
         name_expr[k] = "bpm::" + inst;
         name_expr[k].replace(name_expr[k].find("TARGET_USER"), 11, "bpm::TARGET_USER");
@@ -194,12 +196,12 @@ inline std::string user_fused_program(const std::string& user_src, int algo, int
     return s;
 }
 // -> "" with `code` and the kernel's lowered (mangled) name, or the reason
-inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, const std::string& arch, const char* kernels_h, const char* philox_h,
-                                      int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, std::vector<char>& code, std::string lowered[2]) {
+inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, const std::string& ns, const std::string& arch, const char* kernels_h,
+                                      const char* philox_h, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, int hot, std::vector<char>& code, std::string lowered[2]) {
     const std::string why = load_hiprtc(h);
     if (!why.empty()) return why;
     std::string expr[2];
-    const std::string src = user_fused_program(user_src, algo, lpc, dpl, np, dim, test_hooks, expr);
+    const std::string src = user_fused_program(user_src, ns, algo, lpc, dpl, np, dim, test_hooks, hot, expr);
     const char* hdr_src[] = {kernels_h, philox_h};
     const char* hdr_names[] = {"kernels.h", "philox.h"};
     void* prog = nullptr;

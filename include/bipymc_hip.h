@@ -267,7 +267,8 @@ int bpm_check_device_likelihood(const char* hip_source, const char* arch, char* 
 /* bpm_set_device_likelihood also compiles the UPDATE KERNEL ITSELF around the caller's function (the library carries its kernel source; rows of up to
  * 512 coordinates): bpm_step then needs one launch per half generation instead of three (proposal / likelihood / commit).  Whatever fails on that way
  * leaves the three-kernel form in use: *fused says which runs, `why` (up to why_cap - 1 characters, may be NULL) why not the fused one.
- * Environment: BPM_USER_FUSED=0 does not attempt it. */
+ * The module's kernels are dispatched like the library's own (its AQL queue finds them by name).  Environment: BPM_USER_FUSED=0 does not attempt the
+ * fused form, =2 launches it on the HIP stream (A/B). */
 int bpm_get_device_likelihood_info(bpm_handle_t h, int32_t* fused, char* why, int64_t why_cap);
 
 /* history of this rank's chains: out[(g - g_lo) * n_local * dim + i * dim + j], g in [g_lo, g_hi) */

@@ -17,5 +17,5 @@ e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALL
 e.set_state(X0); e.set_device_likelihood(src, np.concatenate([[c0, a, b], 1 / sig])); e.reserve_history(1000); e.begin_run()
 e.step(50); e.synchronize()
 t0 = time.perf_counter(); e.step(300); e.synchronize(); el = time.perf_counter() - t0
-print("us per generation %.2f  updates/s %.3g" % (el / 300 * 1e6, N * 300 / el))
+print("us per generation %.2f  updates/s %.3g" % (el / 300 * 1e6, N * 300 / el), e.device_likelihood_info(), e.launch_stats())
 e.close()
