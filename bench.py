@@ -896,19 +896,27 @@ def host_callback_config(device, budget_s=4.5):
                 fused, why = e.device_likelihood_info()
                 form.update(update_kernel_compiled_around_the_likelihood=bool(fused), why_not=why or None)
             e.step(STEP)
-        n0 = len(out)
-        run("cfg2 shape with ln_like_fn given as HIP SOURCE (bipymc_amd.HipLikelihood: the update kernel compiled at construction around the caller's function, "
-            "bpm_step drives the sampler): DREAM gauss d=100 N=8192 steady", gen_src, lambda e: e.set_device_likelihood(src, pblock), budget_s * 0.15,
-            dict(pcie=dict(d2h_bytes_per_half_generation=0, h2d_bytes_per_half_generation=0, staging="none"), generations_per_step_call=STEP),
-            max_calls=80)                                             # (3 + 80 calls of 50 generations: inside the 6000 reserved history rows)
-        if len(out) > n0:                                             # `run` timed step calls of STEP generations each
-            ent = out[-1]
-            ent["steps"] *= STEP
-            ent["value"] *= STEP
-            ent["ms_per_step"] /= STEP
-            ent["share_of_time_in_the_callback"] = 0.0
-            ent["form"] = dict(form, note="true: ONE launch per half generation (the library's update kernel compiled at run time with the caller's function "
-                                          "as its target); false: proposal / likelihood / commit kernels")
+        # the per-coordinate form of the same likelihood (HipLikelihood(..., terms=2)): every lane of a chain adds the terms of its own coordinates
+        src_terms = ("#define BPM_LN_LIKE_TERMS 2\n"
+                     "__device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc) { const double z = xj * p[3 + j]; acc[0] += z; acc[1] += z * z; }\n"
+                     "__device__ double ln_like_finish(const double* acc, int d, const double* p) { return p[0] - 0.5 * (p[1] * acc[1] - p[2] * acc[0] * acc[0]); }\n")
+        for the_src, what in ((src, "plain form: ln_like(x, d, p) runs on one lane per chain"),
+                              (src_terms, "per-coordinate form: ln_like_terms / ln_like_finish, every lane adds its own coordinates' terms")):
+            form.clear()
+            n0 = len(out)
+            run("cfg2 shape with ln_like_fn given as HIP SOURCE (bipymc_amd.HipLikelihood, %s; the update kernel compiled at construction around the caller's "
+                "function, bpm_step drives the sampler): DREAM gauss d=100 N=8192 steady" % what, gen_src,
+                lambda e, the_src=the_src: e.set_device_likelihood(the_src, pblock), budget_s * 0.12,
+                dict(pcie=dict(d2h_bytes_per_half_generation=0, h2d_bytes_per_half_generation=0, staging="none"), generations_per_step_call=STEP),
+                max_calls=80)                                         # (3 + 80 calls of 50 generations: inside the 6000 reserved history rows)
+            if len(out) > n0:                                         # `run` timed step calls of STEP generations each
+                ent = out[-1]
+                ent["steps"] *= STEP
+                ent["value"] *= STEP
+                ent["ms_per_step"] /= STEP
+                ent["share_of_time_in_the_callback"] = 0.0
+                ent["form"] = dict(form, note="true: ONE launch per half generation (the library's update kernel compiled at run time with the caller's function "
+                                              "as its target); false: proposal / likelihood / commit kernels")
     except Exception as ex:                                           # noqa: BLE001
         out.append(dict(config="cfg2 shape with ln_like_fn given as HIP source", error=str(ex)))
     return out

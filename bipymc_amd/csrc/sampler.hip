@@ -462,7 +462,8 @@ struct bpm_sampler {
     // ... and the update kernel itself compiled around it (user_likelihood.h: compile_user_fused): one launch per half generation; nullptr: the three-kernel form
     hipModule_t user_fused_mod = nullptr;
     hipFunction_t user_fused_fn = nullptr;     // the general instantiation
-    hipFunction_t user_fused_hot = nullptr;    // the steady-state one (HOT 2): launched when phase_args_hot(a, dream, false, false) holds
+    hipFunction_t user_fused_hot = nullptr;    // the steady-state one (HOT 1 / 2): launched when phase_args_hot(a, dream, with_plan, false) holds
+    hipFunction_t user_fused_eval = nullptr;   // eval_ll_kernel with the same target: the current states' ln-likes by the update kernel's own arithmetic
     unsigned user_fused_block = 0;
     std::string user_fused_names[2];         // their lowered names: what the library's own queue dispatches them by (DirectQueue::kernel_by_name)
     bool user_fused_dq = false;              // ... and both were found among the loaded code objects
@@ -3053,7 +3054,16 @@ static int user_eval_launch(bpm_sampler* s, const double* rows, const int32_t* i
 }
 // ln-like of the local chains' CURRENT states from the installed device likelihood (what bpm_set_loglike takes from the host)
 static int user_refresh_ll(bpm_sampler* s) {
-    CK(user_eval_launch(s, s->G + (uint64_t)s->rank * s->L.blk, nullptr, s->n_local, s->ll));
+    if (s->user_fused_eval) {      // (the update kernel was compiled around the likelihood: the same Target::eval, the same bits)
+        const double* X = s->G + (uint64_t)s->rank * s->L.blk;
+        uint32_t n = s->n_local, ld = s->ld, dim = s->dim;
+        const double* tp = s->user_params;
+        double* out = s->ll;
+        void* args[] = {(void*)&X, (void*)&n, (void*)&ld, (void*)&dim, (void*)&tp, (void*)&out};
+        HIPCK(hipModuleLaunchKernel(s->user_fused_eval, grid_for(n, s->shape.lpc), 1, 1, s->user_fused_block, 1, 1, 0, s->stream, args, nullptr));
+    } else {
+        CK(user_eval_launch(s, s->G + (uint64_t)s->rank * s->L.blk, nullptr, s->n_local, s->ll));
+    }
     if (s->hist_rows >= 1 && s->hist_rows == s->rows_logical)
         HIPCK(hipMemcpyAsync(s->llhist + (size_t)(s->hist_rows - 1) * s->n_local, s->ll, s->n_local * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     HIPCK(hipStreamSynchronize(s->stream));
@@ -3122,14 +3132,14 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
     CK(dev_alloc(&s->user_params, (size_t)std::max(n_params, 1)));
     HIPCK(hipMemsetAsync(s->user_params, 0, (size_t)std::max(n_params, 1) * sizeof(double), s->stream));
     if (n_params > 0) HIPCK(hipMemcpyAsync(s->user_params, params, (size_t)n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    CK(user_refresh_ll(s));
     // the faster form: the update kernel itself compiled around the likelihood.  Whatever goes wrong here leaves the three-kernel form in place
     // (bpm_get_device_likelihood_info says which is in use and why).  BPM_USER_FUSED=0: not attempted (A/B, tests).
     if (s->user_fused_mod) {
         if (s->dq) { s->dq->forget_named(s->user_fused_names[0]); s->dq->forget_named(s->user_fused_names[1]); }
         (void)hipModuleUnload(s->user_fused_mod); s->user_fused_mod = nullptr;
     }
-    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_dq = false; s->user_fused_why.clear();
+    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_eval = nullptr; s->user_fused_dq = false; s->user_fused_why.clear();
+    CK(user_refresh_ll(s));      // (by the kernel of its own; again below by the update kernel's arithmetic once that one is built)
     const bool want_fused = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 0);      // (read at every call: a test switches it)
     if (!want_fused) { s->user_fused_why = "BPM_USER_FUSED=0"; return 0; }
     if (s->shape.idx == SHAPE_WIDE) { s->user_fused_why = "rows wider than 512 coordinates run on the looped kernel, which has no run-time form"; return 0; }
@@ -3142,7 +3152,7 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         const bool hooks = false;
 #endif
         std::vector<char> fcode;
-        std::string lowered[2], fwhy, ns;
+        std::string lowered[3], fwhy, ns;
         { std::lock_guard<std::mutex> lk(g_hiprtc_mu);
           static std::atomic<int> module_no{0};
           ns = "v_user" + std::to_string(module_no.fetch_add(1));
@@ -3150,10 +3160,10 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
                                          s->plan_on ? 1 : 2, fcode, lowered); }
         if (!fwhy.empty()) { s->user_fused_why = fwhy; return 0; }
         hipModule_t fm = nullptr;
-        hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr;
+        hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr, fe = nullptr;
         if (hipModuleLoadData(&fm, fcode.data()) != hipSuccess) { (void)hipGetLastError(); s->user_fused_why = "hipModuleLoadData failed"; return 0; }
         if (hipModuleGetFunction(&ff, fm, lowered[0].c_str()) != hipSuccess || hipModuleGetFunction(&fh, fm, lowered[1].c_str()) != hipSuccess ||
-            hipModuleGetFunction(&fs, fm, "bpm_user_sizeof") != hipSuccess || !ff || !fh || !fs) {
+            hipModuleGetFunction(&fe, fm, lowered[2].c_str()) != hipSuccess || hipModuleGetFunction(&fs, fm, "bpm_user_sizeof") != hipSuccess || !ff || !fh || !fe || !fs) {
             (void)hipGetLastError(); (void)hipModuleUnload(fm);
             s->user_fused_why = "the compiled module lacks " + lowered[0];
             return 0;
@@ -3173,8 +3183,10 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         }
         s->user_fused_mod = fm; s->user_fused_fn = ff; s->user_fused_hot = fh; s->user_fused_block = h_out[1];
         s->user_fused_names[0] = lowered[0]; s->user_fused_names[1] = lowered[1];
+        s->user_fused_eval = fe;
         static const bool dq_wanted = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 2);      // (2: fused, but launched on the stream -- A/B)
         s->user_fused_dq = dq_wanted && s->dq && s->dq->kernel_by_name(lowered[0]) != nullptr && s->dq->kernel_by_name(lowered[1]) != nullptr;
+        CK(user_refresh_ll(s));      // (again, now by the update kernel's own arithmetic: the per-coordinate form adds in the kernel's reduction order)
     }
     return 0;
 }

@@ -6,6 +6,12 @@
 // What the caller writes (HIP device code; double precision; no includes needed):
 //     __device__ double ln_like(const double* x, int d, const double* p)      // x: one parameter vector, p: the caller's parameter block
 // (the device math functions, INFINITY, NAN and M_PI are there; a prior outside its support returns -INFINITY like a Python ln_like_fn would)
+// The PER-COORDINATE form (optional; for likelihoods that are a function of a few sums over the coordinates): the source says
+//     #define BPM_LN_LIKE_TERMS K                                                               // number of accumulators, <= 8
+//     __device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc)       // adds coordinate j's contribution into acc[0 .. K)
+//     __device__ double ln_like_finish(const double* acc, int d, const double* p)                // the value from the K sums
+// and the library derives ln_like from them (user_ln_like_from_terms).  Inside the update kernel every lane of a chain then adds the terms of ITS
+// coordinates and the sums meet in the kernel's own reduction tree -- the shape of the shipped targets -- where the plain form runs on one lane per chain.
 // hiprtc is loaded on demand (libhiprtc.so): a process that never installs such a likelihood never needs it.
 #pragma once
 #include <dlfcn.h>
@@ -97,6 +103,17 @@ inline void user_eval_tile(uint32_t d, int& rpb, int& ldp) {
     rpb = rows >= 4 ? (int)(rows < 16 ? rows : 16) : 0;
 }
 
+// ln_like for a source in the per-coordinate form (appended behind the caller's source in every program)
+inline const char* user_ln_like_from_terms() {
+    return "\n#ifdef BPM_LN_LIKE_TERMS\n"
+           "__device__ double ln_like(const double* x, int d, const double* p) {\n"
+           "    double acc[BPM_LN_LIKE_TERMS];\n"
+           "    for (int k = 0; k < BPM_LN_LIKE_TERMS; ++k) acc[k] = 0.0;\n"
+           "    for (int j = 0; j < d; ++j) ln_like_terms(x[j], j, d, p, acc);\n"
+           "    return ln_like_finish(acc, d, p);\n"
+           "}\n#endif\n";
+}
+
 // user source + wrapper -> code object for `arch` ("gfx950", or a device's gcnArchName).  -> "" and `code`, or the reason (compiler log included).
 // f64 arithmetic unfused (-ffp-contract=off), like the library's own kernels: a formula written the same way in NumPy gives the same bits.
 inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_src, const std::string& arch, std::vector<char>& code) {
@@ -108,7 +125,7 @@ inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_sr
         "#ifndef NAN\n#define NAN (__builtin_nan(\"\"))\n#endif\n"
         "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n"
         "#line 1 \"ln_like.hip\"\n";
-    const std::string src = prelude + user_src + user_eval_wrapper();
+    const std::string src = prelude + user_src + user_ln_like_from_terms() + user_eval_wrapper();
     void* prog = nullptr;
     if (h.CreateProgram(&prog, src.c_str(), "ln_like.hip", 0, nullptr, nullptr) != 0 || !prog) return "hiprtcCreateProgram failed";
     const std::string a = "--offload-arch=" + arch;
@@ -141,10 +158,10 @@ inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_sr
 // inside the library as string literals (embedded_src.h, written by the Makefile).  The kernel-argument block must be the library's own: the program
 // is compiled with the library's BPM_TEST_HOOKS setting and exports sizeof(PhaseArgs) for the caller to compare.
 // Two instantiations: the general one (HOT 0) and the steady-state one (`hot`: 1 with update records, 2 without -- what phase_args_hot(a, dream, with_plan,
-// false) fixes is a compile-time constant) -- name_expr[0 / 1].
+// false) fixes is a compile-time constant) -- name_expr[0 / 1]; name_expr[2]: eval_ll_kernel with the same target.
 // `ns`: the inline namespace the program's device code lives in -- unique per module of the process: the library's queue finds kernels by name.
 inline std::string user_fused_program(const std::string& user_src, const std::string& ns, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks,
-                                      int hot, std::string name_expr[2]) {
+                                      int hot, std::string name_expr[3]) {
     std::string s;
     s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
          "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t;\n"
@@ -154,7 +171,7 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
     if (test_hooks) s += "#define BPM_TEST_HOOKS 1\n";
     s += "#define BPM_USER_LDP " + std::to_string((int)(dim | 1u)) + "\n";
     s += "#define BPM_USER_DIM " + std::to_string((int)dim) + "\n";      // (the caller's loops over d get a compile-time trip count: the sampler's dimension is fixed)
-    s += "#include \"kernels.h\"\n#line 1 \"ln_like.hip\"\n" + user_src + "\n";
+    s += "#include \"kernels.h\"\n#line 1 \"ln_like.hip\"\n" + user_src + "\n" + user_ln_like_from_terms();
     s += "namespace bpm { inline namespace BPM_VARIANT_NS {\n"
          "constexpr int TARGET_USER = 64;\n"
          "template <int LPC, int DPL>\n"
@@ -162,6 +179,20 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
          "    struct Consts { const double* tp; };\n"
          "    static __device__ __forceinline__ Consts load(int, uint32_t, const double* tp) { Consts k; k.tp = tp; return k; }\n"
          "    static __device__ __forceinline__ double eval(const double* v, int q, uint32_t dim, const Consts& k) {\n"
+         "#ifdef BPM_LN_LIKE_TERMS\n"
+         "        // the per-coordinate form: every lane adds the terms of its own coordinates, the kernel's reduction tree adds the lanes\n"
+         "        double acc[BPM_LN_LIKE_TERMS];\n"
+         "#pragma unroll\n"
+         "        for (int t = 0; t < BPM_LN_LIKE_TERMS; ++t) acc[t] = 0.0;\n"
+         "#pragma unroll\n"
+         "        for (int s = 0; s < DPL; ++s) {\n"
+         "            const uint32_t j = 2u * (uint32_t)(q + (s >> 1) * LPC) + (uint32_t)(s & 1);\n"
+         "            if (j < dim) ::ln_like_terms(v[s], (int)j, BPM_USER_DIM, k.tp, acc);\n"
+         "        }\n"
+         "#pragma unroll\n"
+         "        for (int t = 0; t < BPM_LN_LIKE_TERMS; ++t) acc[t] = gsum<LPC>(acc[t]);\n"
+         "        return (double)::ln_like_finish(acc, BPM_USER_DIM, k.tp);\n"
+         "#else\n"
          "        if (LPC == 1) return (double)::ln_like(v, BPM_USER_DIM, k.tp);      // (a lane is a chain: the row is the lane's registers)\n"
          "        __shared__ double rows[(block_for(LPC) / LPC) * BPM_USER_LDP];\n"
          "        const int cw = (int)threadIdx.x / LPC;\n"
@@ -181,6 +212,7 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
          "        __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
          "        __builtin_amdgcn_wave_barrier();\n"
          "        return r;\n"
+         "#endif\n"
          "    }\n"
          "};\n";
     for (int k = 0; k < 2; ++k) {
@@ -190,6 +222,13 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
         name_expr[k] = "bpm::" + inst;
         name_expr[k].replace(name_expr[k].find("TARGET_USER"), 11, "bpm::TARGET_USER");
     }
+    // ... and the library's evaluation kernel with the same target: the ln-likes of given states by exactly the arithmetic the update kernel uses
+    {
+        const std::string inst = "eval_ll_kernel<TARGET_USER, " + std::to_string(lpc) + ", " + std::to_string(dpl) + ">";
+        s += "template __global__ void " + inst + "(const double*, uint32_t, uint32_t, uint32_t, const double*, double*);\n";
+        name_expr[2] = "bpm::" + inst;
+        name_expr[2].replace(name_expr[2].find("TARGET_USER"), 11, "bpm::TARGET_USER");
+    }
     s += "extern \"C\" __global__ void bpm_user_sizeof(unsigned int* out) { out[0] = (unsigned int)sizeof(PhaseArgs); out[1] = (unsigned int)block_for(" +
          std::to_string(lpc) + "); }\n"
          "}}\n";
@@ -197,16 +236,16 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
 }
 // -> "" with `code` and the kernel's lowered (mangled) name, or the reason
 inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, const std::string& ns, const std::string& arch, const char* kernels_h,
-                                      const char* philox_h, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, int hot, std::vector<char>& code, std::string lowered[2]) {
+                                      const char* philox_h, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, int hot, std::vector<char>& code, std::string lowered[3]) {
     const std::string why = load_hiprtc(h);
     if (!why.empty()) return why;
-    std::string expr[2];
+    std::string expr[3];
     const std::string src = user_fused_program(user_src, ns, algo, lpc, dpl, np, dim, test_hooks, hot, expr);
     const char* hdr_src[] = {kernels_h, philox_h};
     const char* hdr_names[] = {"kernels.h", "philox.h"};
     void* prog = nullptr;
     if (h.CreateProgram(&prog, src.c_str(), "bpm_user_fused.hip", 2, hdr_src, hdr_names) != 0 || !prog) return "hiprtcCreateProgram failed";
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
         if (h.AddNameExpression(prog, expr[k].c_str()) != 0) { h.DestroyProgram(&prog); return "hiprtcAddNameExpression failed"; }
     const std::string a = "--offload-arch=" + arch;
     const char* opts[] = {a.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function"};
@@ -219,7 +258,7 @@ inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, co
         while (!log.empty() && (log.back() == '\0' || log.back() == '\n')) log.pop_back();
     }
     if (rc != 0) { h.DestroyProgram(&prog); return "the update kernel does not compile around this likelihood:\n" + log; }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const char* low = nullptr;
         if (h.GetLoweredName(prog, expr[k].c_str(), &low) != 0 || !low) { h.DestroyProgram(&prog); return "hiprtcGetLoweredName failed for " + expr[k]; }
         lowered[k] = low;

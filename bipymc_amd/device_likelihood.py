@@ -20,8 +20,19 @@ import numpy as np
 
 
 class HipLikelihood(object):
-    def __init__(self, source, params=(), python_fn=None):
-        self.source = str(source)
+    """terms=K (optional, 1 ... 8): the PER-COORDINATE form for a likelihood that is a function of K sums over the coordinates.  `source` then defines
+
+        __device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc)     // adds coordinate j's contribution into acc[0 .. K)
+        __device__ double ln_like_finish(const double* acc, int d, const double* p)              // the value from the K sums
+
+    instead of ln_like: inside the update kernel every lane of a chain adds the terms of its own coordinates and the sums meet in the kernel's reduction
+    tree -- the shape of the shipped targets, and their speed (the plain form runs on one lane per chain)."""
+
+    def __init__(self, source, params=(), python_fn=None, terms=0):
+        self.terms = int(terms)
+        if not 0 <= self.terms <= 8:
+            raise ValueError("terms must be 0 (plain ln_like) or 1 ... 8")
+        self.source = ("#define BPM_LN_LIKE_TERMS %d\n" % self.terms if self.terms else "") + str(source)
         self.params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
         self.python_fn = python_fn
 

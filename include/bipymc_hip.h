@@ -255,6 +255,8 @@ int bpm_set_loglike_device(bpm_handle_t h, const double* ll_dev);
 /* ... and with the likelihood given as HIP SOURCE (round 5; samplers.py:36-43 takes any Python callable -- this is the form of it that runs at device
  * speed with no framework in the process): `hip_source` defines
  *     __device__ double ln_like(const double* x, int d, const double* p)       (x: one parameter vector; p: the caller's parameter block = ln_kwargs)
+ * (or, per coordinate: `#define BPM_LN_LIKE_TERMS K` + ln_like_terms(xj, j, d, p, acc) adding coordinate j's contribution to K <= 8 sums +
+ * ln_like_finish(acc, d, p): inside the update kernel every lane of a chain then adds its own coordinates' terms; bipymc_amd/csrc/user_likelihood.h)
  * bpm_set_device_likelihood compiles it with hiprtc (loaded on demand) into one kernel -- a thread per proposal row -- that runs between the library's
  * proposal and commit kernels, copies the n_params doubles of `params` to the device and evaluates the current states (what bpm_set_loglike takes from
  * the host).  From then on bpm_step drives this host-callback sampler like one with a shipped target: no host code inside a generation.  f64 arithmetic

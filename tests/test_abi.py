@@ -214,3 +214,9 @@ def test_hip_source_likelihood_compiles_without_a_gpu():
         HipLikelihood("__device__ double other(const double* x) { return x[0]; }").check()
     with pytest.raises(TypeError):
         ok(np.zeros(3))                                              # no python_fn: device only
+    # the per-coordinate form: ln_like is derived from ln_like_terms / ln_like_finish
+    terms = HipLikelihood("__device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc) { acc[0] += xj * xj; }\n"
+                          "__device__ double ln_like_finish(const double* acc, int d, const double* p) { return -0.5 * acc[0]; }", terms=1)
+    assert terms.check() and terms.source.startswith("#define BPM_LN_LIKE_TERMS 1")
+    with pytest.raises(ValueError):
+        HipLikelihood("", terms=9)

@@ -638,7 +638,14 @@ __device__ double ln_like(const double* x, int d, const double* p) {      // p =
 """
 
 
-@pytest.mark.parametrize("fused", [True, False])
+GAUSS_EQUICORR_HIP_TERMS = """
+#define BPM_LN_LIKE_TERMS 2
+__device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc) { const double z = xj * p[4 + j]; acc[0] += z; acc[1] += z * z; }
+__device__ double ln_like_finish(const double* acc, int d, const double* p) { return p[1] - 0.5 * (p[2] * acc[1] - p[3] * acc[0] * acc[0]); }
+"""
+
+
+@pytest.mark.parametrize("fused", [True, False, "terms"])
 @pytest.mark.parametrize("algo,d,N,kw", [
     (R.ALGO_DREAM, 10, 16, dict(burnin_gen=6, n_cr_gen=2)),
     (R.ALGO_DREAM, 100, 64, dict(burnin_gen=5, n_cr_gen=1)),
@@ -673,10 +680,11 @@ def test_hip_source_likelihood_against_oracle(algo, d, N, kw, fused, monkeypatch
     with pytest.raises(Exception, match="does not compile"):
         eng.set_device_likelihood("__device__ double ln_like(const double* x) { return x[0] }")
     monkeypatch.setenv("BPM_USER_FUSED", "1" if fused else "0")
-    eng.set_device_likelihood(GAUSS_EQUICORR_HIP, params)
+    # "terms": the per-coordinate form of the same likelihood (every lane of a chain adds its own coordinates' terms inside the update kernel)
+    eng.set_device_likelihood(GAUSS_EQUICORR_HIP_TERMS if fused == "terms" else GAUSS_EQUICORR_HIP, params)
     is_fused, why = eng.device_likelihood_info()
     # fused: the update kernel itself compiled around the likelihood (one launch per half generation); else proposal / likelihood / commit kernels
-    assert is_fused == (fused and d <= 512), why
+    assert is_fused == (bool(fused) and d <= 512), why
     np.testing.assert_allclose(eng.get_loglike(), [py_ll(x) for x in X0], rtol=1e-12, atol=1e-12)
     ora.set_state(X0)
     eng.begin_run()

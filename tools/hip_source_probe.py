@@ -1,4 +1,4 @@
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from bipymc_amd import _lib as L
 from bipymc_amd.engine import HipEngine
@@ -11,6 +11,10 @@ src = """__device__ double ln_like(const double* x, int d, const double* p) {
     for (int j = 0; j < d; ++j) { const double z = x[j] * p[3 + j]; s1 += z; s2 += z * z; }
     return p[0] - 0.5 * (p[1] * s2 - p[2] * s1 * s1);
 }"""
+if os.environ.get("HIP_SOURCE_TERMS"):      # the per-coordinate form of the same likelihood
+    src = """#define BPM_LN_LIKE_TERMS 2
+__device__ void ln_like_terms(double xj, int j, int d, const double* p, double* acc) { const double z = xj * p[3 + j]; acc[0] += z; acc[1] += z * z; }
+__device__ double ln_like_finish(const double* acc, int d, const double* p) { return p[0] - 0.5 * (p[1] * acc[1] - p[2] * acc[0] * acc[0]); }"""
 rs = np.random.RandomState(1)
 X0 = sig * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
 e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, burnin_gen=0, n_cr=3)
