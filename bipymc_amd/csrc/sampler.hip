@@ -464,8 +464,10 @@ struct bpm_sampler {
     hipFunction_t user_fused_fn = nullptr;     // the general instantiation
     hipFunction_t user_fused_hot = nullptr;    // the steady-state one (HOT 1 / 2): launched when phase_args_hot(a, dream, with_plan, false) holds
     hipFunction_t user_fused_eval = nullptr;   // eval_ll_kernel with the same target: the current states' ln-likes by the update kernel's own arithmetic
+    hipFunction_t user_fused_adapt = nullptr;  // DREAM's burn-in instantiation (HOT 3 / 4): level 1 of the CR reduction and the consumer-side fold inside the launch
+    unsigned user_fused_block_adapt = 0;
     unsigned user_fused_block = 0;
-    std::string user_fused_names[2];         // their lowered names: what the library's own queue dispatches them by (DirectQueue::kernel_by_name)
+    std::string user_fused_names[3];         // their lowered names ([2]: the burn-in instantiation): what the library's own queue dispatches them by (DirectQueue::kernel_by_name)
     bool user_fused_dq = false;              // ... and both were found among the loaded code objects
     std::string user_fused_why;              // why the fused form is not in use (bpm_get_device_likelihood_info)
     double* aux_buf = nullptr;
@@ -938,7 +940,7 @@ extern "C" int bpm_destroy(bpm_handle_t s) {
     if (free_buffers) { if (s->xcd_args) (void)hipFree(s->xcd_args); if (s->xcd_ctl) (void)hipFree(s->xcd_ctl); }
 #endif
     for (hipEvent_t e : s->chunk_ev) if (e) (void)hipEventDestroy(e);
-    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_fused_mod) { if (s->dq) { s->dq->forget_named(s->user_fused_names[0]); s->dq->forget_named(s->user_fused_names[1]); } (void)hipModuleUnload(s->user_fused_mod); } if (s->user_params) (void)hipFree(s->user_params); }
+    if (free_buffers) { if (s->user_mod) (void)hipModuleUnload(s->user_mod); if (s->user_fused_mod) { if (s->dq) for (const std::string& nm : s->user_fused_names) s->dq->forget_named(nm); (void)hipModuleUnload(s->user_fused_mod); } if (s->user_params) (void)hipFree(s->user_params); }
     for (auto& B : s->tb) {
         if (B.count_h) (void)hipHostFree(B.count_h);
         if (B.built) (void)hipEventDestroy(B.built);
@@ -1488,6 +1490,8 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
 
 // Everything of one generation that is decided on the host: flip, shuffle key, group ranges
 // (demc.py:81-86,95-100), gating flags (dream.py:92,123), history row.
+// the host-callback sampler whose generation loop the update kernel compiled around its HIP-source likelihood is driving (run_generations; else nullptr)
+static thread_local bpm_sampler* g_user_cur = nullptr;
 // totals (cr_state) + `cnt` partial sums of one generation -> cr_state: cr_final_kernel on the queue the generation loop runs on
 static int launch_cr_final(bpm_sampler* s, const double* src, uint32_t cnt) {
     const uint32_t n_cr = (uint32_t)s->cfg.n_cr;
@@ -1661,7 +1665,9 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
     s->gen_fold_planned = false;
     if (s->cr_p1) s->cr_p1_cur = s->cr_p1 + (size_t)(s->t_abs & 1) * 2 * MAX_CR * s->cr_n1;
 #ifdef BPM_PRELOAD      // (the specialised flavours exist only in the preload build: without it every launch ends in the general kernel, which writes the slots)
-    if (s->gen_cr_reduce && dream && s->cfg.target_id != BPM_TARGET_HOST_CALLBACK && s->shape.idx != SHAPE_WIDE && crp_shape(s->shape.lpc, s->shape.dpl) &&
+    // (a host-callback sampler: only while the update kernel compiled around its HIP-source likelihood drives it -- g_user_cur -- and has the burn-in flavour)
+    if (s->gen_cr_reduce && dream && (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK || (g_user_cur == s && s->user_fused_adapt != nullptr && (s->cur_args[0].rec_tab != nullptr) == s->plan_on)) &&
+        s->shape.idx != SHAPE_WIDE && crp_shape(s->shape.lpc, s->shape.dpl) &&
         !test_path("nohot") && !test_path("crslots")) {
         bool ok = true;
         for (int ph = 0; ph < 2; ++ph) {
@@ -2194,7 +2200,6 @@ static bool group_goes_direct(const Group& g, bool push, bool& group_direct) {
 
 static int run_generations_user(bpm_sampler* s, int64_t n_gens);      // (a host-callback sampler with a device likelihood: below, beside the host-callback core)
 // the update kernel compiled at run time around a caller's likelihood (bpm_sampler::user_fused_fn): the general instantiation's launch, from a module
-static thread_local bpm_sampler* g_user_cur = nullptr;
 static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
     bpm_sampler* s = g_user_cur;
     if (!s || !s->user_fused_fn) return;
@@ -2202,12 +2207,15 @@ static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
     ka.tparams = s->user_params;                   // the caller's parameter block is the target's
     size_t sz = sizeof(ka);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    const unsigned block = s->user_fused_block, cpw = block / (unsigned)s->shape.lpc, grid = (a.n_items + cpw - 1u) / cpw;
     static const bool no_hot = test_path("nohot");
+    // burn-in: prepare_generation handed this launch the level-1 sums to write (cr_part1) only after phase_args_hot(a, true, plan, true) held for BOTH launches
+    const bool adapt = a.cr_part1 != nullptr && s->user_fused_adapt != nullptr;
+    if (adapt) { ++g_crp_launched; if (a.cr_fold_part != nullptr) ++g_crfold_launched; }
+    const unsigned block = adapt ? s->user_fused_block_adapt : s->user_fused_block, cpw = block / (unsigned)s->shape.lpc, grid = (a.n_items + cpw - 1u) / cpw;
     // (the steady-state instantiation was compiled for update records exactly when this sampler builds them: HOT 1 / HOT 2)
-    const bool hot = !no_hot && s->user_fused_hot && (a.rec_tab != nullptr) == s->plan_on && phase_args_hot(a, s->cfg.algo == BPM_ALGO_DREAM, a.rec_tab != nullptr, false);
+    const bool hot = !adapt && !no_hot && s->user_fused_hot && (a.rec_tab != nullptr) == s->plan_on && phase_args_hot(a, s->cfg.algo == BPM_ALGO_DREAM, a.rec_tab != nullptr, false);
     if (g_dq) {      // the library's own queue (launch_packed's packet: the module's kernels take the argument block alone, no preloaded leading arguments)
-        const bpm::DqKernel* k = g_dq->kernel_by_name(s->user_fused_names[hot ? 1 : 0]);
+        const bpm::DqKernel* k = g_dq->kernel_by_name(s->user_fused_names[adapt ? 2 : (hot ? 1 : 0)]);
         const int sig = g_dq_sig; g_dq_sig = -1;
         int fence = g_dq_update_fence;
         if (g_dq_need_acquire) { fence |= bpm::DirectQueue::ACQUIRE; g_dq_need_acquire = false; }
@@ -2216,7 +2224,7 @@ static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
         ++g_timed_launches; ++g_n_direct;
         return;
     }
-    (void)hipExtModuleLaunchKernel(hot ? s->user_fused_hot : s->user_fused_fn, grid * block, 1, 1, block, 1, 1, 0, st, nullptr, extra, nullptr, take_stop_event(), 0);
+    (void)hipExtModuleLaunchKernel(adapt ? s->user_fused_adapt : (hot ? s->user_fused_hot : s->user_fused_fn), grid * block, 1, 1, block, 1, 1, 0, st, nullptr, extra, nullptr, take_stop_event(), 0);
     ++g_timed_launches; ++g_n_stream;
 }
 static int run_generations(const Group& g, int64_t n_gens) {
@@ -2227,6 +2235,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
     if (s0->cfg.target_id == BPM_TARGET_HOST_CALLBACK && s0->user_fn && g.R == 1 && !user_fused) return run_generations_user(s0, n_gens);
     if (user_fused && s0->world > 1 && !s0->comm) return fail("bpm_step: a host-callback sampler of a world needs an RCCL communicator (create it with a unique id)");
     g_user_cur = user_fused ? s0 : nullptr;
+    struct UserCurReset { ~UserCurReset() { g_user_cur = nullptr; } } user_cur_reset;      // (prepare_generation asks g_user_cur who drives a host-callback sampler)
     PhaseLaunch fn = user_fused ? launch_user_fused : pick_fused(s0);
     if (!fn) return fail("bpm_step: host-callback target must be driven with bpm_propose / bpm_commit (or give it a device likelihood: bpm_set_device_likelihood)");
     const bool dream = s0->cfg.algo == BPM_ALGO_DREAM;
@@ -3135,10 +3144,10 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
     // the faster form: the update kernel itself compiled around the likelihood.  Whatever goes wrong here leaves the three-kernel form in place
     // (bpm_get_device_likelihood_info says which is in use and why).  BPM_USER_FUSED=0: not attempted (A/B, tests).
     if (s->user_fused_mod) {
-        if (s->dq) { s->dq->forget_named(s->user_fused_names[0]); s->dq->forget_named(s->user_fused_names[1]); }
+        if (s->dq) for (const std::string& nm : s->user_fused_names) s->dq->forget_named(nm);
         (void)hipModuleUnload(s->user_fused_mod); s->user_fused_mod = nullptr;
     }
-    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_eval = nullptr; s->user_fused_dq = false; s->user_fused_why.clear();
+    s->user_fused_fn = nullptr; s->user_fused_hot = nullptr; s->user_fused_eval = nullptr; s->user_fused_adapt = nullptr; s->user_fused_dq = false; s->user_fused_why.clear();
     CK(user_refresh_ll(s));      // (by the kernel of its own; again below by the update kernel's arithmetic once that one is built)
     const bool want_fused = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 0);      // (read at every call: a test switches it)
     if (!want_fused) { s->user_fused_why = "BPM_USER_FUSED=0"; return 0; }
@@ -3152,7 +3161,7 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         const bool hooks = false;
 #endif
         std::vector<char> fcode;
-        std::string lowered[3], fwhy, ns;
+        std::string lowered[4], fwhy, ns;
         { std::lock_guard<std::mutex> lk(g_hiprtc_mu);
           static std::atomic<int> module_no{0};
           ns = "v_user" + std::to_string(module_no.fetch_add(1));
@@ -3160,7 +3169,7 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
                                          s->plan_on ? 1 : 2, fcode, lowered); }
         if (!fwhy.empty()) { s->user_fused_why = fwhy; return 0; }
         hipModule_t fm = nullptr;
-        hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr, fe = nullptr;
+        hipFunction_t ff = nullptr, fh = nullptr, fs = nullptr, fe = nullptr, fa = nullptr;
         if (hipModuleLoadData(&fm, fcode.data()) != hipSuccess) { (void)hipGetLastError(); s->user_fused_why = "hipModuleLoadData failed"; return 0; }
         if (hipModuleGetFunction(&ff, fm, lowered[0].c_str()) != hipSuccess || hipModuleGetFunction(&fh, fm, lowered[1].c_str()) != hipSuccess ||
             hipModuleGetFunction(&fe, fm, lowered[2].c_str()) != hipSuccess || hipModuleGetFunction(&fs, fm, "bpm_user_sizeof") != hipSuccess || !ff || !fh || !fe || !fs) {
@@ -3170,8 +3179,9 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         }
         // the module's view of the argument block must be this library's
         unsigned int* d_out = nullptr;
-        unsigned int h_out[2] = {0u, 0u};
-        if (dev_alloc(&d_out, 2) != 0) { (void)hipModuleUnload(fm); s->user_fused_why = "out of device memory"; return 0; }
+        unsigned int h_out[3] = {0u, 0u, 0u};
+        if (!lowered[3].empty() && (hipModuleGetFunction(&fa, fm, lowered[3].c_str()) != hipSuccess || !fa)) { (void)hipGetLastError(); fa = nullptr; }
+        if (dev_alloc(&d_out, 3) != 0) { (void)hipModuleUnload(fm); s->user_fused_why = "out of device memory"; return 0; }
         void* sargs[] = {(void*)&d_out};
         const bool ran = hipModuleLaunchKernel(fs, 1, 1, 1, 1, 1, 1, 0, s->stream, sargs, nullptr) == hipSuccess &&
                          hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, s->stream) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess;
@@ -3184,8 +3194,11 @@ extern "C" int bpm_set_device_likelihood(bpm_handle_t s, const char* hip_source,
         s->user_fused_mod = fm; s->user_fused_fn = ff; s->user_fused_hot = fh; s->user_fused_block = h_out[1];
         s->user_fused_names[0] = lowered[0]; s->user_fused_names[1] = lowered[1];
         s->user_fused_eval = fe;
+        s->user_fused_adapt = fa; s->user_fused_block_adapt = h_out[2]; s->user_fused_names[2] = lowered[3];
+        if (fa && h_out[2] != (unsigned)block_for_hot(s->shape.lpc, 3, s->shape.dpl)) s->user_fused_adapt = nullptr;
         static const bool dq_wanted = !(getenv("BPM_USER_FUSED") && atoi(getenv("BPM_USER_FUSED")) == 2);      // (2: fused, but launched on the stream -- A/B)
-        s->user_fused_dq = dq_wanted && s->dq && s->dq->kernel_by_name(lowered[0]) != nullptr && s->dq->kernel_by_name(lowered[1]) != nullptr;
+        s->user_fused_dq = dq_wanted && s->dq && s->dq->kernel_by_name(lowered[0]) != nullptr && s->dq->kernel_by_name(lowered[1]) != nullptr &&
+                           (!s->user_fused_adapt || s->dq->kernel_by_name(lowered[3]) != nullptr);
         CK(user_refresh_ll(s));      // (again, now by the update kernel's own arithmetic: the per-coordinate form adds in the kernel's reduction order)
     }
     return 0;

@@ -158,10 +158,10 @@ inline std::string compile_user_likelihood(Hiprtc& h, const std::string& user_sr
 // inside the library as string literals (embedded_src.h, written by the Makefile).  The kernel-argument block must be the library's own: the program
 // is compiled with the library's BPM_TEST_HOOKS setting and exports sizeof(PhaseArgs) for the caller to compare.
 // Two instantiations: the general one (HOT 0) and the steady-state one (`hot`: 1 with update records, 2 without -- what phase_args_hot(a, dream, with_plan,
-// false) fixes is a compile-time constant) -- name_expr[0 / 1]; name_expr[2]: eval_ll_kernel with the same target.
+// false) fixes is a compile-time constant) -- name_expr[0 / 1]; name_expr[2]: eval_ll_kernel with the same target; name_expr[3]: DREAM's burn-in instantiation (hot + 2).
 // `ns`: the inline namespace the program's device code lives in -- unique per module of the process: the library's queue finds kernels by name.
 inline std::string user_fused_program(const std::string& user_src, const std::string& ns, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks,
-                                      int hot, std::string name_expr[3]) {
+                                      int hot, std::string name_expr[4]) {
     std::string s;
     s += "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long uint64_t;\n"
          "typedef signed char int8_t; typedef short int16_t; typedef int int32_t; typedef long int64_t;\n"
@@ -194,7 +194,7 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
          "        return (double)::ln_like_finish(acc, BPM_USER_DIM, k.tp);\n"
          "#else\n"
          "        if (LPC == 1) return (double)::ln_like(v, BPM_USER_DIM, k.tp);      // (a lane is a chain: the row is the lane's registers)\n"
-         "        __shared__ double rows[(block_for(LPC) / LPC) * BPM_USER_LDP];\n"
+         "        __shared__ double rows[(block_for_hot(LPC, 3, DPL) / LPC) * BPM_USER_LDP];      // (the burn-in flavours' workgroups hold the most chains)\n"
          "        const int cw = (int)threadIdx.x / LPC;\n"
          "        double* row = rows + cw * BPM_USER_LDP;\n"
          "#pragma unroll\n"
@@ -215,12 +215,16 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
          "#endif\n"
          "    }\n"
          "};\n";
-    for (int k = 0; k < 2; ++k) {
+    // [0] general, [1] steady state (HOT 1 / 2), [3] DREAM's burn-in (HOT 3 / 4: sums level 1 of the CR reduction itself, folds the previous generation's sums)
+    for (int k = 0; k < 3; ++k) {
+        const int h = k == 0 ? 0 : (k == 1 ? hot : hot + 2);
+        if (k == 2 && algo != 1 /* ALGO_DREAM */) { name_expr[3].clear(); continue; }
         const std::string inst = "phase_fused_kernel<" + std::to_string(algo) + ", TARGET_USER, " + std::to_string(lpc) + ", " + std::to_string(dpl) + ", " +
-                                 std::to_string(np) + ", " + (k == 0 ? "0" : std::to_string(hot)) + ">";
+                                 std::to_string(np) + ", " + std::to_string(h) + ">";
         s += "template __global__ void " + inst + "(const PhaseArgs);\n";
-        name_expr[k] = "bpm::" + inst;
-        name_expr[k].replace(name_expr[k].find("TARGET_USER"), 11, "bpm::TARGET_USER");
+        std::string& e = name_expr[k == 2 ? 3 : k];
+        e = "bpm::" + inst;
+        e.replace(e.find("TARGET_USER"), 11, "bpm::TARGET_USER");
     }
     // ... and the library's evaluation kernel with the same target: the ln-likes of given states by exactly the arithmetic the update kernel uses
     {
@@ -230,23 +234,23 @@ inline std::string user_fused_program(const std::string& user_src, const std::st
         name_expr[2].replace(name_expr[2].find("TARGET_USER"), 11, "bpm::TARGET_USER");
     }
     s += "extern \"C\" __global__ void bpm_user_sizeof(unsigned int* out) { out[0] = (unsigned int)sizeof(PhaseArgs); out[1] = (unsigned int)block_for(" +
-         std::to_string(lpc) + "); }\n"
+         std::to_string(lpc) + "); out[2] = (unsigned int)block_for_hot(" + std::to_string(lpc) + ", 3, " + std::to_string(dpl) + "); }\n"
          "}}\n";
     return s;
 }
 // -> "" with `code` and the kernel's lowered (mangled) name, or the reason
 inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, const std::string& ns, const std::string& arch, const char* kernels_h,
-                                      const char* philox_h, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, int hot, std::vector<char>& code, std::string lowered[3]) {
+                                      const char* philox_h, int algo, int lpc, int dpl, int np, uint32_t dim, bool test_hooks, int hot, std::vector<char>& code, std::string lowered[4]) {
     const std::string why = load_hiprtc(h);
     if (!why.empty()) return why;
-    std::string expr[3];
+    std::string expr[4];
     const std::string src = user_fused_program(user_src, ns, algo, lpc, dpl, np, dim, test_hooks, hot, expr);
     const char* hdr_src[] = {kernels_h, philox_h};
     const char* hdr_names[] = {"kernels.h", "philox.h"};
     void* prog = nullptr;
     if (h.CreateProgram(&prog, src.c_str(), "bpm_user_fused.hip", 2, hdr_src, hdr_names) != 0 || !prog) return "hiprtcCreateProgram failed";
-    for (int k = 0; k < 3; ++k)
-        if (h.AddNameExpression(prog, expr[k].c_str()) != 0) { h.DestroyProgram(&prog); return "hiprtcAddNameExpression failed"; }
+    for (int k = 0; k < 4; ++k)
+        if (!expr[k].empty() && h.AddNameExpression(prog, expr[k].c_str()) != 0) { h.DestroyProgram(&prog); return "hiprtcAddNameExpression failed"; }
     const std::string a = "--offload-arch=" + arch;
     const char* opts[] = {a.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function"};
     const int rc = h.CompileProgram(prog, 5, opts);
@@ -258,8 +262,9 @@ inline std::string compile_user_fused(Hiprtc& h, const std::string& user_src, co
         while (!log.empty() && (log.back() == '\0' || log.back() == '\n')) log.pop_back();
     }
     if (rc != 0) { h.DestroyProgram(&prog); return "the update kernel does not compile around this likelihood:\n" + log; }
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const char* low = nullptr;
+        if (expr[k].empty()) { lowered[k].clear(); continue; }
         if (h.GetLoweredName(prog, expr[k].c_str(), &low) != 0 || !low) { h.DestroyProgram(&prog); return "hiprtcGetLoweredName failed for " + expr[k]; }
         lowered[k] = low;
     }

@@ -17,7 +17,7 @@ __device__ void ln_like_terms(double xj, int j, int d, const double* p, double* 
 __device__ double ln_like_finish(const double* acc, int d, const double* p) { return p[0] - 0.5 * (p[1] * acc[1] - p[2] * acc[0] * acc[0]); }"""
 rs = np.random.RandomState(1)
 X0 = sig * (np.sqrt(0.5) * rs.standard_normal((N, 1)) + np.sqrt(0.5) * rs.standard_normal((N, d)))
-e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, burnin_gen=0, n_cr=3)
+e = HipEngine(algo=L.ALGO_DREAM, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=42, burnin_gen=int(os.environ.get("HIP_SOURCE_BURNIN", "0")), n_cr_gen=5, n_cr=3)
 e.set_state(X0); e.set_device_likelihood(src, np.concatenate([[c0, a, b], 1 / sig])); e.reserve_history(1000); e.begin_run()
 e.step(50); e.synchronize()
 t0 = time.perf_counter(); e.step(300); e.synchronize(); el = time.perf_counter() - t0
