@@ -55,7 +55,12 @@ class DeMc(object):
         self._device_target = tid != L.TARGET_HOST_CALLBACK
         # _init_chains (samplers.py:255-259): chain.py:27 jitter with variance varepsilon * inflate
         eng.init_chains(theta_0, np.asarray(varepsilon, dtype=np.float64) * kwargs.get("inflate", 1e1))
-        if not self._device_target:
+        # ln_like_fn given as HIP source (device_likelihood.py): compiled into the generation loop, the sampler is stepped like one with a shipped target
+        from .device_likelihood import HipLikelihood
+        hip = isinstance(self.log_like_fn, HipLikelihood) and not self._device_target and hasattr(eng, "set_device_likelihood")
+        if hip:
+            eng.set_device_likelihood(self.log_like_fn.source, self.log_like_fn.params)      # (evaluates the jittered start states too)
+        elif not self._device_target:
             X = eng.get_state()
             eng.set_loglike(np.array([self._call(x) for x in X], dtype=np.float64))
         # var_ball(varepsilon * 1e-3, dim) (samplers.py:283): VARIANCE varepsilon*1e-3 -> std for the device jitter
@@ -63,7 +68,7 @@ class DeMc(object):
         n_gens = max(0, -(-(int(n) - self.n_chains) // self.n_chains))          # while j < n - n_chains: j += n_chains
         eng.begin_run(epsilon=eps_std, gamma=gamma, shuffle=False, flip=0.0)
         eng.reserve_history(1 + n_gens)
-        if self._device_target:
+        if self._device_target or hip:
             eng.step(n_gens)
         else:
             for _ in range(n_gens):

@@ -272,6 +272,15 @@ def test_hip_source_likelihood_through_the_sampler_classes(tmp_path):
     assert a2.param_est(0)[2].shape == (64 * 39, d)            # (demc.py:79: 29 + 9 generations behind the start row)
     with pytest.raises(Exception, match="does not compile"):
         DreamMpi(HipLikelihood("double ln_like(x) { }"), mu, n_chains=8, seed=1)
+    # the serial-API sampler (samplers.py:237-336, delayed-accept form) takes it too: the same run as with the formula as a Python callable
+    from bipymc_amd.samplers import DeMc
+    runs = []
+    for fn in (ll, lambda th: float(np_ll(th)[0])):
+        sd = DeMc(fn, n_chains=32, seed=9)
+        sd.run_mcmc(32 * 40, mu, varepsilon=1e-2)
+        runs.append((sd.n_accepted, sd.param_est(0)[2]))
+    assert runs[0][0] == runs[1][0]
+    np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-9, atol=1e-11)
 
 
 def test_nan_ratio_raises_like_numpy():
