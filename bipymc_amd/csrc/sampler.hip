@@ -1492,6 +1492,7 @@ static int ensure_perm_table(bpm_sampler* s, int64_t t, int64_t /*n_ahead*/) {
 // (demc.py:81-86,95-100), gating flags (dream.py:92,123), history row.
 // the host-callback sampler whose generation loop the update kernel compiled around its HIP-source likelihood is driving (run_generations; else nullptr)
 static thread_local bpm_sampler* g_user_cur = nullptr;
+static thread_local bool g_user_launch_failed = false;
 // totals (cr_state) + `cnt` partial sums of one generation -> cr_state: cr_final_kernel on the queue the generation loop runs on
 static int launch_cr_final(bpm_sampler* s, const double* src, uint32_t cnt) {
     const uint32_t n_cr = (uint32_t)s->cfg.n_cr;
@@ -2202,7 +2203,7 @@ static int run_generations_user(bpm_sampler* s, int64_t n_gens);      // (a host
 // the update kernel compiled at run time around a caller's likelihood (bpm_sampler::user_fused_fn): the general instantiation's launch, from a module
 static void launch_user_fused(const PhaseArgs& a, hipStream_t st) {
     bpm_sampler* s = g_user_cur;
-    if (!s || !s->user_fused_fn) return;
+    if (!s || !s->user_fused_fn) { g_user_launch_failed = true; return; }      // (never: run_generations routes here only with the module in place -- and says so if not)
     PhaseArgs ka = a;
     ka.tparams = s->user_params;                   // the caller's parameter block is the target's
     size_t sz = sizeof(ka);
@@ -2313,6 +2314,7 @@ static int run_generations(const Group& g, int64_t n_gens) {
                 }
             }
             CK(rc_gen);
+            if (g_user_launch_failed) { g_user_launch_failed = false; return fail("bpm_step: the update kernel compiled around the HIP-source likelihood was not launched (module gone)"); }
             if (push) for (int r = 0; r < g.R; ++r) g.h[r]->n_push_gens += 1;
             else if (replay) for (int r = 0; r < g.R; ++r) g.h[r]->n_replay_gens += 1;
             ++done;
