@@ -67,4 +67,11 @@ out = [
     entry("cfg5 burn-in + outlier check N=262144", "phase_fused_kernel<1,2,4,2,3,4>", T + "_kernel_stats_cfg5_burnin.csv", "<1, 2, 4, 2, 3, 4>", 592 + 256, 131072, None,
           "level 1 of the CR reduction inside the kernel (round 4), + cr_mid_kernel + cr_final_kernel per generation, outlier check every 50 generations"),
 ]
+# the same loop traced in a torch-free process (profile_bench.sh; profiles/r05_rocprof_torch_artefact.txt): the figure that agrees with bench.py's live one
+nt = T + "_kernel_stats_headline_loop_without_torch.csv"
+if os.path.exists(os.path.join(P, nt)):
+    us, calls = kernel_avg_us(nt, "product::phase_fused_kernel<1, 1, 64, 2, 3, 1>")
+    out[0]["torch_free_trace"] = {"avg_launch_us": us, "launches": calls, "frac": 4096 * 7216 / (us * 1e-6) / 1e9 / PEAK, "source": "profiles/" + nt,
+                                  "note": "under rocprofv3 a process on torch's HIP runtime (bench.py imports torch first) shows a second mode of slow launches "
+                                          "that un-profiled runs do not have; this trace has none"}
 print(json.dumps(out, indent=1))
