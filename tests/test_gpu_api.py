@@ -283,6 +283,54 @@ def test_hip_source_likelihood_through_the_sampler_classes(tmp_path):
     np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=1e-9, atol=1e-11)
 
 
+def test_hip_source_likelihood_on_every_launch_path():
+    """The update kernel compiled around a HIP-source likelihood is dispatched through the library's own queue (found by its lowered name) -- or, without the
+    queue (BPM_DIRECT_QUEUE=0) or on request (BPM_USER_FUSED=2), launched on the HIP stream; BPM_USER_FUSED=0 runs the likelihood as a kernel of its own between
+    the proposal and the commit kernel.  Same draws, same arithmetic in the same order: state, ln-likes, CR statistics and accept counts after a burn-in and a
+    steady stretch are equal bit for bit on all four paths (DREAM d = 100 and d = 8, DE-MC d = 2 with snooker)."""
+    import subprocess
+    import tempfile
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bipymc_amd import _lib as L
+from bipymc_amd.engine import HipEngine
+SRC = """__device__ double ln_like(const double* x, int d, const double* p) {
+    double s = 0.0;
+    for (int j = 0; j < d; ++j) { const double z = (x[j] - p[j]) * p[d + j]; s += z * z; }
+    return -0.5 * s;
+}"""
+out = []
+for algo, d, N, kw in ((L.ALGO_DREAM, 100, 2048, dict(burnin_gen=8, n_cr_gen=2)), (L.ALGO_DREAM, 8, 5000, dict(burnin_gen=8, n_cr_gen=2)),
+                       (L.ALGO_DEMC, 2, 3001, dict(p_snooker=0.2))):
+    e = HipEngine(algo=algo, n_chains=N, dim=d, target_id=L.TARGET_HOST_CALLBACK, target_params=None, seed=11, **kw)
+    e.set_state(np.random.RandomState(d).normal(size=(N, d)))
+    e.set_device_likelihood(SRC, np.concatenate([np.linspace(-1, 1, d), 1.0 / (1.0 + np.arange(d) % 3)]))
+    fused, why = e.device_likelihood_info()
+    assert fused == (os.environ.get("BPM_USER_FUSED", "1") != "0"), why
+    e.begin_run(); e.step(5); e.step(1); e.step(14)
+    st = e.stats()
+    out += [e.get_state(), e.get_loglike(), np.asarray(st["p_cr"], dtype=float), np.array([st["local_n_accepted"], st["local_n_rejected"]], dtype=float)]
+    ls = e.launch_stats()
+    want_direct = fused and os.environ.get("BPM_DIRECT_QUEUE", "1") != "0" and os.environ.get("BPM_USER_FUSED", "1") == "1"
+    assert (ls["direct"] > 0) == want_direct, ls
+    e.close()
+np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
+'''
+    res = []
+    for extra in ({}, {"BPM_DIRECT_QUEUE": "0"}, {"BPM_USER_FUSED": "2"}, {"BPM_USER_FUSED": "0"}):
+        env = dict(os.environ)
+        for k in ("BPM_DIRECT_QUEUE", "BPM_USER_FUSED", "BPM_TEST_PATHS", "BPM_LIB_PATH"):
+            env.pop(k, None)
+        env.update(extra)
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npy")
+            subprocess.check_call([sys.executable, "-c", code, f], env=env, cwd=os.path.join(os.path.dirname(__file__), ".."))
+            res.append(np.load(f))
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)
+
+
 def test_nan_ratio_raises_like_numpy():
     """both ln_like values -inf -> alpha NaN -> the reference's np.random.choice raises ValueError (samplers.py:336)"""
     from bipymc_amd import DeMcMpi
