@@ -1148,8 +1148,9 @@ extern "C" int bpm_create(const bpm_config_t* cfg, bpm_handle_t* out) {
     // (the banana's kernels have the lean form only: its ln_like is a dozen flops)
     s->lean = s->shape.idx < 3 && tid != BPM_TARGET_HOST_CALLBACK &&
               (tid == BPM_TARGET_BANANA_2D || ((s->n_local >= 49152u || test_path("lean")) && !test_path("nolean")));
-    s->hist_by_pos = s->world == 1 && s->shape.idx < 3 && cfg->keep_history != 0 && tid != BPM_TARGET_HOST_CALLBACK && cfg->algo != BPM_ALGO_DEMC_SYNC &&
-                     !test_path("histchain");
+    // (a host-callback sampler: used only while the update kernel compiled around its HIP-source likelihood drives it -- prepare_generation asks g_user_cur;
+    // the proposal / commit kernels of the host transports append by chain)
+    s->hist_by_pos = s->world == 1 && s->shape.idx < 3 && cfg->keep_history != 0 && cfg->algo != BPM_ALGO_DEMC_SYNC && !test_path("histchain");
     if (s->hist_by_pos) CKD(dev_alloc(&s->hist_tmp, (size_t)s->n_local * (s->ld + 1)));
     if (s->cfg.running_moments) {
         s->gs_nb = (uint32_t)std::max<uint32_t>(1u, std::min<uint32_t>(256u, (s->n_local + 63u) / 64u));
@@ -1625,7 +1626,8 @@ static int prepare_generation(bpm_sampler* s, int64_t n_ahead) {
         // (while the outlier check is due every few generations -- DREAM burn-in with outlier_every > 0 -- the ln-like goes by chain: the check sums
         // every chain's ln-like history, and reads the state rows of the few chains it resets where they lie: outlier_row_keys)
         const bool outlier_phase = dream && s->cfg.outlier_every > 0 && s->k_gen < s->cfg.burnin_gen;
-        a.hist_by_pos = (s->hist_by_pos && hist_row != nullptr && !by_chain && !sync && s->trace_i32 == nullptr) ? (outlier_phase ? 2u : 1u) : 0u;
+        a.hist_by_pos = (s->hist_by_pos && (s->cfg.target_id != BPM_TARGET_HOST_CALLBACK || g_user_cur == s) && hist_row != nullptr && !by_chain && !sync &&
+                         s->trace_i32 == nullptr) ? (outlier_phase ? 2u : 1u) : 0u;
         { static const bool wt8 = test_path("wt8"); a.wt = g_wt_stores ? (wt8 ? 1u : 2u) : 0u; }
         a.lean = s->lean ? 1u : 0u;
         a.algo = (uint32_t)s->cfg.algo;

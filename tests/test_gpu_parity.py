@@ -654,6 +654,7 @@ __device__ double ln_like_finish(const double* acc, int d, const double* p) { re
     (R.ALGO_DREAM, 30, 77, dict(burnin_gen=4, n_cr_gen=2, del_pairs=1)),
     (R.ALGO_DEMC, 2, 24, dict(p_snooker=0.3)),
     (R.ALGO_DEMC, 2, 3000, dict()),
+    (R.ALGO_DREAM, 8, 700, dict(burnin_gen=6, n_cr_gen=1, outlier_every=2)),        # 4 lanes per chain, history in shuffle order, the outlier check due
     (R.ALGO_DEMC, 150, 40, dict(p_snooker=0.2)),
     (R.ALGO_DEMC_SYNC, 3, 10, dict()),
     (R.ALGO_DREAM, 600, 12, dict(burnin_gen=5, n_cr_gen=1)),
@@ -670,7 +671,7 @@ def test_hip_source_likelihood_against_oracle(algo, d, N, kw, fused, monkeypatch
         return float(R.ll_gauss_equicorr(theta, params))
 
     eng = _engine(algo=algo, n_chains=N, dim=d, target_id=R.TARGET_HOST, target_params=None, seed=78, **kw)
-    okw = {k: v for k, v in kw.items() if k in ("del_pairs", "burnin_gen", "n_cr_gen", "p_snooker")}
+    okw = {k: v for k, v in kw.items() if k in ("del_pairs", "burnin_gen", "n_cr_gen", "p_snooker", "outlier_every")}
     ora = R.OracleSampler(algo, N, d, R.TARGET_HOST, None, 78, ll_fn=py_ll, **okw)
     X0 = np.random.RandomState(5).normal(size=(N, d)) * np.sqrt(np.arange(d) + 1.0)
     eng.set_state(X0)
