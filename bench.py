@@ -1116,6 +1116,10 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-torch", action="store_true",
+                    help="N = 1 only: keep PyTorch out of the process (synchronisation through the library alone, no measured copy rate, no torch callback entry). "
+                         "For the rocprofv3 kernel trace: under the profiler a process on the torch wheel's HIP runtime shows a second mode of slow launches "
+                         "that un-profiled runs do not have (profiles/r05_rocprof_torch_artefact.txt)")
     ap.add_argument("--no-exchange-alternatives", action="store_true", help="N > 1: skip the untimed runs under the exchanges the headline did not use")
     ap.add_argument("--preheat", type=float, default=0.5, help="seconds of untimed steady-state generations before burn-in (0: none)")
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU, help="experiments only; the default is the BASELINE workload")
@@ -1153,8 +1157,16 @@ def main(argv=None):
     watch.enter("init")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (before anything initialises HSA: dmabuf IPC, what hipIpcGetMemHandle and RCCL need on this pool)
-    import torch                      # first: the HIP runtime is then shared with libbipymc_hip.so
-    ndev = torch.cuda.device_count()
+    if args.no_torch:
+        if world > 1 or os.environ.get("BPM_FORCE_DIST"):
+            sys.stderr.write("bench.py: --no-torch is for N = 1 (the ranks of a world meet through torch.distributed)\n")
+            return 2
+        torch = None
+        from bipymc_amd.demc import _visible_device_count
+        ndev = _visible_device_count()
+    else:
+        import torch                  # first: the HIP runtime is then shared with libbipymc_hip.so
+        ndev = torch.cuda.device_count()
     if ndev <= 0:
         sys.stderr.write("bench.py: no GPU visible (this benchmark has no CPU path)\n")
         return 2
@@ -1269,7 +1281,8 @@ def main(argv=None):
     def fence(what="fence"):
         watch.pending(what + ": bpm_synchronize")
         eng.synchronize()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if dist is not None:
             watch.pending(what + ": dist.barrier")
             dist.barrier()
@@ -1316,7 +1329,10 @@ def main(argv=None):
         watch.pending("the timed region: bpm_step_timed (%d generations) + barrier" % args.steps)
         t0 = time.perf_counter()
         eng.step_timed(args.steps, read=False)
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+        else:
+            eng.synchronize()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -1439,7 +1455,7 @@ def main(argv=None):
                              fence_scope={"push-agent": "agent", "push": "system"}.get(left[0]))
     out = None
     if rank == 0:
-        copy_gbs = measured_copy_bandwidth(torch, local_rank)
+        copy_gbs = measured_copy_bandwidth(torch, local_rank) if torch is not None else None
         out = {
             "metric": "chain-updates/sec" if not args.share_gpu else "REHEARSAL (ranks share one GPU): not a benchmark number",
             "value": value, "unit": "chain-updates/s",
@@ -1470,7 +1486,7 @@ def main(argv=None):
                          "bytes_per_unit": BYTES_PER_UPDATE,
                          "units_per_launch": units_per_launch, "avg_launch_us": k_avg_ms * 1e3,
                          "launches_timed": n_launch, "avg_launch_us_event_pairs": (pair_ms / pair_n * 1e3) if pair_ms > 0 else None,
-                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs},
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
             "posterior": extra,
         }
         if per_rank is not None:
@@ -1524,7 +1540,7 @@ def main(argv=None):
     eng.close()
     if rank == 0:
         watch.enter("extras")
-        if world == 1 and not use_dist and not args.no_other_configs and CHAINS_PER_GPU == 8192:
+        if world == 1 and not use_dist and not args.no_other_configs and not args.no_torch and CHAINS_PER_GPU == 8192:
             watch.pending("other_configs")
             out["configs"] = other_configs(local_rank)
             try:
