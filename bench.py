@@ -1116,6 +1116,10 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--burnin-gens", type=int, default=BURNIN_GEN,
+                    help="burn-in generations (CR adaptation) in front of the steady state (default %d).  0 for the rocprofv3 kernel trace: once the process has run the "
+                         "burn-in kernels the profiler shows a mode of slow steady-state launches that un-profiled runs do not have "
+                         "(profiles/r05_rocprof_torch_artefact.txt)" % BURNIN_GEN)
     ap.add_argument("--no-torch", action="store_true",
                     help="N = 1 only: keep PyTorch out of the process (synchronisation through the library alone, no measured copy rate, no torch callback entry). "
                          "For the rocprofv3 kernel trace: under the profiler a process on the torch wheel's HIP runtime shows a second mode of slow launches "
@@ -1127,6 +1131,7 @@ def main(argv=None):
     ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL ONLY (never a benchmark number): the N ranks share GPU 0 (push exchange "
                     "between processes, no RCCL: it refuses two ranks on one device; torch.distributed over gloo) -- runs every line of the N > 1 path on a one-GPU box")
     args = ap.parse_args(argv)
+    globals()["BURNIN_GEN"] = max(0, int(args.burnin_gens))      # (every use below reads the module attribute)
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")

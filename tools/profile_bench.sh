@@ -16,10 +16,10 @@ echo "kernel trace" >> $O/progress.txt
 # (the DEFAULT invocation's 1000 timed generations, and nothing else of the steady-state kernel in the process: no pre-heat, no posterior gates -- their
 # samplers keep no history and their launches of the same instantiation are ~0.2 us shorter; rounds 2-4 traced the driver's 20 generations behind a
 # 0.1 s pre-heat, i.e. mostly pre-heat launches)
-# (--no-torch: under the profiler a process on the torch wheel's HIP runtime shows a second mode of slow launches -- a fifth of them at 6-7.6 us -- that un-profiled
-# runs do not have, profiles/r05_rocprof_torch_artefact.txt; the flag keeps torch out of the traced process, the run is otherwise the default invocation's;
-# the trace WITH torch is kept beside it)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-other-configs --no-moments --preheat 0 --no-torch > $O/kt.log 2>&1
+# (--no-torch --burnin-gens 0: under the profiler a process that has torch's HIP runtime loaded, or has run the burn-in kernels, shows a mode of slow steady-state
+# launches -- up to a third of them at 6-7.6 us -- that un-profiled runs do not have, profiles/r05_rocprof_torch_artefact.txt; the flags keep both out of the traced
+# process, the timed region is the default invocation's 1000 steady-state generations; the trace of the unmodified command is kept beside it)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-other-configs --no-moments --preheat 0 --no-torch --burnin-gens 0 > $O/kt.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_torch -o kt -- python $R/bench.py --no-cpu-baseline --no-other-configs --no-moments --preheat 0 > $O/kt_torch.log 2>&1
 # ... and the same loop in a process WITHOUT torch (tools/micro/nohist_probe.py): under the profiler a process on torch's HIP runtime shows a second mode (a fifth of
 # the launches at 6-7.6 us) that un-profiled runs do not have (profiles/r05_rocprof_torch_artefact.txt); this trace is the one that agrees with bench.py's live figure

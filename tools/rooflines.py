@@ -55,7 +55,7 @@ out = [
     entry("cfg2 DREAM d=100 N=8192 steady", "phase_fused_kernel<1,1,64,2,3,1>",
           T + ("_kernel_stats_bench_default.csv" if os.path.exists(os.path.join(P, T + "_kernel_stats_bench_default.csv")) else "_kernel_stats_bench_driver.csv"),
           "product::phase_fused_kernel<1, 1, 64, 2, 3, 1>" if os.path.exists(os.path.join(P, T + "_kernel_stats_bench_default.csv")) else "64, 2, 3, 1>", 7216, 4096,
-          traffic(T + "_pmc_bench_driver.txt"), "kernel-trace duration (python bench.py --no-moments --preheat 0 under rocprofv3 --kernel-trace); bench.py reports the back-to-back launch period"),
+          traffic(T + "_pmc_bench_driver.txt"), "kernel-trace duration (python bench.py --no-cpu-baseline --no-other-configs --no-moments --preheat 0 --no-torch --burnin-gens 0 under rocprofv3 --kernel-trace: torch's runtime and the burn-in kernels kept out of the traced process, profiles/r05_rocprof_torch_artefact.txt); bench.py reports the back-to-back launch period"),
     entry("cfg2 burn-in (CR adaptation)", "phase_fused_kernel<1,1,64,2,3,3>", T + "_kernel_stats_cfg2_burnin.csv", "64, 2, 3, 3>", 7216 + 3200, 4096, None,
           "Welford moments r/w add 32 d bytes per update; level 1 of the CR reduction inside the kernel (round 4); the fold of a generation's sums inside the NEXT generation's first launch (round 5: that launch 10.0-10.6 us, the other 8.3-8.7), no reduction dispatch"),
     entry("cfg3 DE-MC banana d=2 N=65536 snooker 0.1", "phase_fused_kernel<0,3,1,2,1,2>", T + "_kernel_stats_cfg3.csv", "<0, 3, 1, 2, 1, 2>", 97.6, 32768,
