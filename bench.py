@@ -1482,6 +1482,7 @@ def main(argv=None):
                        "exchange": dict(xstat or {}, **(exchange_info or {})) if use_dist else None,
                        # how the update kernels were dispatched: packets written by the library into its own AQL queue
                        # (bipymc_amd/csrc/aql_queue.h) or launches on the HIP stream (BPM_DIRECT_QUEUE=0)
+                       "burnin_generations": BURNIN_GEN, "torch_in_the_process": "torch" in sys.modules,
                        "update_dispatches": {"direct_aql_queue": lstat["direct"], "hip_stream": lstat["stream"],
                                              "packet_fence": lstat["fence"]},
                        "final_state_sha256_16": state_sha},

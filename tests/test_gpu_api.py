@@ -331,6 +331,24 @@ np.save(sys.argv[1], np.concatenate([o.reshape(-1) for o in out]))
         assert np.array_equal(res[0], r)
 
 
+def test_bench_runs_without_torch_and_without_burn_in_for_the_kernel_trace():
+    """tools/profile_bench.sh traces `python bench.py ... --no-torch --burnin-gens 0`: under rocprofv3 a process that loaded torch's HIP runtime, or has run the
+    burn-in kernels, shows a mode of slow steady-state launches that un-profiled runs do not have (profiles/r05_rocprof_torch_artefact.txt).  The flags must
+    keep producing the contract's one JSON line -- same metric, same workload, roofline from the live time stamps -- with torch never imported."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs", "--no-moments",
+                        "--preheat", "0", "--no-torch", "--burnin-gens", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["metric"] == "chain-updates/sec" and line["n_gpus"] == 1 and line["steps"] == 40 and line["value"] > 1e8
+    assert line["config"]["torch_in_the_process"] is False and line["config"]["burnin_generations"] == 0
+    assert line["roofline"]["bound"] == "hbm" and 0.3 < line["roofline"]["frac"] < 1.0 and line["roofline"]["measured_copy_GBps"] is None
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-torch"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=root)
+    assert r2.returncode != 0                    # (the ranks of a world meet through torch.distributed: refused, on every rank)
+
+
 def test_nan_ratio_raises_like_numpy():
     """both ln_like values -inf -> alpha NaN -> the reference's np.random.choice raises ValueError (samplers.py:336)"""
     from bipymc_amd import DeMcMpi
